@@ -1,0 +1,188 @@
+/*
+ * retto_hip.h -- C ABI of libretto_hip.so, the MI355X (gfx950) backend for
+ * retto-core's OCR hot path.  Plain pointers and sizes only; no C++/torch types.
+ *
+ * What each entry point replaces in the reference (paths relative to
+ * /root/reference):
+ *
+ *   L1 tensor-level worker  (trait RettoInnerWorker, retto-core/src/worker.rs:69-73;
+ *                            ORT implementation retto-core/src/worker/ort_worker.rs:189-220)
+ *       rt_det / rt_cls / rt_rec
+ *   worker construction     (trait RettoWorker::new/init, worker.rs:91-98; model source
+ *                            resolution worker.rs:18-56; ort_worker.rs:120-181)
+ *       rt_create / rt_destroy
+ *   L2 pipeline             (RettoSession::run / run_stream, retto-core/src/session.rs:75-143)
+ *       rt_run_batch (+ rt_results_* accessors); stage order Det -> Cls -> Rec
+ *   stage functions, exported so each row of SURVEY.md section 8(a) can be checked
+ *   against the oracle on its own:
+ *       rt_resize_both        ImageHelper::resize_both            image_helper.rs:106-148   (a2)
+ *       rt_det_preprocess     DetProcessor::preprocess            det_processor.rs:256-274  (a3)
+ *       rt_det_postprocess    DetProcessor::postprocess           det_processor.rs:279-335  (a5)
+ *       rt_crop_images        ImageHelper::get_crop_img           image_helper.rs:223-249   (a6)
+ *       rt_scale_and_clip     PointBox::scale_and_clip            points.rs:179-194         (a7)
+ *       rt_resize_norm_image  ImageHelper::resize_norm_image      image_helper.rs:176-209   (a8/a10)
+ *       rt_ctc_decode         RecProcessor::postprocess + decode  rec_processor.rs:48-97,190-208 (a12)
+ *
+ * Error convention (retto-core/src/error.rs:2-21): every call returns an rt_status;
+ * rt_last_error() gives the message of the last failure on that session (or of the
+ * last failed rt_create on this thread when session == NULL).
+ *
+ * Threading (worker.rs:70-72, session.rs:108,133 take &mut self): one call in flight
+ * per session; sessions are independent (one per GPU); a session may be used from a
+ * thread other than the one that created it.
+ *
+ * Ownership: caller-owned inputs stay caller-owned; outputs are written into
+ * caller-allocated buffers, except rt_results which is library-owned until
+ * rt_results_free().
+ *
+ * All computation happens on the GPU.  There is no CPU fallback: if no gfx950 device
+ * is visible rt_create fails with RT_ERR_BACKEND.
+ */
+#ifndef RETTO_HIP_H
+#define RETTO_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RT_API __attribute__((visibility("default")))
+
+typedef enum rt_status {
+  RT_OK = 0,
+  RT_ERR_IO = 1,              /* RettoError::IOError */
+  RT_ERR_IMAGE = 2,           /* RettoError::ImageError */
+  RT_ERR_SHAPE = 3,           /* RettoError::ShapeError */
+  RT_ERR_BACKEND = 4,         /* RettoError::OrtError's slot: HIP / device failures */
+  RT_ERR_UTF8 = 5,            /* RettoError::Utf8Error */
+  RT_ERR_MODEL_NOT_FOUND = 7, /* RettoError::ModelNotFoundError */
+  RT_ERR_INVALID = 8,         /* NULL / out-of-range argument */
+  RT_ERR_CAPACITY = 9         /* a device-side work list overflowed its configured capacity */
+} rt_status;
+
+/* RettoWorkerModelSource::{Path,Blob} (worker.rs:18-27): path != NULL selects Path,
+ * otherwise (data,len) is a Blob.  A missing path or an empty blob is
+ * RT_ERR_MODEL_NOT_FOUND (worker.rs:33-47).  Model format: RTWB (retto_amd/synth.py). */
+typedef struct rt_model_source {
+  const char* path;
+  const void* data;
+  size_t len;
+} rt_model_source;
+
+/* RettoSessionConfig + Det/Cls/RecProcessorConfig defaults (session.rs:28-39,
+ * det_processor.rs:75-93, cls_processor.rs:27-36, rec_processor.rs:111-136). */
+typedef struct rt_config {
+  int32_t device_id;         /* HIP device ordinal (RettoOrtWorkerDevice::Cuda(id) analogue) */
+  rt_model_source det, cls, rec, dict;
+  int32_t max_side_len;      /* 2000 */
+  int32_t min_side_len;      /* 30 */
+  /* det */
+  int32_t det_limit_side_len; /* 736 */
+  int32_t det_limit_type;     /* 0 = Min (default), 1 = Max */
+  float det_mean[3];          /* 0.5 */
+  float det_std[3];           /* 0.5 */
+  float det_scale;            /* 1/255 */
+  float det_thresh;           /* 0.3 */
+  float det_box_thresh;       /* 0.5 */
+  float det_unclip_ratio;     /* 1.6 */
+  int32_t det_min_mini_box_size; /* 3 */
+  int32_t det_dilation;       /* 1 = 2x2 ones kernel (default), 0 = none */
+  /* cls */
+  int32_t cls_image_shape[3]; /* 3,48,192 */
+  int32_t cls_batch_num;      /* 6 */
+  float cls_thresh;           /* 0.9 */
+  /* rec */
+  int32_t rec_image_shape[3]; /* 3,48,320 */
+  int32_t rec_batch_num;      /* 6 */
+  /* backend knobs (no reference counterpart) */
+  int32_t max_boxes_per_page; /* capacity of the per-page box list; 0 = default 4096 */
+  int32_t det_sub_batch;      /* pages per det launch group; 0 = default */
+} rt_config;
+
+typedef struct rt_session rt_session;
+typedef struct rt_results rt_results;
+
+RT_API void rt_config_default(rt_config* cfg);
+RT_API int rt_create(const rt_config* cfg, rt_session** out);
+RT_API void rt_destroy(rt_session* s);
+RT_API const char* rt_last_error(const rt_session* s);
+RT_API const char* rt_version(void);
+
+/* ---- L1: RettoInnerWorker (host tensors in, host tensors out) ------------------- */
+/* det: f32 NCHW [n,3,h,w] (h,w multiples of 32) -> f32 [n,1,h,w] */
+RT_API int rt_det(rt_session* s, const float* nchw, int n, int c, int h, int w, float* out);
+/* cls: f32 [n,3,48,192] -> f32 [n,2] (softmax) */
+RT_API int rt_cls(rt_session* s, const float* nchw, int n, int c, int h, int w, float* out);
+/* rec: f32 [n,3,48,w] -> f32 [n,T,6625] (softmax); *t_out = T; call with out == NULL to
+ * query T only. */
+RT_API int rt_rec(rt_session* s, const float* nchw, int n, int c, int h, int w, float* out, int* t_out);
+RT_API int rt_rec_classes(const rt_session* s);
+
+/* ---- stage functions (host buffers; computed on the GPU) ------------------------- */
+RT_API int rt_resize_both_dims(const rt_session* s, int h, int w, int* out_h, int* out_w);
+RT_API int rt_resize_both(rt_session* s, const uint8_t* rgb, int h, int w, uint8_t* out, int out_h, int out_w);
+RT_API int rt_det_input_dims(const rt_session* s, int h, int w, int* out_h, int* out_w);
+/* a3: u8 HWC RGB (after resize_both) -> f32 [1,3,out_h,out_w] */
+RT_API int rt_det_preprocess(rt_session* s, const uint8_t* rgb, int h, int w, float* out_nchw);
+/* a5: f32 [h,w] map -> boxes (n x 8 f32: TL,TR,BR,BL x,y in ori_* coordinates) + scores. */
+RT_API int rt_det_postprocess(rt_session* s, const float* pred, int h, int w, int ori_h, int ori_w,
+                              float* boxes, float* scores, int max_out, int* n_out);
+/* a6: crop sizes for n boxes (w,h after the optional rotate270), then the crops packed
+ * back to back (RGB8) into out (capacity out_cap bytes). */
+RT_API int rt_crop_dims(const float* boxes, int n, int* ws, int* hs);
+RT_API int rt_crop_images(rt_session* s, const uint8_t* rgb, int h, int w, const float* boxes, int n,
+                          uint8_t* out, size_t out_cap);
+RT_API int rt_scale_and_clip(float* boxes, int n, double bitmap_w, double bitmap_h, double ori_w, double ori_h);
+/* a8/a10: one crop -> f32 [3,img_h,W]; W = img_w when max_wh_ratio <= 0 else (int)(img_h*max_wh_ratio). */
+RT_API int rt_resize_norm_width(int img_h, int img_w, float max_wh_ratio);
+RT_API int rt_resize_norm_image(rt_session* s, const uint8_t* crop, int h, int w, int ori_h, int ori_w,
+                                int img_h, int img_w, float max_wh_ratio, float* out_chw);
+/* a12: probs [n,T,C] -> argmax idx [n,T], max prob [n,T], kept tokens [n,T] (+count), score [n] */
+RT_API int rt_ctc_decode(rt_session* s, const float* probs, int n, int t, int c, int32_t* idx, float* prob,
+                         int32_t* tokens, int32_t* n_tokens, float* scores);
+
+/* ---- L2: RettoSession::run over a batch of pages --------------------------------- */
+#define RT_MEM_HOST 0
+#define RT_MEM_DEVICE 1
+/* rgb[i]: RGB8 HWC page i (hs[i] x ws[i]); mem says where the pixels live.
+ * det_map_override (may be NULL, entries may be NULL): f32 [H,W] probability map at the
+ * det input size of page i, same memory space as the pages, used INSTEAD of the det
+ * network's output when building boxes (the network still runs).  This is the hook the
+ * synthetic-weights benchmark and the teacher-forced parity tests use. */
+RT_API int rt_run_batch(rt_session* s, const uint8_t* const* rgb, const int* hs, const int* ws, int n_pages,
+                        int mem, const float* const* det_map_override, rt_results** out);
+RT_API void rt_results_free(rt_results* r);
+RT_API int rt_results_pages(const rt_results* r);
+RT_API int rt_results_count(const rt_results* r, int page);
+/* det: boxes in ORIGINAL image coordinates (session.rs:94-97) */
+RT_API const float* rt_results_boxes(const rt_results* r, int page);      /* n x 8 */
+RT_API const float* rt_results_det_scores(const rt_results* r, int page); /* n */
+RT_API const uint16_t* rt_results_cls_labels(const rt_results* r, int page);
+RT_API const float* rt_results_cls_scores(const rt_results* r, int page);
+RT_API const float* rt_results_rec_scores(const rt_results* r, int page);
+RT_API int rt_results_rec_tokens(const rt_results* r, int page, int line, const int32_t** tokens);
+RT_API const char* rt_results_rec_text(const rt_results* r, int page, int line); /* UTF-8 */
+/* f32 sum of every det probability map produced in the call (keeps the network's
+ * output observable when det_map_override is used) */
+RT_API double rt_results_det_checksum(const rt_results* r);
+/* RettoWorkerStageResult JSON of one page in the serde shape retto-wasm emits
+ * (retto-wasm/fe/index.ts:5-42); stage 0 = det, 1 = cls, 2 = rec. Library-owned. */
+RT_API const char* rt_results_json(rt_results* r, int page, int stage);
+
+/* ---- device memory + timing helpers for harnesses -------------------------------- */
+RT_API int rt_device_malloc(rt_session* s, size_t bytes, void** out);
+RT_API int rt_device_free(rt_session* s, void* p);
+RT_API int rt_memcpy_h2d(rt_session* s, void* dst, const void* src, size_t bytes);
+RT_API int rt_memcpy_d2h(rt_session* s, void* dst, const void* src, size_t bytes);
+RT_API int rt_synchronize(rt_session* s);
+/* Per-kernel-family device time of the last rt_run_batch / L1 call, measured with HIP
+ * events on the session's own stream.  names/ms are library-owned arrays of *n entries. */
+RT_API int rt_profile_enable(rt_session* s, int on);
+RT_API int rt_profile_get(rt_session* s, const char* const** names, const float** ms, const int** calls, int* n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RETTO_HIP_H */

@@ -1,0 +1,212 @@
+// extern "C" surface of libretto_hip.so (include/retto_hip.h).
+#include <cstring>
+#include <new>
+
+#include "geom_math.h"
+#include "session.h"
+
+using namespace rt;
+
+static thread_local std::string g_create_error;
+const char* rt_results_json_impl(rt_results* r, int page, int stage);
+
+template <typename F>
+static int guarded(rt_session* s, F&& f) {
+  try {
+    f();
+    return RT_OK;
+  } catch (const RtError& e) {
+    if (s) s->last_error = e.what(); else g_create_error = e.what();
+    return e.code;
+  } catch (const std::bad_alloc&) {
+    if (s) s->last_error = "out of host memory"; else g_create_error = "out of host memory";
+    return RT_ERR_BACKEND;
+  } catch (const std::exception& e) {
+    if (s) s->last_error = e.what(); else g_create_error = e.what();
+    return RT_ERR_BACKEND;
+  }
+}
+#define RT_REQUIRE(cond, s, msg)                                             \
+  do {                                                                        \
+    if (!(cond)) {                                                            \
+      if (s) (s)->last_error = msg; else g_create_error = msg;                \
+      return RT_ERR_INVALID;                                                  \
+    }                                                                         \
+  } while (0)
+
+extern "C" {
+
+void rt_config_default(rt_config* c) {
+  if (!c) return;
+  memset(c, 0, sizeof(*c));
+  c->device_id = 0;
+  c->max_side_len = 2000; c->min_side_len = 30;
+  c->det_limit_side_len = 736; c->det_limit_type = 0;
+  for (int i = 0; i < 3; i++) { c->det_mean[i] = 0.5f; c->det_std[i] = 0.5f; }
+  c->det_scale = 1.0f / 255.0f;
+  c->det_thresh = 0.3f; c->det_box_thresh = 0.5f; c->det_unclip_ratio = 1.6f;
+  c->det_min_mini_box_size = 3; c->det_dilation = 1;
+  c->cls_image_shape[0] = 3; c->cls_image_shape[1] = 48; c->cls_image_shape[2] = 192;
+  c->cls_batch_num = 6; c->cls_thresh = 0.9f;
+  c->rec_image_shape[0] = 3; c->rec_image_shape[1] = 48; c->rec_image_shape[2] = 320;
+  c->rec_batch_num = 6;
+  c->max_boxes_per_page = 0; c->det_sub_batch = 0;
+}
+
+int rt_create(const rt_config* cfg, rt_session** out) {
+  RT_REQUIRE(cfg && out, (rt_session*)nullptr, "rt_create: null argument");
+  *out = nullptr;
+  RT_REQUIRE(cfg->rec_batch_num > 0 && cfg->cls_batch_num > 0, (rt_session*)nullptr, "batch_num must be positive");
+  RT_REQUIRE(cfg->cls_image_shape[0] == 3 && cfg->rec_image_shape[0] == 3 && cfg->rec_image_shape[1] == 48 &&
+                 cfg->cls_image_shape[1] == 48 && cfg->cls_image_shape[2] == 192,
+             (rt_session*)nullptr, "unsupported cls/rec image_shape for the PP-OCRv4 mobile graphs");
+  return guarded(nullptr, [&] { *out = rt_session_create(cfg); });
+}
+void rt_destroy(rt_session* s) {
+  if (!s) return;
+  (void)hipSetDevice(s->device);
+  if (s->st) { (void)hipStreamSynchronize(s->st); }
+  s->det.reset(); s->cls.reset(); s->rec.reset();
+  if (s->d_flags) (void)hipFree(s->d_flags);
+  if (s->st) (void)hipStreamDestroy(s->st);
+  delete s;
+}
+const char* rt_last_error(const rt_session* s) { return s ? s->last_error.c_str() : g_create_error.c_str(); }
+const char* rt_version(void) { return "retto_hip 0.1.0 (gfx950)"; }
+
+int rt_det(rt_session* s, const float* nchw, int n, int c, int h, int w, float* out) {
+  RT_REQUIRE(s && nchw && out, s, "rt_det: null argument");
+  if (c != 3 || n <= 0 || h <= 0 || w <= 0 || h % 32 || w % 32) { s->last_error = "rt_det: expected [n,3,h,w] with h,w multiples of 32"; return RT_ERR_SHAPE; }
+  return guarded(s, [&] { s->det_forward(nchw, n, h, w, out); });
+}
+int rt_cls(rt_session* s, const float* nchw, int n, int c, int h, int w, float* out) {
+  RT_REQUIRE(s && nchw && out, s, "rt_cls: null argument");
+  if (c != 3 || n <= 0 || h != 48 || w != 192) { s->last_error = "rt_cls: expected [n,3,48,192]"; return RT_ERR_SHAPE; }
+  return guarded(s, [&] { s->cls_forward(nchw, n, h, w, out); });
+}
+int rt_rec(rt_session* s, const float* nchw, int n, int c, int h, int w, float* out, int* t_out) {
+  RT_REQUIRE(s, s, "rt_rec: null session");
+  if (c != 3 || n <= 0 || h != 48 || w < 8) { s->last_error = "rt_rec: expected [n,3,48,w>=8]"; return RT_ERR_SHAPE; }
+  RT_REQUIRE(out == nullptr || nchw != nullptr, s, "rt_rec: null input");
+  return guarded(s, [&] { s->rec_forward(nchw, n, h, w, out, t_out); });
+}
+int rt_rec_classes(const rt_session* s) { return s ? s->rec->classes() : 0; }
+
+int rt_resize_both_dims(const rt_session* s, int h, int w, int* out_h, int* out_w) {
+  if (!s || !out_h || !out_w) return RT_ERR_INVALID;
+  int plan[4];
+  int n = gm::resize_both_plan(h, w, s->cfg.max_side_len, s->cfg.min_side_len, plan);
+  *out_h = n ? plan[2 * (n - 1)] : h; *out_w = n ? plan[2 * (n - 1) + 1] : w;
+  return RT_OK;
+}
+int rt_resize_both(rt_session* s, const uint8_t* rgb, int h, int w, uint8_t* out, int out_h, int out_w) {
+  RT_REQUIRE(s && rgb && out && h > 0 && w > 0, s, "rt_resize_both: bad argument");
+  return guarded(s, [&] { s->resize_both(rgb, h, w, out, out_h, out_w); });
+}
+int rt_det_input_dims(const rt_session* s, int h, int w, int* out_h, int* out_w) {
+  if (!s || !out_h || !out_w) return RT_ERR_INVALID;
+  gm::resize_either_dims(h, w, s->cfg.det_limit_type, s->cfg.det_limit_side_len, out_h, out_w);
+  return RT_OK;
+}
+int rt_det_preprocess(rt_session* s, const uint8_t* rgb, int h, int w, float* out_nchw) {
+  RT_REQUIRE(s && rgb && out_nchw && h > 0 && w > 0, s, "rt_det_preprocess: bad argument");
+  return guarded(s, [&] { s->det_preprocess(rgb, h, w, out_nchw); });
+}
+int rt_det_postprocess(rt_session* s, const float* pred, int h, int w, int ori_h, int ori_w, float* boxes, float* scores,
+                       int max_out, int* n_out) {
+  RT_REQUIRE(s && pred && boxes && scores && n_out && h > 0 && w > 0, s, "rt_det_postprocess: bad argument");
+  return guarded(s, [&] { s->det_postprocess(pred, h, w, ori_h, ori_w, boxes, scores, max_out, n_out); });
+}
+int rt_crop_dims(const float* boxes, int n, int* ws, int* hs) {
+  if (!boxes || !ws || !hs) return RT_ERR_INVALID;
+  for (int i = 0; i < n; i++) {
+    gm::CropDims d = gm::crop_dims(boxes + 8 * i);
+    ws[i] = d.rot ? d.h : d.w; hs[i] = d.rot ? d.w : d.h;
+  }
+  return RT_OK;
+}
+int rt_crop_images(rt_session* s, const uint8_t* rgb, int h, int w, const float* boxes, int n, uint8_t* out, size_t out_cap) {
+  RT_REQUIRE(s && rgb && boxes && out && h > 0 && w > 0 && n >= 0, s, "rt_crop_images: bad argument");
+  return guarded(s, [&] { s->crop_images(rgb, h, w, boxes, n, out, out_cap); });
+}
+int rt_scale_and_clip(float* boxes, int n, double bitmap_w, double bitmap_h, double ori_w, double ori_h) {
+  if (!boxes) return RT_ERR_INVALID;
+  for (int i = 0; i < n; i++) gm::scale_and_clip(boxes + 8 * i, bitmap_w, bitmap_h, ori_w, ori_h);
+  return RT_OK;
+}
+int rt_resize_norm_width(int img_h, int img_w, float max_wh_ratio) { return gm::resize_norm_width(img_h, img_w, max_wh_ratio); }
+int rt_resize_norm_image(rt_session* s, const uint8_t* crop, int h, int w, int ori_h, int ori_w, int img_h, int img_w,
+                         float max_wh_ratio, float* out_chw) {
+  RT_REQUIRE(s && crop && out_chw && h > 0 && w > 0 && img_h > 0, s, "rt_resize_norm_image: bad argument");
+  return guarded(s, [&] { s->resize_norm_image(crop, h, w, ori_h, ori_w, img_h, img_w, max_wh_ratio, out_chw); });
+}
+int rt_ctc_decode(rt_session* s, const float* probs, int n, int t, int c, int32_t* idx, float* prob, int32_t* tokens,
+                  int32_t* n_tokens, float* scores) {
+  RT_REQUIRE(s && probs && idx && prob && tokens && n_tokens && scores && n > 0 && t > 0 && c > 0, s, "rt_ctc_decode: bad argument");
+  return guarded(s, [&] { s->ctc_decode(probs, n, t, c, idx, prob, tokens, n_tokens, scores); });
+}
+
+int rt_run_batch(rt_session* s, const uint8_t* const* rgb, const int* hs, const int* ws, int n_pages, int mem,
+                 const float* const* det_map_override, rt_results** out) {
+  RT_REQUIRE(s && out && n_pages >= 0 && (n_pages == 0 || (rgb && hs && ws)), s, "rt_run_batch: bad argument");
+  RT_REQUIRE(mem == RT_MEM_HOST || mem == RT_MEM_DEVICE, s, "rt_run_batch: bad mem kind");
+  *out = nullptr;
+  return guarded(s, [&] { *out = s->run_batch(rgb, hs, ws, n_pages, mem, det_map_override); });
+}
+void rt_results_free(rt_results* r) { delete r; }
+int rt_results_pages(const rt_results* r) { return r ? (int)r->pages.size() : 0; }
+#define RT_PAGE(r, page) ((r) && (page) >= 0 && (size_t)(page) < (r)->pages.size() ? &(r)->pages[(size_t)(page)] : nullptr)
+int rt_results_count(const rt_results* r, int page) { auto* p = RT_PAGE(r, page); return p ? (int)p->det_scores.size() : 0; }
+const float* rt_results_boxes(const rt_results* r, int page) { auto* p = RT_PAGE(r, page); return p ? p->boxes.data() : nullptr; }
+const float* rt_results_det_scores(const rt_results* r, int page) { auto* p = RT_PAGE(r, page); return p ? p->det_scores.data() : nullptr; }
+const uint16_t* rt_results_cls_labels(const rt_results* r, int page) { auto* p = RT_PAGE(r, page); return p ? p->cls_labels.data() : nullptr; }
+const float* rt_results_cls_scores(const rt_results* r, int page) { auto* p = RT_PAGE(r, page); return p ? p->cls_scores.data() : nullptr; }
+const float* rt_results_rec_scores(const rt_results* r, int page) { auto* p = RT_PAGE(r, page); return p ? p->rec_scores.data() : nullptr; }
+int rt_results_rec_tokens(const rt_results* r, int page, int line, const int32_t** tokens) {
+  auto* p = RT_PAGE(r, page);
+  if (!p || line < 0 || (size_t)line >= p->tokens.size()) return 0;
+  if (tokens) *tokens = p->tokens[(size_t)line].data();
+  return (int)p->tokens[(size_t)line].size();
+}
+const char* rt_results_rec_text(const rt_results* r, int page, int line) {
+  auto* p = RT_PAGE(r, page);
+  if (!p || line < 0 || (size_t)line >= p->text.size()) return nullptr;
+  return p->text[(size_t)line].c_str();
+}
+double rt_results_det_checksum(const rt_results* r) { return r ? r->det_checksum : 0.0; }
+const char* rt_results_json(rt_results* r, int page, int stage) {
+  if (!RT_PAGE(r, page) || stage < 0 || stage > 2) return nullptr;
+  return rt_results_json_impl(r, page, stage);
+}
+
+int rt_device_malloc(rt_session* s, size_t bytes, void** out) {
+  RT_REQUIRE(s && out, s, "rt_device_malloc: null argument");
+  return guarded(s, [&] { RT_HIP_CHECK(hipSetDevice(s->device)); RT_HIP_CHECK(hipMalloc(out, bytes)); });
+}
+int rt_device_free(rt_session* s, void* p) {
+  RT_REQUIRE(s, s, "rt_device_free: null session");
+  return guarded(s, [&] { RT_HIP_CHECK(hipSetDevice(s->device)); RT_HIP_CHECK(hipFree(p)); });
+}
+int rt_memcpy_h2d(rt_session* s, void* dst, const void* src, size_t bytes) {
+  RT_REQUIRE(s && dst && src, s, "rt_memcpy_h2d: null argument");
+  return guarded(s, [&] { RT_HIP_CHECK(hipSetDevice(s->device)); RT_HIP_CHECK(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice)); });
+}
+int rt_memcpy_d2h(rt_session* s, void* dst, const void* src, size_t bytes) {
+  RT_REQUIRE(s && dst && src, s, "rt_memcpy_d2h: null argument");
+  return guarded(s, [&] { RT_HIP_CHECK(hipSetDevice(s->device)); RT_HIP_CHECK(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost)); });
+}
+int rt_synchronize(rt_session* s) {
+  RT_REQUIRE(s, s, "rt_synchronize: null session");
+  return guarded(s, [&] { RT_HIP_CHECK(hipSetDevice(s->device)); RT_HIP_CHECK(hipDeviceSynchronize()); });
+}
+int rt_profile_enable(rt_session* s, int on) {
+  RT_REQUIRE(s, s, "rt_profile_enable: null session");
+  return guarded(s, [&] { s->prof.clear(); s->prof.on = on != 0; });
+}
+int rt_profile_get(rt_session* s, const char* const** names, const float** ms, const int** calls, int* n) {
+  RT_REQUIRE(s && names && ms && calls && n, s, "rt_profile_get: null argument");
+  *names = s->prof.names.data(); *ms = s->prof.ms.data(); *calls = s->prof.calls.data(); *n = (int)s->prof.names.size();
+  return RT_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,47 @@
+// Shared host/device declarations for libretto_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <stdexcept>
+#include <string>
+
+namespace rt {
+
+// One image of a ragged batch at some pyramid level: `off` = index of its first
+// pixel in the level's concatenated NHWC activation buffer.
+struct ImgGeom {
+  long long off;
+  int H, W;
+  int pad_;
+};
+
+enum Act { ACT_NONE = 0, ACT_RELU = 1, ACT_HSWISH = 2, ACT_SWISH = 3, ACT_SIGMOID = 4 };
+
+// Fused conv/GEMM epilogue: y = lab(act(acc + bias)) [+ residual]
+struct Epilogue {
+  const float* bias;      // [Npad16] zero padded, or nullptr
+  int act;                // Act
+  int has_lab;            // LCNetV3 LearnableAffineBlock after the activation
+  float lab_a, lab_c;
+  const float* residual;  // optional, same row indexing as the output
+  int ld_res;
+};
+
+struct RtError : std::runtime_error {
+  int code;
+  RtError(int c, const std::string& m) : std::runtime_error(m), code(c) {}
+};
+
+#define RT_HIP_CHECK(expr)                                                                       \
+  do {                                                                                           \
+    hipError_t e__ = (expr);                                                                     \
+    if (e__ != hipSuccess)                                                                       \
+      throw ::rt::RtError(4, std::string(#expr) + ": " + hipGetErrorString(e__) + " (" __FILE__ ":" + \
+                                 std::to_string(__LINE__) + ")");                                \
+  } while (0)
+
+static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+static inline long long round_up_ll(long long v, long long m) { return (v + m - 1) / m * m; }
+
+}  // namespace rt

@@ -1,0 +1,488 @@
+#include "nets.h"
+
+#include <cstring>
+
+namespace rt {
+
+// ---------------------------------------------------------------------------
+// levels
+// ---------------------------------------------------------------------------
+static void finish_level(Level& L) {
+  long long off = 0;
+  L.maxH = L.maxW = 0; L.maxPix = 0;
+  for (auto& g : L.h) {
+    g.off = off; g.pad_ = 0;
+    off += (long long)g.H * g.W;
+    L.maxH = std::max(L.maxH, g.H); L.maxW = std::max(L.maxW, g.W);
+    L.maxPix = std::max(L.maxPix, (long long)g.H * g.W);
+  }
+  L.total = off;
+}
+Level make_level(const std::vector<std::pair<int, int>>& hw) {
+  Level L;
+  for (auto& p : hw) L.h.push_back(ImgGeom{0, p.first, p.second, 0});
+  finish_level(L);
+  return L;
+}
+Level down_level(const Level& in, int sh, int sw) {
+  Level L;
+  for (auto& g : in.h) L.h.push_back(ImgGeom{0, (g.H - 1) / sh + 1, (g.W - 1) / sw + 1, 0});
+  finish_level(L);
+  return L;
+}
+Level pool_level(const Level& in, int kh, int kw) {
+  Level L;
+  for (auto& g : in.h) L.h.push_back(ImgGeom{0, g.H >= kh ? (g.H - kh) / kh + 1 : 0, g.W >= kw ? (g.W - kw) / kw + 1 : 0, 0});
+  finish_level(L);
+  return L;
+}
+void upload_levels(RunCtx& c, std::vector<Level*> levels) {
+  size_t total = 0;
+  for (auto* L : levels) total += L->h.size();
+  if (total == 0) return;
+  ImgGeom* hbuf = c.pinned->alloc<ImgGeom>(total);
+  ImgGeom* dbuf = c.arena->alloc<ImgGeom>(total);
+  size_t o = 0;
+  for (auto* L : levels) {
+    memcpy(hbuf + o, L->h.data(), L->h.size() * sizeof(ImgGeom));
+    L->d = dbuf + o;
+    o += L->h.size();
+  }
+  RT_HIP_CHECK(hipMemcpyAsync(dbuf, hbuf, total * sizeof(ImgGeom), hipMemcpyHostToDevice, c.st));
+}
+
+// ---------------------------------------------------------------------------
+// weights
+// ---------------------------------------------------------------------------
+WeightStore::~WeightStore() { for (void* p : bufs_) (void)hipFree(p); }
+float* WeightStore::upload(const std::vector<float>& host) {
+  void* p = nullptr;
+  size_t bytes = std::max<size_t>(host.size(), 4) * sizeof(float);
+  RT_HIP_CHECK(hipMalloc(&p, bytes));
+  RT_HIP_CHECK(hipMemcpy(p, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice));
+  bufs_.push_back(p); total_ += bytes;
+  return (float*)p;
+}
+
+static void expect_dims(const BlobTensor& t, std::initializer_list<int> d, const std::string& name) {
+  if (t.dims != std::vector<int>(d)) throw RtError(3, "RTWB: unexpected shape for " + name);
+}
+
+// conv weight [cout, cin, kh, kw] -> [nkc][taps][Npad][KC]
+static PackedDense pack_conv(WeightStore& ws, const Blob& b, const std::string& name, int cout, int cin, int kh, int kw) {
+  const BlobTensor& w = b.get(name + ".w");
+  expect_dims(w, {cout, cin, kh, kw}, name + ".w");
+  PackedDense p;
+  p.K = round_up(cin, 4); p.N = cout; p.Npad = round_up(cout, 16); p.kh = kh; p.kw = kw;
+  const int taps = kh * kw, nkc = (p.K + nn::KC - 1) / nn::KC;
+  std::vector<float> host((size_t)nkc * taps * p.Npad * nn::KC, 0.f);
+  for (int n = 0; n < cout; n++)
+    for (int k = 0; k < cin; k++)
+      for (int t = 0; t < taps; t++) {
+        int kc = k / nn::KC, kk = k % nn::KC;
+        host[(((size_t)kc * taps + t) * p.Npad + n) * nn::KC + kk] = w.data[((size_t)n * cin + k) * taps + t];
+      }
+  p.w = ws.upload(host);
+  std::vector<float> bias(p.Npad, 0.f);
+  if (b.has(name + ".b")) {
+    const BlobTensor& bt = b.get(name + ".b");
+    expect_dims(bt, {cout}, name + ".b");
+    memcpy(bias.data(), bt.data, cout * sizeof(float));
+  }
+  p.b = ws.upload(bias);
+  return p;
+}
+// linear weight [in, out]
+static PackedDense pack_linear(WeightStore& ws, const Blob& b, const std::string& name, int cin, int cout) {
+  const BlobTensor& w = b.get(name + ".w");
+  expect_dims(w, {cin, cout}, name + ".w");
+  PackedDense p;
+  p.K = round_up(cin, 4); p.N = cout; p.Npad = round_up(cout, 16);
+  const int nkc = (p.K + nn::KC - 1) / nn::KC;
+  std::vector<float> host((size_t)nkc * p.Npad * nn::KC, 0.f);
+  for (int k = 0; k < cin; k++)
+    for (int n = 0; n < cout; n++)
+      host[((size_t)(k / nn::KC) * p.Npad + n) * nn::KC + (k % nn::KC)] = w.data[(size_t)k * cout + n];
+  p.w = ws.upload(host);
+  std::vector<float> bias(p.Npad, 0.f);
+  const BlobTensor& bt = b.get(name + ".b");
+  expect_dims(bt, {cout}, name + ".b");
+  memcpy(bias.data(), bt.data, cout * sizeof(float));
+  p.b = ws.upload(bias);
+  return p;
+}
+static PackedDw pack_dw(WeightStore& ws, const Blob& b, const std::string& name, int C, int k) {
+  const BlobTensor& w = b.get(name + ".w");
+  expect_dims(w, {C, 1, k, k}, name + ".w");
+  PackedDw p; p.k = k; p.C = C; p.Cp = round_up(C, 4);
+  std::vector<float> host((size_t)k * k * p.Cp, 0.f), bias(p.Cp, 0.f);
+  for (int c = 0; c < C; c++)
+    for (int t = 0; t < k * k; t++) host[(size_t)t * p.Cp + c] = w.data[(size_t)c * k * k + t];
+  const BlobTensor& bt = b.get(name + ".b");
+  expect_dims(bt, {C}, name + ".b");
+  memcpy(bias.data(), bt.data, C * sizeof(float));
+  p.w = ws.upload(host); p.b = ws.upload(bias);
+  return p;
+}
+static void pack_stem(WeightStore& ws, const Blob& b, const std::string& name, int cout, float** w_out, float** b_out) {
+  const BlobTensor& w = b.get(name + ".w");
+  expect_dims(w, {cout, 3, 3, 3}, name + ".w");
+  std::vector<float> host(27 * cout), bias(cout);
+  for (int n = 0; n < cout; n++)
+    for (int ci = 0; ci < 3; ci++)
+      for (int t = 0; t < 9; t++) host[(t * 3 + ci) * cout + n] = w.data[(n * 3 + ci) * 9 + t];
+  const BlobTensor& bt = b.get(name + ".b");
+  expect_dims(bt, {cout}, name + ".b");
+  memcpy(bias.data(), bt.data, cout * sizeof(float));
+  *w_out = ws.upload(host); *b_out = ws.upload(bias);
+}
+static Lab get_lab(const Blob& b, const std::string& name) {
+  Lab l;
+  if (b.has(name + ".a")) { l.has = 1; l.a = b.get(name + ".a").data[0]; l.c = b.get(name + ".c").data[0]; }
+  return l;
+}
+static float* upload_raw(WeightStore& ws, const Blob& b, const std::string& name, size_t expect_numel) {
+  const BlobTensor& t = b.get(name);
+  if (t.numel() != expect_numel) throw RtError(3, "RTWB: unexpected size for " + name);
+  return ws.upload(std::vector<float>(t.data, t.data + t.numel()));
+}
+static SeW get_se(WeightStore& ws, const Blob& b, const std::string& name, int C) {
+  SeW s; s.C = C; s.Cr = C / 4;
+  s.w1 = upload_raw(ws, b, name + ".fc1.w", (size_t)s.Cr * C); s.b1 = upload_raw(ws, b, name + ".fc1.b", s.Cr);
+  s.w2 = upload_raw(ws, b, name + ".fc2.w", (size_t)s.Cr * C); s.b2 = upload_raw(ws, b, name + ".fc2.b", C);
+  return s;
+}
+
+struct LcSpec { const char* name; int k, cin, cout, sh, sw; bool se; };
+static const LcSpec DET_SPEC[] = {
+    {"s2.0", 3, 16, 32, 1, 1, false}, {"s3.0", 3, 32, 48, 2, 2, false}, {"s3.1", 3, 48, 48, 1, 1, false},
+    {"s4.0", 3, 48, 96, 2, 2, false}, {"s4.1", 3, 96, 96, 1, 1, false}, {"s5.0", 3, 96, 192, 2, 2, false},
+    {"s5.1", 5, 192, 192, 1, 1, false}, {"s5.2", 5, 192, 192, 1, 1, false}, {"s5.3", 5, 192, 192, 1, 1, false},
+    {"s5.4", 5, 192, 192, 1, 1, false}, {"s6.0", 5, 192, 384, 2, 2, true}, {"s6.1", 5, 384, 384, 1, 1, true},
+    {"s6.2", 5, 384, 384, 1, 1, false}, {"s6.3", 5, 384, 384, 1, 1, false}};
+static const LcSpec REC_SPEC[] = {
+    {"s2.0", 3, 16, 32, 1, 1, false}, {"s3.0", 3, 32, 64, 1, 1, false}, {"s3.1", 3, 64, 64, 1, 1, false},
+    {"s4.0", 3, 64, 128, 2, 1, false}, {"s4.1", 3, 128, 128, 1, 1, false}, {"s5.0", 3, 128, 240, 1, 2, false},
+    {"s5.1", 5, 240, 240, 1, 1, false}, {"s5.2", 5, 240, 240, 1, 1, false}, {"s5.3", 5, 240, 240, 1, 1, false},
+    {"s5.4", 5, 240, 240, 1, 1, false}, {"s6.0", 5, 240, 480, 2, 1, true}, {"s6.1", 5, 480, 480, 1, 1, true},
+    {"s6.2", 5, 480, 480, 2, 1, false}, {"s6.3", 5, 480, 480, 1, 1, false}};
+
+static LcBlock build_lc(WeightStore& ws, const Blob& b, const std::string& prefix, const LcSpec& s) {
+  LcBlock blk;
+  std::string p = prefix + "." + s.name;
+  blk.dw = pack_dw(ws, b, p + ".dw", s.cin, s.k);
+  blk.dw_lab = get_lab(b, p + ".dw");
+  blk.dw_act = blk.dw_lab.has ? ACT_HSWISH : ACT_NONE;  // LearnableRepLayer: act only when stride != 2
+  blk.se = s.se;
+  if (s.se) blk.sew = get_se(ws, b, p + ".se", s.cin);
+  blk.pw = pack_conv(ws, b, p + ".pw", s.cout, s.cin, 1, 1);
+  blk.pw_lab = get_lab(b, p + ".pw");
+  blk.sh = s.sh; blk.sw = s.sw; blk.cin = s.cin; blk.cout = s.cout;
+  return blk;
+}
+
+static Epilogue make_epi(const PackedDense& p, int act, const Lab* lab = nullptr, const float* residual = nullptr,
+                         int ld_res = 0) {
+  Epilogue e;
+  e.bias = p.b; e.act = act;
+  e.has_lab = lab ? lab->has : 0; e.lab_a = lab ? lab->a : 1.f; e.lab_c = lab ? lab->c : 0.f;
+  e.residual = residual; e.ld_res = ld_res;
+  return e;
+}
+
+static void run_se(RunCtx& c, float* x, const Level& L, const SeW& se, float slope, int residual) {
+  int Cp = round_up(se.C, 4);
+  float* partial = c.arena->alloc<float>((size_t)L.n() * nn::pool_chunks(L.maxPix) * Cp);
+  float* scale = c.arena->alloc<float>((size_t)L.n() * Cp);
+  { ProfScope ps(c.prof, c.st, "se_pool_fc");
+    nn::se_scale(c.st, x, L.d, L.n(), L.maxPix, se.C, Cp, se.w1, se.b1, se.w2, se.b2, se.Cr, slope, residual, partial, scale); }
+  { ProfScope ps(c.prof, c.st, "scale_channels");
+    nn::scale_channels(c.st, x, L.d, L.n(), L.maxPix, Cp, scale); }
+}
+
+static const float HSIG_LCNET = 0.1666667f;  // paddle nn.Hardsigmoid
+static const float HSIG_MBV3 = 0.2f;         // F.hardsigmoid(slope=0.2, offset=0.5)
+
+static float* run_lc(RunCtx& c, const LcBlock& b, const float* x, const Level& Lin, const Level& Lout) {
+  float* y1 = c.arena->alloc<float>((size_t)Lout.total * b.dw.Cp);
+  { ProfScope ps(c.prof, c.st, b.dw.k == 3 ? "dwconv3" : "dwconv5");
+    nn::dwconv(c.st, b.dw.k, b.sh, b.sw, x, Lin.d, Lout.d, Lout.n(), Lout.maxH, Lout.maxW, b.dw.Cp, b.dw.w, b.dw.b,
+               b.dw_act, b.dw_lab.has, b.dw_lab.a, b.dw_lab.c, y1); }
+  if (b.se) run_se(c, y1, Lout, b.sew, HSIG_LCNET, 0);
+  int Cpo = round_up(b.cout, 4);
+  float* y2 = c.arena->alloc<float>((size_t)Lout.total * Cpo);
+  { ProfScope ps(c.prof, c.st, "gemm_pw");
+    nn::gemm(c.st, y1, b.dw.Cp, Lout.total, b.pw.K, b.pw.w, b.pw.N, b.pw.Npad, y2, Cpo, 0,
+             make_epi(b.pw, ACT_HSWISH, &b.pw_lab)); }
+  return y2;
+}
+
+// ---------------------------------------------------------------------------
+// DetNet
+// ---------------------------------------------------------------------------
+DetNet::DetNet(const Blob& b) {
+  pack_stem(ws_, b, "det.stem", 16, &stem_w_, &stem_b_);
+  for (const LcSpec& s : DET_SPEC) blocks_.push_back(build_lc(ws_, b, "det", s));
+  tap_after_[0] = 2; tap_after_[1] = 4; tap_after_[2] = 9; tap_after_[3] = 13;
+  const int tap_c[4] = {48, 96, 192, 384}, out_c[4] = {12, 18, 42, 360};
+  for (int j = 0; j < 4; j++) {
+    std::string js = std::to_string(j);
+    out_[j] = pack_conv(ws_, b, "det.out" + js, out_c[j], tap_c[j], 1, 1);
+    ins_[j] = pack_conv(ws_, b, "det.fpn.ins" + js, 96, out_c[j], 1, 1);
+    ins_se_[j] = get_se(ws_, b, "det.fpn.ins" + js + ".se", 96);
+    inp_[j] = pack_conv(ws_, b, "det.fpn.inp" + js, 24, 96, 3, 3);
+    inp_se_[j] = get_se(ws_, b, "det.fpn.inp" + js + ".se", 24);
+  }
+  head_conv1_ = pack_conv(ws_, b, "det.head.conv1", 24, 96, 3, 3);
+  dc1_w_ = upload_raw(ws_, b, "det.head.deconv1.w", 24 * 24 * 4); dc1_b_ = upload_raw(ws_, b, "det.head.deconv1.b", 24);
+  dc2_w_ = upload_raw(ws_, b, "det.head.deconv2.w", 24 * 4); dc2_b_ = upload_raw(ws_, b, "det.head.deconv2.b", 1);
+}
+
+float* DetNet::run(RunCtx& c, const float* x, Level& L0) {
+  for (auto& g : L0.h)
+    if (g.H % 32 != 0 || g.W % 32 != 0 || g.H == 0 || g.W == 0) throw RtError(3, "det input sides must be non-zero multiples of 32");
+  Level L2 = down_level(L0, 2, 2), L4 = down_level(L2, 2, 2), L8 = down_level(L4, 2, 2), L16 = down_level(L8, 2, 2),
+        L32 = down_level(L16, 2, 2);
+  upload_levels(c, {&L0, &L2, &L4, &L8, &L16, &L32});
+  Level* lv[6] = {&L0, &L2, &L4, &L8, &L16, &L32};
+  float* t = c.arena->alloc<float>((size_t)L2.total * 16);
+  { ProfScope ps(c.prof, c.st, "stem");
+    nn::stem_conv(c.st, x, L0.d, L2.d, L2.n(), L2.maxH, L2.maxW, 16, stem_w_, stem_b_, ACT_NONE, t); }
+  int li = 1;
+  float* taps[4] = {nullptr, nullptr, nullptr, nullptr};
+  Level* tap_lv[4] = {nullptr, nullptr, nullptr, nullptr};
+  for (size_t i = 0; i < blocks_.size(); i++) {
+    const LcBlock& b = blocks_[i];
+    Level* Lin = lv[li];
+    if (b.sh == 2) li++;
+    t = run_lc(c, b, t, *Lin, *lv[li]);
+    for (int j = 0; j < 4; j++)
+      if (tap_after_[j] == (int)i) {
+        int Cpo = round_up(out_[j].N, 4);
+        float* o = c.arena->alloc<float>((size_t)lv[li]->total * Cpo);
+        ProfScope ps(c.prof, c.st, "gemm_misc");
+        nn::gemm(c.st, t, round_up(b.cout, 4), lv[li]->total, out_[j].K, out_[j].w, out_[j].N, out_[j].Npad, o, Cpo, 0,
+                 make_epi(out_[j], ACT_NONE));
+        taps[j] = o; tap_lv[j] = lv[li];
+      }
+  }
+  // RSEFPN
+  float* in[4];
+  for (int j = 3; j >= 0; j--) {
+    in[j] = c.arena->alloc<float>((size_t)tap_lv[j]->total * 96);
+    { ProfScope ps(c.prof, c.st, "gemm_misc");
+      nn::gemm(c.st, taps[j], round_up(out_[j].N, 4), tap_lv[j]->total, ins_[j].K, ins_[j].w, 96, ins_[j].Npad, in[j], 96,
+               0, make_epi(ins_[j], ACT_NONE)); }
+    run_se(c, in[j], *tap_lv[j], ins_se_[j], HSIG_MBV3, 1);
+  }
+  for (int j = 2; j >= 0; j--) {
+    ProfScope ps(c.prof, c.st, "upsample_add");
+    nn::upsample_add(c.st, in[j], in[j + 1], tap_lv[j]->d, tap_lv[j + 1]->d, tap_lv[j]->n(), tap_lv[j]->maxPix, 96, in[j]);
+  }
+  float* p[4];
+  for (int j = 3; j >= 0; j--) {
+    p[j] = c.arena->alloc<float>((size_t)tap_lv[j]->total * 24);
+    { ProfScope ps(c.prof, c.st, "conv3x3");
+      nn::conv_sp(c.st, 3, 3, in[j], 96, tap_lv[j]->d, tap_lv[j]->n(), tap_lv[j]->maxH, tap_lv[j]->maxW, 96, inp_[j].w, 24,
+                  inp_[j].Npad, p[j], 24, make_epi(inp_[j], ACT_NONE)); }
+    run_se(c, p[j], *tap_lv[j], inp_se_[j], HSIG_MBV3, 1);
+  }
+  float* fuse = c.arena->alloc<float>((size_t)L4.total * 96);
+  { ProfScope ps(c.prof, c.st, "fpn_concat");
+    nn::fpn_concat(c.st, p[3], p[2], p[1], p[0], L32.d, L16.d, L8.d, L4.d, L4.n(), L4.maxPix, 24, fuse); }
+  float* h1 = c.arena->alloc<float>((size_t)L4.total * 24);
+  { ProfScope ps(c.prof, c.st, "conv3x3");
+    nn::conv_sp(c.st, 3, 3, fuse, 96, L4.d, L4.n(), L4.maxH, L4.maxW, 96, head_conv1_.w, 24, head_conv1_.Npad, h1, 24,
+                make_epi(head_conv1_, ACT_RELU)); }
+  float* map = c.arena->alloc<float>((size_t)L0.total);
+  { ProfScope ps(c.prof, c.st, "db_head_tail");
+    nn::db_head_tail(c.st, h1, L4.d, L0.d, L4.n(), L4.maxPix, dc1_w_, dc1_b_, dc2_w_, dc2_b_, map); }
+  return map;
+}
+
+// ---------------------------------------------------------------------------
+// RecNet
+// ---------------------------------------------------------------------------
+RecNet::RecNet(const Blob& b) {
+  pack_stem(ws_, b, "rec.stem", 16, &stem_w_, &stem_b_);
+  for (const LcSpec& s : REC_SPEC) blocks_.push_back(build_lc(ws_, b, "rec", s));
+  const int C = 480, D = 120;
+  conv1_ = pack_conv(ws_, b, "rec.neck.conv1", C / 8, C, 1, 3);
+  conv2_ = pack_conv(ws_, b, "rec.neck.conv2", D, C / 8, 1, 1);
+  for (int i = 0; i < 2; i++) {
+    std::string p = "rec.neck.blk" + std::to_string(i);
+    blk_[i].qkv = pack_linear(ws_, b, p + ".qkv", D, 3 * D);
+    blk_[i].proj = pack_linear(ws_, b, p + ".proj", D, D);
+    blk_[i].fc1 = pack_linear(ws_, b, p + ".fc1", D, 2 * D);
+    blk_[i].fc2 = pack_linear(ws_, b, p + ".fc2", 2 * D, D);
+    blk_[i].n1g = upload_raw(ws_, b, p + ".norm1.g", D); blk_[i].n1b = upload_raw(ws_, b, p + ".norm1.beta", D);
+    blk_[i].n2g = upload_raw(ws_, b, p + ".norm2.g", D); blk_[i].n2b = upload_raw(ws_, b, p + ".norm2.beta", D);
+  }
+  ng_ = upload_raw(ws_, b, "rec.neck.norm.g", D); nb_ = upload_raw(ws_, b, "rec.neck.norm.beta", D);
+  conv3_ = pack_conv(ws_, b, "rec.neck.conv3", C, D, 1, 1);
+  conv4_ = pack_conv(ws_, b, "rec.neck.conv4", C / 8, 2 * C, 1, 3);
+  conv1x1_ = pack_conv(ws_, b, "rec.neck.conv1x1", D, C / 8, 1, 1);
+  const BlobTensor& fw = b.get("rec.head.fc.w");
+  if (fw.dims.size() != 2 || fw.dims[0] != D) throw RtError(3, "RTWB: unexpected shape for rec.head.fc.w");
+  classes_ = fw.dims[1];
+  fc_ = pack_linear(ws_, b, "rec.head.fc", D, classes_);
+}
+
+int RecNet::tokens_for_width(int w) {
+  int wa = (w - 1) / 2 + 1, wc = (wa - 1) / 2 + 1;
+  return wc >= 2 ? (wc - 2) / 2 + 1 : 0;
+}
+
+float* RecNet::run(RunCtx& c, const float* x, Level& L0, Level& Lt) {
+  for (auto& g : L0.h) if (g.H != 48 || g.W < 8) throw RtError(3, "rec input must be 48 high and at least 8 wide");
+  Level La = down_level(L0, 2, 2);
+  std::vector<Level> lv; lv.reserve(16);
+  lv.push_back(La);
+  for (const LcBlock& b : blocks_) lv.push_back(down_level(lv.back(), b.sh, b.sw));
+  Lt = pool_level(lv.back(), 3, 2);
+  std::vector<Level*> ups = {&L0};
+  for (auto& l : lv) ups.push_back(&l);
+  ups.push_back(&Lt);
+  upload_levels(c, ups);
+  float* t = c.arena->alloc<float>((size_t)lv[0].total * 16);
+  { ProfScope ps(c.prof, c.st, "stem");
+    nn::stem_conv(c.st, x, L0.d, lv[0].d, lv[0].n(), lv[0].maxH, lv[0].maxW, 16, stem_w_, stem_b_, ACT_NONE, t); }
+  for (size_t i = 0; i < blocks_.size(); i++) t = run_lc(c, blocks_[i], t, lv[i], lv[i + 1]);
+  const long long rows = Lt.total;
+  const int C = 480, D = 120;
+  float* cat = c.arena->alloc<float>((size_t)rows * 2 * C);
+  { ProfScope ps(c.prof, c.st, "avgpool");
+    nn::avgpool_3x2(c.st, t, lv.back().d, Lt.d, Lt.n(), Lt.maxPix, C, cat, 2 * C); }
+  float* z1 = c.arena->alloc<float>((size_t)rows * 60);
+  { ProfScope ps(c.prof, c.st, "conv1x3");
+    nn::conv_sp(c.st, 1, 3, cat, 2 * C, Lt.d, Lt.n(), Lt.maxH, Lt.maxW, C, conv1_.w, 60, conv1_.Npad, z1, 60,
+                make_epi(conv1_, ACT_SWISH)); }
+  float* z = c.arena->alloc<float>((size_t)rows * D);
+  { ProfScope ps(c.prof, c.st, "gemm_neck");
+    nn::gemm(c.st, z1, 60, rows, conv2_.K, conv2_.w, D, conv2_.Npad, z, D, 0, make_epi(conv2_, ACT_SWISH)); }
+  float* qkv = c.arena->alloc<float>((size_t)rows * 3 * D);
+  float* a = c.arena->alloc<float>((size_t)rows * D);
+  float* a2 = c.arena->alloc<float>((size_t)rows * D);
+  float* m = c.arena->alloc<float>((size_t)rows * 2 * D);
+  for (int i = 0; i < 2; i++) {
+    const Blk& k = blk_[i];
+    { ProfScope ps(c.prof, c.st, "gemm_neck");
+      nn::gemm(c.st, z, D, rows, k.qkv.K, k.qkv.w, 3 * D, k.qkv.Npad, qkv, 3 * D, 0, make_epi(k.qkv, ACT_NONE)); }
+    { ProfScope ps(c.prof, c.st, "attention");
+      nn::attention(c.st, qkv, Lt.d, Lt.n(), Lt.maxW * Lt.maxH, 8, D / 8, a); }
+    { ProfScope ps(c.prof, c.st, "gemm_neck");
+      nn::gemm(c.st, a, D, rows, k.proj.K, k.proj.w, D, k.proj.Npad, a2, D, 0, make_epi(k.proj, ACT_NONE)); }
+    float* zn = c.arena->alloc<float>((size_t)rows * D);
+    { ProfScope ps(c.prof, c.st, "layernorm");
+      nn::add_layernorm(c.st, z, a2, rows, D, k.n1g, k.n1b, 1e-5f, zn); }
+    { ProfScope ps(c.prof, c.st, "gemm_neck");
+      nn::gemm(c.st, zn, D, rows, k.fc1.K, k.fc1.w, 2 * D, k.fc1.Npad, m, 2 * D, 0, make_epi(k.fc1, ACT_SWISH));
+      nn::gemm(c.st, m, 2 * D, rows, k.fc2.K, k.fc2.w, D, k.fc2.Npad, a2, D, 0, make_epi(k.fc2, ACT_NONE)); }
+    float* zo = c.arena->alloc<float>((size_t)rows * D);
+    { ProfScope ps(c.prof, c.st, "layernorm");
+      nn::add_layernorm(c.st, zn, a2, rows, D, k.n2g, k.n2b, 1e-5f, zo); }
+    z = zo;
+  }
+  float* zf = c.arena->alloc<float>((size_t)rows * D);
+  { ProfScope ps(c.prof, c.st, "layernorm");
+    nn::add_layernorm(c.st, z, nullptr, rows, D, ng_, nb_, 1e-6f, zf); }
+  { ProfScope ps(c.prof, c.st, "gemm_neck");
+    nn::gemm(c.st, zf, D, rows, conv3_.K, conv3_.w, C, conv3_.Npad, cat, 2 * C, C, make_epi(conv3_, ACT_SWISH)); }
+  float* z4 = c.arena->alloc<float>((size_t)rows * 60);
+  { ProfScope ps(c.prof, c.st, "conv1x3");
+    nn::conv_sp(c.st, 1, 3, cat, 2 * C, Lt.d, Lt.n(), Lt.maxH, Lt.maxW, 2 * C, conv4_.w, 60, conv4_.Npad, z4, 60,
+                make_epi(conv4_, ACT_SWISH)); }
+  float* z5 = c.arena->alloc<float>((size_t)rows * D);
+  { ProfScope ps(c.prof, c.st, "gemm_neck");
+    nn::gemm(c.st, z4, 60, rows, conv1x1_.K, conv1x1_.w, D, conv1x1_.Npad, z5, D, 0, make_epi(conv1x1_, ACT_SWISH)); }
+  const int ld = logits_ld();
+  float* logits = c.arena->alloc<float>((size_t)rows * ld);
+  { ProfScope ps(c.prof, c.st, "gemm_ctc_fc");
+    nn::gemm(c.st, z5, D, rows, fc_.K, fc_.w, classes_, fc_.Npad, logits, ld, 0, make_epi(fc_, ACT_NONE)); }
+  return logits;
+}
+
+// ---------------------------------------------------------------------------
+// ClsNet
+// ---------------------------------------------------------------------------
+struct ClsSpec { int k, mid, cout; bool se; int act, sh, sw; };
+static const ClsSpec CLS_SPEC[] = {
+    {3, 8, 8, true, ACT_RELU, 2, 1},      {3, 24, 8, false, ACT_RELU, 2, 1},    {3, 32, 8, false, ACT_RELU, 1, 1},
+    {5, 32, 16, true, ACT_HSWISH, 2, 1},  {5, 88, 16, true, ACT_HSWISH, 1, 1},  {5, 88, 16, true, ACT_HSWISH, 1, 1},
+    {5, 40, 16, true, ACT_HSWISH, 1, 1},  {5, 48, 16, true, ACT_HSWISH, 1, 1},  {5, 104, 32, true, ACT_HSWISH, 2, 1},
+    {5, 200, 32, true, ACT_HSWISH, 1, 1}, {5, 200, 32, true, ACT_HSWISH, 1, 1}};
+
+ClsNet::ClsNet(const Blob& b) {
+  pack_stem(ws_, b, "cls.stem", 8, &stem_w_, &stem_b_);
+  int cin = 8, i = 0;
+  for (const ClsSpec& s : CLS_SPEC) {
+    std::string p = "cls.b" + std::to_string(i++);
+    B blk;
+    blk.expand = pack_conv(ws_, b, p + ".expand", s.mid, cin, 1, 1);
+    blk.dw = pack_dw(ws_, b, p + ".dw", s.mid, s.k);
+    blk.se = s.se;
+    if (s.se) blk.sew = get_se(ws_, b, p + ".se", s.mid);
+    blk.linear = pack_conv(ws_, b, p + ".linear", s.cout, s.mid, 1, 1);
+    blk.act = s.act; blk.sh = s.sh; blk.sw = s.sw;
+    blk.shortcut = (s.sh == 1 && s.sw == 1 && cin == s.cout);
+    blocks_.push_back(blk);
+    cin = s.cout;
+  }
+  conv2_ = pack_conv(ws_, b, "cls.conv2", 200, cin, 1, 1);
+  fc_ = pack_linear(ws_, b, "cls.head.fc", 200, 2);
+}
+
+float* ClsNet::run(RunCtx& c, const float* x, Level& L0) {
+  std::vector<Level> lv; lv.reserve(16);
+  lv.push_back(down_level(L0, 2, 2));
+  for (const B& b : blocks_) lv.push_back(down_level(lv.back(), b.sh, b.sw));
+  Level Lp = pool_level(lv.back(), 2, 2);
+  std::vector<Level*> ups = {&L0};
+  for (auto& l : lv) ups.push_back(&l);
+  ups.push_back(&Lp);
+  upload_levels(c, ups);
+  float* t = c.arena->alloc<float>((size_t)lv[0].total * 8);
+  { ProfScope ps(c.prof, c.st, "stem");
+    nn::stem_conv(c.st, x, L0.d, lv[0].d, lv[0].n(), lv[0].maxH, lv[0].maxW, 8, stem_w_, stem_b_, ACT_HSWISH, t); }
+  int cin = 8;
+  for (size_t i = 0; i < blocks_.size(); i++) {
+    const B& b = blocks_[i];
+    const Level &Lin = lv[i], &Lout = lv[i + 1];
+    int mid = b.dw.Cp;
+    float* e = c.arena->alloc<float>((size_t)Lin.total * mid);
+    { ProfScope ps(c.prof, c.st, "gemm_cls");
+      nn::gemm(c.st, t, cin, Lin.total, b.expand.K, b.expand.w, b.expand.N, b.expand.Npad, e, mid, 0,
+               make_epi(b.expand, b.act)); }
+    float* d = c.arena->alloc<float>((size_t)Lout.total * mid);
+    { ProfScope ps(c.prof, c.st, b.dw.k == 3 ? "dwconv3" : "dwconv5");
+      nn::dwconv(c.st, b.dw.k, b.sh, b.sw, e, Lin.d, Lout.d, Lout.n(), Lout.maxH, Lout.maxW, mid, b.dw.w, b.dw.b, b.act, 0,
+                 1.f, 0.f, d); }
+    if (b.se) run_se(c, d, Lout, b.sew, HSIG_MBV3, 0);
+    int co = b.linear.N;
+    float* y = c.arena->alloc<float>((size_t)Lout.total * co);
+    { ProfScope ps(c.prof, c.st, "gemm_cls");
+      nn::gemm(c.st, d, mid, Lout.total, b.linear.K, b.linear.w, co, b.linear.Npad, y, co, 0,
+               make_epi(b.linear, ACT_NONE, nullptr, b.shortcut ? t : nullptr, cin)); }
+    t = y; cin = co;
+  }
+  const Level& Ll = lv.back();
+  float* f = c.arena->alloc<float>((size_t)Ll.total * 200);
+  { ProfScope ps(c.prof, c.st, "gemm_cls");
+    nn::gemm(c.st, t, cin, Ll.total, conv2_.K, conv2_.w, 200, conv2_.Npad, f, 200, 0, make_epi(conv2_, ACT_HSWISH)); }
+  float* mp = c.arena->alloc<float>((size_t)Lp.total * 200);
+  { ProfScope ps(c.prof, c.st, "maxpool");
+    nn::maxpool_2x2(c.st, f, Ll.d, Lp.d, Lp.n(), Lp.maxPix, 200, mp); }
+  float* partial = c.arena->alloc<float>((size_t)Lp.n() * nn::pool_chunks(Lp.maxPix) * 200);
+  float* gm = c.arena->alloc<float>((size_t)Lp.n() * 200);
+  { ProfScope ps(c.prof, c.st, "global_mean");
+    nn::global_mean(c.st, mp, Lp.d, Lp.n(), Lp.maxPix, 200, partial, gm); }
+  float* logits = c.arena->alloc<float>((size_t)Lp.n() * 4);
+  float* probs = c.arena->alloc<float>((size_t)Lp.n() * 2);
+  { ProfScope ps(c.prof, c.st, "gemm_cls");
+    nn::gemm(c.st, gm, 200, Lp.n(), fc_.K, fc_.w, 2, fc_.Npad, logits, 4, 0, make_epi(fc_, ACT_NONE)); }
+  { ProfScope ps(c.prof, c.st, "softmax");
+    nn::softmax_rows(c.st, logits, 4, Lp.n(), 2, probs); }
+  return probs;
+}
+
+}  // namespace rt

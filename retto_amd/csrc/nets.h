@@ -1,0 +1,112 @@
+// The three networks behind RettoInnerWorker::{det,cls,rec}
+// (/root/reference/retto-core/src/worker.rs:69-73), built from RTWB blobs and run as
+// sequences of nn:: kernel launches over ragged NHWC batches.  Architecture: PP-OCRv4
+// mobile det (PPLCNetV3 x0.75 + RSEFPN + DBHead), ch_ppocr_mobile_v2.0 cls
+// (MobileNetV3-small x0.35) and PP-OCRv4 rec (PPLCNetV3 x0.95 + SVTR neck + CTC head);
+// see SURVEY.md Appendix C.
+#pragma once
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "nn.h"
+#include "runtime.h"
+
+namespace rt {
+
+// A pyramid level of a ragged batch: host copy + device copy of the per-image geometry.
+struct Level {
+  std::vector<ImgGeom> h;
+  const ImgGeom* d = nullptr;
+  long long total = 0;    // pixels over all images
+  int maxH = 0, maxW = 0;
+  long long maxPix = 0;   // max H*W over images
+  int n() const { return (int)h.size(); }
+};
+
+struct RunCtx {
+  hipStream_t st;
+  Arena* arena;     // activations + descriptor tables of this pass
+  Pinned* pinned;   // host staging for descriptor uploads
+  Profiler* prof;
+};
+
+Level make_level(const std::vector<std::pair<int, int>>& hw);
+Level down_level(const Level& in, int sh, int sw);             // conv k odd, pad k/2
+Level pool_level(const Level& in, int kh, int kw);             // stride = kernel, no pad
+void upload_levels(RunCtx& c, std::vector<Level*> levels);     // one H2D copy for all tables
+
+struct PackedDense {  // gemm / conv_sp weights on device
+  float* w = nullptr; float* b = nullptr;
+  int K = 0, N = 0, Npad = 0, kh = 1, kw = 1;
+};
+struct PackedDw { float* w = nullptr; float* b = nullptr; int k = 3, C = 0, Cp = 0; };
+struct Lab { int has = 0; float a = 1.f, c = 0.f; };
+struct SeW { float *w1 = nullptr, *b1 = nullptr, *w2 = nullptr, *b2 = nullptr; int C = 0, Cr = 0; };
+
+class WeightStore {  // owns one device allocation per network
+ public:
+  ~WeightStore();
+  float* upload(const std::vector<float>& host);
+  size_t bytes() const { return total_; }
+ private:
+  std::vector<void*> bufs_;
+  size_t total_ = 0;
+};
+
+struct LcBlock {
+  PackedDw dw; Lab dw_lab; int dw_act = 0;
+  bool se = false; SeW sew;
+  PackedDense pw; Lab pw_lab;
+  int sh = 1, sw = 1, cin = 0, cout = 0;
+};
+
+class DetNet {
+ public:
+  explicit DetNet(const Blob& b);
+  // x: f32 NHWC pitch-4 (B,G,R,0) at level L0 (every H,W a multiple of 32).
+  // Returns the probability maps, one float per L0 pixel (arena memory).
+  float* run(RunCtx& c, const float* x, Level& L0);
+ private:
+  WeightStore ws_;
+  float* stem_w_; float* stem_b_;
+  std::vector<LcBlock> blocks_;
+  int tap_after_[4];
+  PackedDense out_[4], ins_[4], inp_[4], head_conv1_;
+  SeW ins_se_[4], inp_se_[4];
+  float *dc1_w_, *dc1_b_, *dc2_w_, *dc2_b_;
+};
+
+class RecNet {
+ public:
+  explicit RecNet(const Blob& b);
+  int classes() const { return classes_; }
+  int logits_ld() const { return round_up(classes_, 4); }
+  // x: f32 NHWC pitch-4 (R,G,B,0), level L0 = lines of height 48. Returns logits
+  // [rows, logits_ld()] with rows = sum of T_i; Lt (out) is the token level (H=1, W=T_i).
+  float* run(RunCtx& c, const float* x, Level& L0, Level& Lt);
+  static int tokens_for_width(int w);
+ private:
+  WeightStore ws_;
+  float* stem_w_; float* stem_b_;
+  std::vector<LcBlock> blocks_;
+  PackedDense conv1_, conv2_, conv3_, conv4_, conv1x1_, fc_;
+  struct Blk { PackedDense qkv, proj, fc1, fc2; float *n1g, *n1b, *n2g, *n2b; } blk_[2];
+  float *ng_, *nb_;
+  int classes_ = 0;
+};
+
+class ClsNet {
+ public:
+  explicit ClsNet(const Blob& b);
+  // x: f32 NHWC pitch-4, n images of 48 x 192. Returns softmax probs [n,2] (arena).
+  float* run(RunCtx& c, const float* x, Level& L0);
+ private:
+  struct B { PackedDense expand, linear; PackedDw dw; bool se; SeW sew; int act, sh, sw; bool shortcut; };
+  WeightStore ws_;
+  float* stem_w_; float* stem_b_;
+  std::vector<B> blocks_;
+  PackedDense conv2_, fc_;
+};
+
+}  // namespace rt

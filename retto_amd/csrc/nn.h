@@ -1,0 +1,77 @@
+// Launchers of the neural-network kernels (nn_kernels.hip).  All activations are
+// fp32 NHWC with a channel pitch that is a multiple of 4; batches are ragged lists of
+// images described by device arrays of rt::ImgGeom.
+#pragma once
+#include "common.h"
+
+namespace rt {
+namespace nn {
+
+constexpr int KC = 32;  // K-chunk of the MFMA GEMM / conv kernels (weights are packed in KC slabs)
+
+// C[M, ldc] (+coff) = epi(A[M, lda] x W), W packed as [ceil(K/KC)][Npad16][KC].
+void gemm(hipStream_t st, const float* A, int lda, long long M, int K, const float* Wp, int N, int Npad16, float* C,
+          int ldc, int coff, const Epilogue& epi);
+
+// Dense stride-1 "same" convolution, kernel (KH,KW) in {(3,3),(1,3)}; W packed as
+// [ceil(Cin/KC)][KH*KW][Npad16][KC].
+void conv_sp(hipStream_t st, int KH, int KW, const float* x, int ldx, const ImgGeom* geom, int n_img, int maxH,
+             int maxW, int Cin, const float* Wp, int N, int Npad16, float* y, int ldy, const Epilogue& epi);
+
+// Depthwise KxK (K in {3,5}), stride (sh,sw), pad K/2.  Wd packed [K*K][Cp].
+void dwconv(hipStream_t st, int K, int sh, int sw, const float* x, const ImgGeom* gin, const ImgGeom* gout, int n_img,
+            int maxHo, int maxWo, int Cp, const float* Wd, const float* bias, int act, int has_lab, float lab_a,
+            float lab_c, float* y);
+
+// 3x3 stride-2 stem on a 3(+1 pad)-channel f32 NHWC input. Ws packed [27][COUT]. COUT in {8,16}.
+void stem_conv(hipStream_t st, const float* x, const ImgGeom* gin, const ImgGeom* gout, int n_img, int maxHo, int maxWo,
+               int COUT, const float* Ws, const float* bias, int act, float* y);
+
+// NCHW f32 [n,3,H,W] (uniform dims) -> NHWC pitch 4 (pad = 0)
+void nchw3_to_nhwc4(hipStream_t st, const float* in, int n, int H, int W, float* out);
+
+// Squeeze-excite: deterministic two-stage spatial mean, then fc1-relu-fc2-hardsigmoid.
+// scale[n][Cp] = hsig(...) (+1 when residual: RSELayer's x + x*s).  `partial` scratch holds
+// n_img*chunks*Cp floats with chunks = pool_chunks(maxPix).
+int pool_chunks(long long max_pix);
+void se_scale(hipStream_t st, const float* x, const ImgGeom* geom, int n_img, long long max_pix, int C, int Cp,
+              const float* w1, const float* b1, const float* w2, const float* b2, int Cr, float slope, int residual,
+              float* partial, float* scale);
+void scale_channels(hipStream_t st, float* x, const ImgGeom* geom, int n_img, long long max_pix, int Cp,
+                    const float* scale);
+// mean over H*W per image -> out[n][Cp] (uses the same partial scratch)
+void global_mean(hipStream_t st, const float* x, const ImgGeom* geom, int n_img, long long max_pix, int Cp,
+                 float* partial, float* out);
+
+// out = a + nearest_up2(b)   (in place on a allowed)
+void upsample_add(hipStream_t st, const float* a, const float* b, const ImgGeom* ga, const ImgGeom* gb, int n_img,
+                  long long max_pix, int Cp, float* out);
+// fuse = concat(up8(p5), up4(p4), up2(p3), p2) along channels; every input has pitch Cq, output pitch 4*Cq
+void fpn_concat(hipStream_t st, const float* p5, const float* p4, const float* p3, const float* p2, const ImgGeom* g5,
+                const ImgGeom* g4, const ImgGeom* g3, const ImgGeom* g2, int n_img, long long max_pix, int Cq,
+                float* out);
+// DB head tail: convT2x2s2(24->24)+relu, convT2x2s2(24->1), sigmoid. in [.,.,24] at 1/4 res,
+// out f32 map at full res (geometry gout, one float per pixel).
+void db_head_tail(hipStream_t st, const float* x, const ImgGeom* gin, const ImgGeom* gout, int n_img, long long max_pix,
+                  const float* w1, const float* b1, const float* w2, const float* b2, float* out);
+
+void avgpool_3x2(hipStream_t st, const float* x, const ImgGeom* gin, const ImgGeom* gout, int n_img, long long max_pix,
+                 int Cp, float* y, int ldy);
+void maxpool_2x2(hipStream_t st, const float* x, const ImgGeom* gin, const ImgGeom* gout, int n_img, long long max_pix,
+                 int Cp, float* y);
+// y = LayerNorm(x + r) over the last dim C (r may be null), rows contiguous with pitch C
+void add_layernorm(hipStream_t st, const float* x, const float* r, long long rows, int C, const float* g,
+                   const float* beta, float eps, float* y);
+// Global multi-head attention over each image's tokens. qkv [rows, 3*C] (q|k|v, channel = head*hd + d)
+void attention(hipStream_t st, const float* qkv, const ImgGeom* geom, int n_img, int maxT, int heads, int hd,
+               float* out);
+void copy_channels(hipStream_t st, const float* src, int lds, long long rows, int C, float* dst, int ldd, int coff);
+// row softmax: in [rows, ld] (first C valid) -> out [rows, C] dense
+void softmax_rows(hipStream_t st, const float* in, int ld, long long rows, int C, float* out);
+// per-row (argmax logit, softmax max prob) without materialising the softmax: in [rows, ld]
+void argmax_prob_rows(hipStream_t st, const float* in, int ld, long long rows, int C, int* idx, float* prob);
+// per-row (first argmax, max value) of rows that already hold probabilities (ndarray-stats argmax/max)
+void argmax_rows(hipStream_t st, const float* in, int ld, long long rows, int C, int* idx, float* maxval);
+
+}  // namespace nn
+}  // namespace rt

@@ -1,0 +1,851 @@
+// Neural-network kernels for gfx950 (CDNA4): fp32 NHWC, 64-wide wavefronts,
+// v_mfma_f32_16x16x4_f32 for the dense 1x1 / 3x3 / 1x3 contractions (exact fp32
+// fmaf chains: no reduced-precision path exists on gfx950 and parity is fp32),
+// VALU for the depthwise / pooling / normalisation work which is HBM bound.
+//
+// The networks these serve replace ONNX Runtime's Session::run in
+// /root/reference/retto-core/src/worker/ort_worker.rs:189-220.
+#include "nn.h"
+
+namespace rt {
+namespace nn {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float act_apply(float v, int act) {
+  switch (act) {
+    case ACT_RELU: return fmaxf(v, 0.0f);
+    case ACT_HSWISH: return v * fminf(fmaxf(v + 3.0f, 0.0f), 6.0f) / 6.0f;
+    case ACT_SWISH: return v / (1.0f + expf(-v));
+    case ACT_SIGMOID: return 1.0f / (1.0f + expf(-v));
+    default: return v;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// MFMA micro-kernel shared by gemm and conv_sp.
+// LDS rows are KC(32)+4 floats.  Weights are the MFMA "A" operand (M dim = cout),
+// pixels the "B" operand (N dim = pixel), so each lane ends up holding 4 consecutive
+// output channels of one pixel -> one 16-byte store per accumulator.
+// Lane l: r = l & 15, q = l >> 4.  Within a 16-deep k group lane quarter q reads
+// k = 4q..4q+3 as one ds_read_b128 and feeds element s to MFMA step s; the weight
+// operand uses the same (q, s) -> k map, which is all the instruction requires.
+// ---------------------------------------------------------------------------
+constexpr int LROW = KC + 4;
+
+template <int NT>
+__device__ __forceinline__ void mma_chunk(const float* __restrict__ xs0, const float* __restrict__ xs1,
+                                          const float* __restrict__ ws, int nt_valid, f32x4 (&acc)[2][NT], int r,
+                                          int q) {
+#pragma unroll
+  for (int g = 0; g < KC / 16; g++) {
+    f32x4 a0 = *reinterpret_cast<const f32x4*>(xs0 + g * 16 + 4 * q);
+    f32x4 a1 = *reinterpret_cast<const f32x4*>(xs1 + g * 16 + 4 * q);
+#pragma unroll
+    for (int nt = 0; nt < NT; nt++) {
+      if (nt < nt_valid) {
+        f32x4 b = *reinterpret_cast<const f32x4*>(ws + (nt * 16 + r) * LROW + g * 16 + 4 * q);
+#pragma unroll
+        for (int s = 0; s < 4; s++) {
+          acc[0][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[s], a0[s], acc[0][nt], 0, 0, 0);
+          acc[1][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[s], a1[s], acc[1][nt], 0, 0, 0);
+        }
+      }
+    }
+  }
+}
+
+template <int NT>
+__device__ __forceinline__ void epilogue_store(f32x4 (&acc)[2][NT], int nt_valid, const Epilogue& epi, int n0, int N,
+                                               int nstore, float* __restrict__ yrow0, float* __restrict__ yrow1,
+                                               bool v0, bool v1, const float* res0, const float* res1, int q) {
+#pragma unroll
+  for (int nt = 0; nt < NT; nt++) {
+    if (nt >= nt_valid) continue;
+    int col = n0 + nt * 16 + q * 4;
+    if (col >= nstore) continue;
+    f32x4 bias = {0.f, 0.f, 0.f, 0.f};
+    if (epi.bias) bias = *reinterpret_cast<const f32x4*>(epi.bias + col);
+#pragma unroll
+    for (int mt = 0; mt < 2; mt++) {
+      bool valid = mt == 0 ? v0 : v1;
+      if (!valid) continue;
+      float* yr = mt == 0 ? yrow0 : yrow1;
+      const float* rr = mt == 0 ? res0 : res1;
+      f32x4 v = acc[mt][nt];
+      f32x4 o;
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        float t = act_apply(v[j] + bias[j], epi.act);
+        if (epi.has_lab) t = fmaf(t, epi.lab_a, epi.lab_c);
+        if (rr) t += rr[col + j];
+        o[j] = (col + j < N) ? t : 0.0f;
+      }
+      *reinterpret_cast<f32x4*>(yr + col) = o;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Flat GEMM: rows = pixels (any ragged batch is just a longer M).
+// Block 256 threads (4 waves), tile 128 rows x 16*NT cols, K in 32-chunks.
+// ---------------------------------------------------------------------------
+template <int NT>
+__global__ __launch_bounds__(256) void k_gemm(const float* __restrict__ A, int lda, long long M, int K,
+                                              const float* __restrict__ Wp, int N, int Npad, float* __restrict__ C,
+                                              int ldc, int coff, Epilogue epi) {
+  __shared__ __attribute__((aligned(16))) float lds[(128 + 16 * NT) * LROW];
+  float* xs = lds;
+  float* ws = lds + 128 * LROW;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, q = lane >> 4;
+  const long long m0 = (long long)blockIdx.x * 128;
+  const int n0 = blockIdx.y * 16 * NT;
+  const int nt_valid = min(NT, (Npad - n0) / 16);
+  f32x4 acc[2][NT];
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int j = 0; j < NT; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nkc = (K + KC - 1) / KC;
+  for (int kc = 0; kc < nkc; kc++) {
+    const int k0 = kc * KC;
+    // stage X: 128 rows x 32 floats
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      int idx = tid + 256 * i;
+      int row = idx >> 3, c4 = idx & 7;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      long long m = m0 + row;
+      if (m < M && k0 + c4 * 4 < K) v = *reinterpret_cast<const f32x4*>(A + m * lda + k0 + c4 * 4);
+      *reinterpret_cast<f32x4*>(xs + row * LROW + c4 * 4) = v;
+    }
+    // stage W: 16*NT rows x 32 floats
+    for (int idx = tid; idx < 16 * NT * 8; idx += 256) {
+      int row = idx >> 3, c4 = idx & 7;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (n0 + row < Npad) v = *reinterpret_cast<const f32x4*>(Wp + ((long long)kc * Npad + n0 + row) * KC + c4 * 4);
+      *reinterpret_cast<f32x4*>(ws + row * LROW + c4 * 4) = v;
+    }
+    __syncthreads();
+    mma_chunk<NT>(xs + (wave * 32 + r) * LROW, xs + (wave * 32 + 16 + r) * LROW, ws, nt_valid, acc, r, q);
+    __syncthreads();
+  }
+  long long ma = m0 + wave * 32 + r, mb = ma + 16;
+  const int nstore = (N + 3) & ~3;
+  epilogue_store<NT>(acc, nt_valid, epi, n0, N, nstore, C + ma * ldc + coff, C + mb * ldc + coff, ma < M, mb < M,
+                     epi.residual ? epi.residual + ma * epi.ld_res : nullptr,
+                     epi.residual ? epi.residual + mb * epi.ld_res : nullptr, q);
+}
+
+void gemm(hipStream_t st, const float* A, int lda, long long M, int K, const float* Wp, int N, int Npad16, float* C,
+          int ldc, int coff, const Epilogue& epi) {
+  if (M <= 0) return;
+  int ntiles = Npad16 / 16;
+  int NT = ntiles >= 8 ? 8 : ntiles;
+  if (ntiles > 8) {  // pick the split with least padding among 8 / 6 / 5
+    int best = 8, waste = round_up(ntiles, 8) - ntiles;
+    for (int c : {6, 5, 4}) {
+      int w = round_up(ntiles, c) - ntiles;
+      if (w < waste) { waste = w; best = c; }
+    }
+    NT = best;
+  }
+  dim3 grid((unsigned)((M + 127) / 128), (unsigned)((ntiles + NT - 1) / NT));
+#define RT_GEMM_CASE(n) \
+  case n: hipLaunchKernelGGL(k_gemm<n>, grid, dim3(256), 0, st, A, lda, M, K, Wp, N, Npad16, C, ldc, coff, epi); break;
+  switch (NT) {
+    RT_GEMM_CASE(1) RT_GEMM_CASE(2) RT_GEMM_CASE(3) RT_GEMM_CASE(4) RT_GEMM_CASE(5) RT_GEMM_CASE(6) RT_GEMM_CASE(7)
+    RT_GEMM_CASE(8)
+  }
+#undef RT_GEMM_CASE
+}
+
+// ---------------------------------------------------------------------------
+// Spatial dense conv (stride 1, zero "same" padding) as implicit GEMM.
+// One block = one TH x TW (=128 pixel) output tile of one image x 16*NT couts.
+// The halo tile of a 32-channel slab is staged once in LDS and reused by all taps.
+// ---------------------------------------------------------------------------
+template <int KH, int KW, int TH, int TW, int NT>
+__global__ __launch_bounds__(256) void k_conv_sp(const float* __restrict__ x, int ldx, const ImgGeom* __restrict__ geom,
+                                                 int Cin, const float* __restrict__ Wp, int N, int Npad,
+                                                 float* __restrict__ y, int ldy, Epilogue epi) {
+  constexpr int HH = TH + KH - 1, HW = TW + KW - 1, TAPS = KH * KW;
+  __shared__ __attribute__((aligned(16))) float lds[(HH * HW + TAPS * 16 * NT) * LROW];
+  float* xs = lds;
+  float* ws = lds + HH * HW * LROW;
+  const ImgGeom g = geom[blockIdx.y];
+  const int tiles_x = (g.W + TW - 1) / TW, tiles_y = (g.H + TH - 1) / TH;
+  if ((int)blockIdx.x >= tiles_x * tiles_y) return;
+  const int ty = blockIdx.x / tiles_x, tx = blockIdx.x % tiles_x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, q = lane >> 4;
+  const int n0 = blockIdx.z * 16 * NT;
+  const int nt_valid = min(NT, (Npad - n0) / 16);
+  f32x4 acc[2][NT];
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int j = 0; j < NT; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // this lane's two pixels (tile-local)
+  const int p0 = wave * 32 + r, p1 = p0 + 16;
+  const int py0 = p0 / TW, px0 = p0 % TW, py1 = p1 / TW, px1 = p1 % TW;
+
+  const int nkc = (Cin + KC - 1) / KC;
+  for (int kc = 0; kc < nkc; kc++) {
+    const int k0 = kc * KC;
+    for (int idx = tid; idx < HH * HW * 8; idx += 256) {
+      int hp = idx >> 3, c4 = idx & 7;
+      int hy = hp / HW, hx = hp % HW;
+      int gy = ty * TH + hy - KH / 2, gx = tx * TW + hx - KW / 2;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (gy >= 0 && gy < g.H && gx >= 0 && gx < g.W && k0 + c4 * 4 < Cin)
+        v = *reinterpret_cast<const f32x4*>(x + (g.off + (long long)gy * g.W + gx) * ldx + k0 + c4 * 4);
+      *reinterpret_cast<f32x4*>(xs + hp * LROW + c4 * 4) = v;
+    }
+    for (int idx = tid; idx < TAPS * 16 * NT * 8; idx += 256) {
+      int row = idx >> 3, c4 = idx & 7;
+      int tap = row / (16 * NT), n = row % (16 * NT);
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (n0 + n < Npad)
+        v = *reinterpret_cast<const f32x4*>(Wp + (((long long)kc * TAPS + tap) * Npad + n0 + n) * KC + c4 * 4);
+      *reinterpret_cast<f32x4*>(ws + row * LROW + c4 * 4) = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int dy = 0; dy < KH; dy++)
+#pragma unroll
+      for (int dx = 0; dx < KW; dx++)
+        mma_chunk<NT>(xs + ((py0 + dy) * HW + px0 + dx) * LROW, xs + ((py1 + dy) * HW + px1 + dx) * LROW,
+                      ws + (dy * KW + dx) * 16 * NT * LROW, nt_valid, acc, r, q);
+    __syncthreads();
+  }
+  const int oy0 = ty * TH + py0, ox0 = tx * TW + px0, oy1 = ty * TH + py1, ox1 = tx * TW + px1;
+  const bool v0 = oy0 < g.H && ox0 < g.W, v1 = oy1 < g.H && ox1 < g.W;
+  const long long pa = g.off + (long long)oy0 * g.W + ox0, pb = g.off + (long long)oy1 * g.W + ox1;
+  const int nstore = (N + 3) & ~3;
+  epilogue_store<NT>(acc, nt_valid, epi, n0, N, nstore, y + pa * ldy, y + pb * ldy, v0, v1,
+                     epi.residual ? epi.residual + pa * epi.ld_res : nullptr,
+                     epi.residual ? epi.residual + pb * epi.ld_res : nullptr, q);
+}
+
+void conv_sp(hipStream_t st, int KH, int KW, const float* x, int ldx, const ImgGeom* geom, int n_img, int maxH,
+             int maxW, int Cin, const float* Wp, int N, int Npad16, float* y, int ldy, const Epilogue& epi) {
+  if (n_img <= 0) return;
+  int ntiles = Npad16 / 16;
+  if (KH == 3 && KW == 3) {
+    int NT = ntiles >= 2 ? 2 : 1;
+    dim3 grid(((maxW + 15) / 16) * ((maxH + 7) / 8), n_img, (ntiles + NT - 1) / NT);
+    if (NT == 2)
+      hipLaunchKernelGGL((k_conv_sp<3, 3, 8, 16, 2>), grid, dim3(256), 0, st, x, ldx, geom, Cin, Wp, N, Npad16, y, ldy,
+                         epi);
+    else
+      hipLaunchKernelGGL((k_conv_sp<3, 3, 8, 16, 1>), grid, dim3(256), 0, st, x, ldx, geom, Cin, Wp, N, Npad16, y, ldy,
+                         epi);
+  } else if (KH == 1 && KW == 3) {
+    int NT = ntiles >= 4 ? 4 : ntiles;
+    dim3 grid(((maxW + 127) / 128) * maxH, n_img, (ntiles + NT - 1) / NT);
+#define RT_C13(n)                                                                                                   \
+  case n:                                                                                                           \
+    hipLaunchKernelGGL((k_conv_sp<1, 3, 1, 128, n>), grid, dim3(256), 0, st, x, ldx, geom, Cin, Wp, N, Npad16, y, ldy, \
+                       epi);                                                                                        \
+    break;
+    switch (NT) { RT_C13(1) RT_C13(2) RT_C13(3) RT_C13(4) }
+#undef RT_C13
+  } else {
+    throw RtError(8, "conv_sp: unsupported kernel size");
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Depthwise conv: HBM/L2 bound. Thread = (output pixel, 4 channels).
+// ---------------------------------------------------------------------------
+template <int K>
+__global__ __launch_bounds__(256) void k_dwconv(int sh, int sw, const float* __restrict__ x,
+                                                const ImgGeom* __restrict__ gin, const ImgGeom* __restrict__ gout,
+                                                int Cp, const float* __restrict__ Wd, const float* __restrict__ bias,
+                                                int act, int has_lab, float lab_a, float lab_c, float* __restrict__ y) {
+  const ImgGeom gi = gin[blockIdx.y], go = gout[blockIdx.y];
+  const int C4 = Cp >> 2;
+  long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  long long total = (long long)go.H * go.W * C4;
+  if (idx >= total) return;
+  int c4 = (int)(idx % C4);
+  long long p = idx / C4;
+  int oy = (int)(p / go.W), ox = (int)(p % go.W);
+  f32x4 acc = *reinterpret_cast<const f32x4*>(bias + c4 * 4);
+  const int iy0 = oy * sh - K / 2, ix0 = ox * sw - K / 2;
+#pragma unroll
+  for (int dy = 0; dy < K; dy++) {
+    int iy = iy0 + dy;
+    if (iy < 0 || iy >= gi.H) continue;
+#pragma unroll
+    for (int dx = 0; dx < K; dx++) {
+      int ix = ix0 + dx;
+      if (ix < 0 || ix >= gi.W) continue;
+      f32x4 v = *reinterpret_cast<const f32x4*>(x + (gi.off + (long long)iy * gi.W + ix) * Cp + c4 * 4);
+      f32x4 w = *reinterpret_cast<const f32x4*>(Wd + (dy * K + dx) * Cp + c4 * 4);
+#pragma unroll
+      for (int j = 0; j < 4; j++) acc[j] = fmaf(v[j], w[j], acc[j]);
+    }
+  }
+  f32x4 o;
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    float t = act_apply(acc[j], act);
+    if (has_lab) t = fmaf(t, lab_a, lab_c);
+    o[j] = t;
+  }
+  *reinterpret_cast<f32x4*>(y + (go.off + p) * Cp + c4 * 4) = o;
+}
+
+void dwconv(hipStream_t st, int K, int sh, int sw, const float* x, const ImgGeom* gin, const ImgGeom* gout, int n_img,
+            int maxHo, int maxWo, int Cp, const float* Wd, const float* bias, int act, int has_lab, float lab_a,
+            float lab_c, float* y) {
+  if (n_img <= 0) return;
+  long long total = (long long)maxHo * maxWo * (Cp / 4);
+  dim3 grid((unsigned)((total + 255) / 256), n_img);
+  if (K == 3)
+    hipLaunchKernelGGL(k_dwconv<3>, grid, dim3(256), 0, st, sh, sw, x, gin, gout, Cp, Wd, bias, act, has_lab, lab_a,
+                       lab_c, y);
+  else if (K == 5)
+    hipLaunchKernelGGL(k_dwconv<5>, grid, dim3(256), 0, st, sh, sw, x, gin, gout, Cp, Wd, bias, act, has_lab, lab_a,
+                       lab_c, y);
+  else
+    throw RtError(8, "dwconv: unsupported kernel size");
+}
+
+// ---------------------------------------------------------------------------
+// Stem: 3x3 stride 2 pad 1, 3 -> COUT, thread per output pixel.
+// ---------------------------------------------------------------------------
+template <int COUT>
+__global__ __launch_bounds__(256) void k_stem(const float* __restrict__ x, const ImgGeom* __restrict__ gin,
+                                              const ImgGeom* __restrict__ gout, const float* __restrict__ Ws,
+                                              const float* __restrict__ bias, int act, float* __restrict__ y) {
+  __shared__ float w[27 * COUT + COUT];
+  for (int i = threadIdx.x; i < 27 * COUT; i += 256) w[i] = Ws[i];
+  for (int i = threadIdx.x; i < COUT; i += 256) w[27 * COUT + i] = bias[i];
+  __syncthreads();
+  const ImgGeom gi = gin[blockIdx.y], go = gout[blockIdx.y];
+  long long p = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (p >= (long long)go.H * go.W) return;
+  int oy = (int)(p / go.W), ox = (int)(p % go.W);
+  float acc[COUT];
+#pragma unroll
+  for (int c = 0; c < COUT; c++) acc[c] = w[27 * COUT + c];
+#pragma unroll
+  for (int dy = 0; dy < 3; dy++) {
+    int iy = oy * 2 - 1 + dy;
+    if (iy < 0 || iy >= gi.H) continue;
+#pragma unroll
+    for (int dx = 0; dx < 3; dx++) {
+      int ix = ox * 2 - 1 + dx;
+      if (ix < 0 || ix >= gi.W) continue;
+      f32x4 v = *reinterpret_cast<const f32x4*>(x + (gi.off + (long long)iy * gi.W + ix) * 4);
+      const float* wt = w + (dy * 3 + dx) * 3 * COUT;
+#pragma unroll
+      for (int ci = 0; ci < 3; ci++)
+#pragma unroll
+        for (int c = 0; c < COUT; c++) acc[c] = fmaf(v[ci], wt[ci * COUT + c], acc[c]);
+    }
+  }
+  float* o = y + (go.off + p) * COUT;
+#pragma unroll
+  for (int c = 0; c < COUT; c += 4) {
+    f32x4 t = {act_apply(acc[c], act), act_apply(acc[c + 1], act), act_apply(acc[c + 2], act),
+               act_apply(acc[c + 3], act)};
+    *reinterpret_cast<f32x4*>(o + c) = t;
+  }
+}
+
+void stem_conv(hipStream_t st, const float* x, const ImgGeom* gin, const ImgGeom* gout, int n_img, int maxHo, int maxWo,
+               int COUT, const float* Ws, const float* bias, int act, float* y) {
+  if (n_img <= 0) return;
+  dim3 grid((unsigned)(((long long)maxHo * maxWo + 255) / 256), n_img);
+  if (COUT == 16) hipLaunchKernelGGL(k_stem<16>, grid, dim3(256), 0, st, x, gin, gout, Ws, bias, act, y);
+  else if (COUT == 8) hipLaunchKernelGGL(k_stem<8>, grid, dim3(256), 0, st, x, gin, gout, Ws, bias, act, y);
+  else throw RtError(8, "stem_conv: unsupported COUT");
+}
+
+__global__ void k_nchw3_to_nhwc4(const float* __restrict__ in, int n, int H, int W, float* __restrict__ out) {
+  long long p = (long long)blockIdx.x * 256 + threadIdx.x;
+  long long plane = (long long)H * W;
+  if (p >= plane * n) return;
+  long long im = p / plane, pp = p % plane;
+  const float* b = in + im * 3 * plane + pp;
+  f32x4 v = {b[0], b[plane], b[2 * plane], 0.0f};
+  *reinterpret_cast<f32x4*>(out + p * 4) = v;
+}
+void nchw3_to_nhwc4(hipStream_t st, const float* in, int n, int H, int W, float* out) {
+  long long total = (long long)n * H * W;
+  if (total <= 0) return;
+  hipLaunchKernelGGL(k_nchw3_to_nhwc4, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, in, n, H, W, out);
+}
+
+// ---------------------------------------------------------------------------
+// Squeeze-excite / global mean: deterministic two-stage reduction.
+// ---------------------------------------------------------------------------
+constexpr int POOL_PIX = 1024;  // pixels per partial block
+int pool_chunks(long long max_pix) { return (int)((max_pix + POOL_PIX - 1) / POOL_PIX); }
+
+__global__ __launch_bounds__(256) void k_pool_partial(const float* __restrict__ x, const ImgGeom* __restrict__ geom,
+                                                      int Cp, int chunks, float* __restrict__ partial) {
+  __shared__ __attribute__((aligned(16))) float red[256 * 4];
+  const ImgGeom g = geom[blockIdx.y];
+  const long long npix = (long long)g.H * g.W;
+  const long long p0 = (long long)blockIdx.x * POOL_PIX;
+  const int C4 = Cp >> 2;
+  float* out = partial + ((long long)blockIdx.y * chunks + blockIdx.x) * Cp;
+  // channel groups are processed in passes of up to 256/PL groups... keep it simple:
+  // PL pixel lanes per channel group so that PL * C4pass <= 256.
+  for (int cbase = 0; cbase < C4; cbase += 256) {
+    int cgroups = min(256, C4 - cbase);
+    int PL = 256 / cgroups;
+    int c4 = cbase + (threadIdx.x % cgroups), pl = threadIdx.x / cgroups;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    if (pl < PL && p0 < npix) {
+      long long pend = min(npix, p0 + POOL_PIX);
+      for (long long p = p0 + pl; p < pend; p += PL) {
+        f32x4 v = *reinterpret_cast<const f32x4*>(x + (g.off + p) * Cp + c4 * 4);
+        s += v;
+      }
+    }
+    *reinterpret_cast<f32x4*>(red + threadIdx.x * 4) = s;
+    __syncthreads();
+    if (threadIdx.x < cgroups) {
+      f32x4 t = {0.f, 0.f, 0.f, 0.f};
+      for (int l = 0; l < PL; l++) t += *reinterpret_cast<const f32x4*>(red + (l * cgroups + threadIdx.x) * 4);
+      *reinterpret_cast<f32x4*>(out + (cbase + threadIdx.x) * 4) = t;
+    }
+    __syncthreads();
+  }
+}
+
+// block per image: mean -> fc1 -> relu -> fc2 -> hardsigmoid
+__global__ __launch_bounds__(256) void k_se_fc(const float* __restrict__ partial, const ImgGeom* __restrict__ geom,
+                                               int chunks_alloc, int C, int Cp, const float* __restrict__ w1,
+                                               const float* __restrict__ b1, const float* __restrict__ w2,
+                                               const float* __restrict__ b2, int Cr, float slope, int residual,
+                                               float* __restrict__ scale) {
+  extern __shared__ float sm[];  // mean[Cp] + hid[Cr]
+  float* mean = sm;
+  float* hid = sm + Cp;
+  const ImgGeom g = geom[blockIdx.x];
+  const long long npix = (long long)g.H * g.W;
+  const int chunks = (int)((npix + POOL_PIX - 1) / POOL_PIX);
+  const float inv = 1.0f / (float)npix;
+  for (int c = threadIdx.x; c < Cp; c += 256) {
+    float s = 0.f;
+    for (int k = 0; k < chunks; k++) s += partial[((long long)blockIdx.x * chunks_alloc + k) * Cp + c];
+    mean[c] = s * inv;
+  }
+  __syncthreads();
+  if (w1 == nullptr) {  // plain global mean
+    for (int c = threadIdx.x; c < Cp; c += 256) scale[(long long)blockIdx.x * Cp + c] = mean[c];
+    return;
+  }
+  for (int j = threadIdx.x; j < Cr; j += 256) {  // w1 [Cr][C]
+    float s = b1[j];
+    for (int c = 0; c < C; c++) s = fmaf(mean[c], w1[j * C + c], s);
+    hid[j] = fmaxf(s, 0.f);
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < Cp; c += 256) {  // w2 [C][Cr]
+    float o = 0.f;
+    if (c < C) {
+      float s = b2[c];
+      for (int j = 0; j < Cr; j++) s = fmaf(hid[j], w2[c * Cr + j], s);
+      o = fminf(fmaxf(fmaf(s, slope, 0.5f), 0.f), 1.f);
+      if (residual) o += 1.0f;
+    }
+    scale[(long long)blockIdx.x * Cp + c] = o;
+  }
+}
+
+void se_scale(hipStream_t st, const float* x, const ImgGeom* geom, int n_img, long long max_pix, int C, int Cp,
+              const float* w1, const float* b1, const float* w2, const float* b2, int Cr, float slope, int residual,
+              float* partial, float* scale) {
+  if (n_img <= 0) return;
+  int chunks = pool_chunks(max_pix);
+  hipLaunchKernelGGL(k_pool_partial, dim3(chunks, n_img), dim3(256), 0, st, x, geom, Cp, chunks, partial);
+  hipLaunchKernelGGL(k_se_fc, dim3(n_img), dim3(256), (Cp + Cr + 4) * sizeof(float), st, partial, geom, chunks, C, Cp,
+                     w1, b1, w2, b2, Cr, slope, residual, scale);
+}
+void global_mean(hipStream_t st, const float* x, const ImgGeom* geom, int n_img, long long max_pix, int Cp,
+                 float* partial, float* out) {
+  if (n_img <= 0) return;
+  int chunks = pool_chunks(max_pix);
+  hipLaunchKernelGGL(k_pool_partial, dim3(chunks, n_img), dim3(256), 0, st, x, geom, Cp, chunks, partial);
+  hipLaunchKernelGGL(k_se_fc, dim3(n_img), dim3(256), (Cp + 4) * sizeof(float), st, partial, geom, chunks, Cp, Cp,
+                     (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, 0,
+                     0.f, 0, out);
+}
+
+__global__ __launch_bounds__(256) void k_scale_channels(float* __restrict__ x, const ImgGeom* __restrict__ geom, int Cp,
+                                                        const float* __restrict__ scale) {
+  const ImgGeom g = geom[blockIdx.y];
+  const int C4 = Cp >> 2;
+  long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (long long)g.H * g.W * C4) return;
+  int c4 = (int)(idx % C4);
+  f32x4 s = *reinterpret_cast<const f32x4*>(scale + (long long)blockIdx.y * Cp + c4 * 4);
+  f32x4* p = reinterpret_cast<f32x4*>(x + g.off * Cp) + idx;
+  f32x4 v = *p;
+  v *= s;
+  *p = v;
+}
+void scale_channels(hipStream_t st, float* x, const ImgGeom* geom, int n_img, long long max_pix, int Cp,
+                    const float* scale) {
+  if (n_img <= 0) return;
+  long long total = max_pix * (Cp / 4);
+  hipLaunchKernelGGL(k_scale_channels, dim3((unsigned)((total + 255) / 256), n_img), dim3(256), 0, st, x, geom, Cp,
+                     scale);
+}
+
+// ---------------------------------------------------------------------------
+// FPN glue
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_upsample_add(const float* __restrict__ a, const float* __restrict__ b,
+                                                      const ImgGeom* __restrict__ ga, const ImgGeom* __restrict__ gb,
+                                                      int Cp, float* __restrict__ out) {
+  const ImgGeom A = ga[blockIdx.y], B = gb[blockIdx.y];
+  const int C4 = Cp >> 2;
+  long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (long long)A.H * A.W * C4) return;
+  int c4 = (int)(idx % C4);
+  long long p = idx / C4;
+  int y = (int)(p / A.W), x = (int)(p % A.W);
+  int by = min(y >> 1, B.H - 1), bx = min(x >> 1, B.W - 1);
+  f32x4 va = *reinterpret_cast<const f32x4*>(a + (A.off + p) * Cp + c4 * 4);
+  f32x4 vb = *reinterpret_cast<const f32x4*>(b + (B.off + (long long)by * B.W + bx) * Cp + c4 * 4);
+  *reinterpret_cast<f32x4*>(out + (A.off + p) * Cp + c4 * 4) = va + vb;
+}
+void upsample_add(hipStream_t st, const float* a, const float* b, const ImgGeom* ga, const ImgGeom* gb, int n_img,
+                  long long max_pix, int Cp, float* out) {
+  if (n_img <= 0) return;
+  long long total = max_pix * (Cp / 4);
+  hipLaunchKernelGGL(k_upsample_add, dim3((unsigned)((total + 255) / 256), n_img), dim3(256), 0, st, a, b, ga, gb, Cp,
+                     out);
+}
+
+__global__ __launch_bounds__(256) void k_fpn_concat(const float* __restrict__ p5, const float* __restrict__ p4,
+                                                    const float* __restrict__ p3, const float* __restrict__ p2,
+                                                    const ImgGeom* __restrict__ g5, const ImgGeom* __restrict__ g4,
+                                                    const ImgGeom* __restrict__ g3, const ImgGeom* __restrict__ g2,
+                                                    int Cq, float* __restrict__ out) {
+  const ImgGeom G2 = g2[blockIdx.y];
+  const int Q4 = Cq >> 2, C4 = Q4 * 4;
+  long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (long long)G2.H * G2.W * C4) return;
+  int c4 = (int)(idx % C4);
+  long long p = idx / C4;
+  int y = (int)(p / G2.W), x = (int)(p % G2.W);
+  int lvl = c4 / Q4, cc = c4 % Q4;
+  const float* src;
+  ImgGeom G;
+  int sh;
+  if (lvl == 0) { src = p5; G = g5[blockIdx.y]; sh = 3; }
+  else if (lvl == 1) { src = p4; G = g4[blockIdx.y]; sh = 2; }
+  else if (lvl == 2) { src = p3; G = g3[blockIdx.y]; sh = 1; }
+  else { src = p2; G = G2; sh = 0; }
+  int sy = min(y >> sh, G.H - 1), sx = min(x >> sh, G.W - 1);
+  f32x4 v = *reinterpret_cast<const f32x4*>(src + (G.off + (long long)sy * G.W + sx) * Cq + cc * 4);
+  *reinterpret_cast<f32x4*>(out + (G2.off + p) * (4 * Cq) + c4 * 4) = v;
+}
+void fpn_concat(hipStream_t st, const float* p5, const float* p4, const float* p3, const float* p2, const ImgGeom* g5,
+                const ImgGeom* g4, const ImgGeom* g3, const ImgGeom* g2, int n_img, long long max_pix, int Cq,
+                float* out) {
+  if (n_img <= 0) return;
+  long long total = max_pix * Cq;  // 4 levels * Cq/4 groups
+  hipLaunchKernelGGL(k_fpn_concat, dim3((unsigned)((total + 255) / 256), n_img), dim3(256), 0, st, p5, p4, p3, p2, g5,
+                     g4, g3, g2, Cq, out);
+}
+
+// DB head tail. w1 [24][24][2][2] (cin, cout, dy, dx), w2 [24][1][2][2].
+__global__ __launch_bounds__(256) void k_db_head_tail(const float* __restrict__ x, const ImgGeom* __restrict__ gin,
+                                                      const ImgGeom* __restrict__ gout, const float* __restrict__ w1,
+                                                      const float* __restrict__ b1, const float* __restrict__ w2,
+                                                      const float* __restrict__ b2, float* __restrict__ out) {
+  __shared__ float sw1[4 * 24 * 24];  // [pos][ci][co]
+  __shared__ float sw2[4 * 24];       // [pos][co]
+  __shared__ float sb1[24];
+  for (int i = threadIdx.x; i < 4 * 24 * 24; i += 256) {
+    int pos = i / 576, ci = (i / 24) % 24, co = i % 24;
+    sw1[i] = w1[(ci * 24 + co) * 4 + pos];
+  }
+  for (int i = threadIdx.x; i < 96; i += 256) { int pos = i / 24, co = i % 24; sw2[i] = w2[co * 4 + pos]; }
+  if (threadIdx.x < 24) sb1[threadIdx.x] = b1[threadIdx.x];
+  __syncthreads();
+  const ImgGeom gi = gin[blockIdx.y], go = gout[blockIdx.y];
+  long long p = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (p >= (long long)gi.H * gi.W) return;
+  int iy = (int)(p / gi.W), ix = (int)(p % gi.W);
+  float in[24];
+  const f32x4* src = reinterpret_cast<const f32x4*>(x + (gi.off + p) * 24);
+#pragma unroll
+  for (int i = 0; i < 6; i++) { f32x4 v = src[i]; in[4 * i] = v[0]; in[4 * i + 1] = v[1]; in[4 * i + 2] = v[2]; in[4 * i + 3] = v[3]; }
+  const float bias2 = b2[0];
+  float o[4][4];
+#pragma unroll
+  for (int pos1 = 0; pos1 < 4; pos1++) {
+    float mid[24];
+#pragma unroll
+    for (int co = 0; co < 24; co++) mid[co] = sb1[co];
+#pragma unroll
+    for (int ci = 0; ci < 24; ci++)
+#pragma unroll
+      for (int co = 0; co < 24; co++) mid[co] = fmaf(in[ci], sw1[(pos1 * 24 + ci) * 24 + co], mid[co]);
+#pragma unroll
+    for (int pos2 = 0; pos2 < 4; pos2++) {
+      float s = bias2;
+#pragma unroll
+      for (int co = 0; co < 24; co++) s = fmaf(fmaxf(mid[co], 0.f), sw2[pos2 * 24 + co], s);
+      int oy = (pos1 >> 1) * 2 + (pos2 >> 1), ox = (pos1 & 1) * 2 + (pos2 & 1);
+      o[oy][ox] = 1.0f / (1.0f + expf(-s));
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    f32x4 v = {o[r][0], o[r][1], o[r][2], o[r][3]};
+    *reinterpret_cast<f32x4*>(out + go.off + (long long)(iy * 4 + r) * go.W + ix * 4) = v;
+  }
+}
+void db_head_tail(hipStream_t st, const float* x, const ImgGeom* gin, const ImgGeom* gout, int n_img, long long max_pix,
+                  const float* w1, const float* b1, const float* w2, const float* b2, float* out) {
+  if (n_img <= 0) return;
+  hipLaunchKernelGGL(k_db_head_tail, dim3((unsigned)((max_pix + 255) / 256), n_img), dim3(256), 0, st, x, gin, gout, w1,
+                     b1, w2, b2, out);
+}
+
+// ---------------------------------------------------------------------------
+// Pooling
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_avgpool_3x2(const float* __restrict__ x, const ImgGeom* __restrict__ gin,
+                                                     const ImgGeom* __restrict__ gout, int Cp, float* __restrict__ y,
+                                                     int ldy) {
+  const ImgGeom gi = gin[blockIdx.y], go = gout[blockIdx.y];
+  const int C4 = Cp >> 2;
+  long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (long long)go.H * go.W * C4) return;
+  int c4 = (int)(idx % C4);
+  long long p = idx / C4;
+  int oy = (int)(p / go.W), ox = (int)(p % go.W);
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int dy = 0; dy < 3; dy++)
+#pragma unroll
+    for (int dx = 0; dx < 2; dx++)
+      s += *reinterpret_cast<const f32x4*>(x + (gi.off + (long long)(oy * 3 + dy) * gi.W + ox * 2 + dx) * Cp + c4 * 4);
+  s *= (1.0f / 6.0f);
+  *reinterpret_cast<f32x4*>(y + (go.off + p) * ldy + c4 * 4) = s;
+}
+void avgpool_3x2(hipStream_t st, const float* x, const ImgGeom* gin, const ImgGeom* gout, int n_img, long long max_pix,
+                 int Cp, float* y, int ldy) {
+  if (n_img <= 0) return;
+  long long total = max_pix * (Cp / 4);
+  hipLaunchKernelGGL(k_avgpool_3x2, dim3((unsigned)((total + 255) / 256), n_img), dim3(256), 0, st, x, gin, gout, Cp, y,
+                     ldy);
+}
+__global__ __launch_bounds__(256) void k_maxpool_2x2(const float* __restrict__ x, const ImgGeom* __restrict__ gin,
+                                                     const ImgGeom* __restrict__ gout, int Cp, float* __restrict__ y) {
+  const ImgGeom gi = gin[blockIdx.y], go = gout[blockIdx.y];
+  const int C4 = Cp >> 2;
+  long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (long long)go.H * go.W * C4) return;
+  int c4 = (int)(idx % C4);
+  long long p = idx / C4;
+  int oy = (int)(p / go.W), ox = (int)(p % go.W);
+  f32x4 m;
+  bool first = true;
+#pragma unroll
+  for (int dy = 0; dy < 2; dy++)
+#pragma unroll
+    for (int dx = 0; dx < 2; dx++) {
+      f32x4 v = *reinterpret_cast<const f32x4*>(x + (gi.off + (long long)(oy * 2 + dy) * gi.W + ox * 2 + dx) * Cp + c4 * 4);
+      if (first) { m = v; first = false; }
+      else { for (int j = 0; j < 4; j++) m[j] = fmaxf(m[j], v[j]); }
+    }
+  *reinterpret_cast<f32x4*>(y + (go.off + p) * Cp + c4 * 4) = m;
+}
+void maxpool_2x2(hipStream_t st, const float* x, const ImgGeom* gin, const ImgGeom* gout, int n_img, long long max_pix,
+                 int Cp, float* y) {
+  if (n_img <= 0) return;
+  long long total = max_pix * (Cp / 4);
+  hipLaunchKernelGGL(k_maxpool_2x2, dim3((unsigned)((total + 255) / 256), n_img), dim3(256), 0, st, x, gin, gout, Cp, y);
+}
+
+// ---------------------------------------------------------------------------
+// SVTR pieces
+// ---------------------------------------------------------------------------
+// one wavefront per row; wave-shuffle reductions (two-pass mean / variance like F.layer_norm)
+__global__ __launch_bounds__(256) void k_add_layernorm(const float* __restrict__ x, const float* __restrict__ r,
+                                                       long long rows, int C, const float* __restrict__ g,
+                                                       const float* __restrict__ beta, float eps,
+                                                       float* __restrict__ y) {
+  long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  int lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  float v[4];  // C <= 256
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    int c = lane + 64 * i;
+    float t = 0.f;
+    if (c < C) { t = x[row * C + c]; if (r) t += r[row * C + c]; }
+    v[i] = t; s += t;
+  }
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  float mean = s / (float)C;
+  float ss = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; i++) { int c = lane + 64 * i; if (c < C) { float d = v[i] - mean; ss = fmaf(d, d, ss); } }
+  for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
+  float rstd = 1.0f / sqrtf(ss / (float)C + eps);
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    int c = lane + 64 * i;
+    if (c < C) y[row * C + c] = fmaf((v[i] - mean) * rstd, g[c], beta[c]);
+  }
+}
+void add_layernorm(hipStream_t st, const float* x, const float* r, long long rows, int C, const float* g,
+                   const float* beta, float eps, float* y) {
+  if (rows <= 0) return;
+  if (C > 256) throw RtError(8, "add_layernorm: C > 256");
+  hipLaunchKernelGGL(k_add_layernorm, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, x, r, rows, C, g, beta, eps, y);
+}
+
+// block = (query chunk of 64, head, image); K/V of the head streamed through LDS in tiles of 64 keys
+template <int HD>
+__global__ __launch_bounds__(64) void k_attention(const float* __restrict__ qkv, const ImgGeom* __restrict__ geom,
+                                                  int heads, float* __restrict__ out) {
+  const ImgGeom g = geom[blockIdx.z];
+  const int T = g.H * g.W, C = heads * HD, head = blockIdx.y;
+  const int t = blockIdx.x * 64 + threadIdx.x;
+  if (blockIdx.x * 64 >= T) return;
+  __shared__ float ks[64 * HD], vs[64 * HD];
+  const float scale = 1.0f / sqrtf((float)HD);
+  float qv[HD], acc[HD];
+  const bool valid = t < T;
+#pragma unroll
+  for (int d = 0; d < HD; d++) {
+    qv[d] = valid ? qkv[(g.off + t) * 3 * C + head * HD + d] * scale : 0.f;
+    acc[d] = 0.f;
+  }
+  float m = -INFINITY, l = 0.f;
+  for (int k0 = 0; k0 < T; k0 += 64) {
+    int kn = min(64, T - k0);
+    __syncthreads();
+    for (int i = threadIdx.x; i < kn * HD; i += 64) {
+      int kk = i / HD, d = i % HD;
+      ks[i] = qkv[(g.off + k0 + kk) * 3 * C + C + head * HD + d];
+      vs[i] = qkv[(g.off + k0 + kk) * 3 * C + 2 * C + head * HD + d];
+    }
+    __syncthreads();
+    for (int kk = 0; kk < kn; kk++) {
+      float s = 0.f;
+#pragma unroll
+      for (int d = 0; d < HD; d++) s = fmaf(qv[d], ks[kk * HD + d], s);
+      float mn = fmaxf(m, s);
+      float corr = expf(m - mn), p = expf(s - mn);
+      l = l * corr + p;
+#pragma unroll
+      for (int d = 0; d < HD; d++) acc[d] = fmaf(acc[d], corr, p * vs[kk * HD + d]);
+      m = mn;
+    }
+  }
+  if (valid) {
+    float inv = 1.0f / l;
+#pragma unroll
+    for (int d = 0; d < HD; d++) out[(g.off + t) * C + head * HD + d] = acc[d] * inv;
+  }
+}
+void attention(hipStream_t st, const float* qkv, const ImgGeom* geom, int n_img, int maxT, int heads, int hd,
+               float* out) {
+  if (n_img <= 0) return;
+  if (hd != 15) throw RtError(8, "attention: head dim must be 15");
+  hipLaunchKernelGGL(k_attention<15>, dim3((maxT + 63) / 64, heads, n_img), dim3(64), 0, st, qkv, geom, heads, out);
+}
+
+__global__ __launch_bounds__(256) void k_copy_channels(const float* __restrict__ src, int lds, long long rows, int C4,
+                                                       float* __restrict__ dst, int ldd, int coff) {
+  long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= rows * C4) return;
+  long long row = idx / C4;
+  int c4 = (int)(idx % C4);
+  *reinterpret_cast<f32x4*>(dst + row * ldd + coff + c4 * 4) = *reinterpret_cast<const f32x4*>(src + row * lds + c4 * 4);
+}
+void copy_channels(hipStream_t st, const float* src, int lds, long long rows, int C, float* dst, int ldd, int coff) {
+  if (rows <= 0) return;
+  long long total = rows * (C / 4);
+  hipLaunchKernelGGL(k_copy_channels, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, src, lds, rows, C / 4, dst,
+                     ldd, coff);
+}
+
+// block per row; max, sum(exp), then write (MODE 0) or argmax + max prob (MODE 1)
+template <int MODE>
+__global__ __launch_bounds__(256) void k_softmax_rows(const float* __restrict__ in, int ld, long long rows, int C,
+                                                      float* __restrict__ out, int* __restrict__ idx_out,
+                                                      float* __restrict__ prob_out) {
+  __shared__ float sv[4];
+  __shared__ int si[4];
+  __shared__ float bc[2];
+  const long long row = blockIdx.x;
+  const float* x = in + row * ld;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float m = -INFINITY;
+  int mi = 0x7fffffff;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float v = x[c];
+    if (v > m) { m = v; mi = c; }
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    float om = __shfl_xor(m, o);
+    int oi = __shfl_xor(mi, o);
+    if (om > m || (om == m && oi < mi)) { m = om; mi = oi; }
+  }
+  if (lane == 0) { sv[wave] = m; si[wave] = mi; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float bm = sv[0]; int bi = si[0];
+    for (int w = 1; w < 4; w++) if (sv[w] > bm || (sv[w] == bm && si[w] < bi)) { bm = sv[w]; bi = si[w]; }
+    bc[0] = bm; si[0] = bi;
+  }
+  __syncthreads();
+  const float gm = bc[0];
+  const int gi = si[0];
+  if (MODE == 2) {  // argmax + the maximum itself (rows that are already probabilities)
+    if (threadIdx.x == 0) { idx_out[row] = gi; prob_out[row] = gm; }
+    return;
+  }
+  float s = 0.f;
+  for (int c = threadIdx.x; c < C; c += 256) s += expf(x[c] - gm);
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  __syncthreads();
+  if (lane == 0) sv[wave] = s;
+  __syncthreads();
+  const float tot = (sv[0] + sv[1]) + (sv[2] + sv[3]);
+  if (MODE == 0) {
+    for (int c = threadIdx.x; c < C; c += 256) out[row * C + c] = expf(x[c] - gm) / tot;
+  } else if (threadIdx.x == 0) {
+    idx_out[row] = gi;
+    prob_out[row] = 1.0f / tot;  // exp(0) / sum
+  }
+}
+void softmax_rows(hipStream_t st, const float* in, int ld, long long rows, int C, float* out) {
+  if (rows <= 0) return;
+  hipLaunchKernelGGL(k_softmax_rows<0>, dim3((unsigned)rows), dim3(256), 0, st, in, ld, rows, C, out, (int*)nullptr,
+                     (float*)nullptr);
+}
+void argmax_prob_rows(hipStream_t st, const float* in, int ld, long long rows, int C, int* idx, float* prob) {
+  if (rows <= 0) return;
+  hipLaunchKernelGGL(k_softmax_rows<1>, dim3((unsigned)rows), dim3(256), 0, st, in, ld, rows, C, (float*)nullptr, idx,
+                     prob);
+}
+
+void argmax_rows(hipStream_t st, const float* in, int ld, long long rows, int C, int* idx, float* maxval) {
+  if (rows <= 0) return;
+  hipLaunchKernelGGL(k_softmax_rows<2>, dim3((unsigned)rows), dim3(256), 0, st, in, ld, rows, C, (float*)nullptr, idx,
+                     maxval);
+}
+
+}  // namespace nn
+}  // namespace rt

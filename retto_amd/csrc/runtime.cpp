@@ -1,0 +1,162 @@
+#include "runtime.h"
+
+#include <sys/stat.h>
+
+#include <cstdio>
+#include <cstring>
+
+namespace rt {
+
+// ---- sources / blob ---------------------------------------------------------------
+std::vector<uint8_t> read_source_bytes(const char* path, const void* data, size_t len, const char* what) {
+  std::vector<uint8_t> out;
+  if (path != nullptr) {
+    struct stat sb;
+    if (stat(path, &sb) != 0) throw RtError(7, std::string("Model not found: ") + path);
+    FILE* f = fopen(path, "rb");
+    if (!f) throw RtError(1, std::string("cannot open ") + path);
+    out.resize((size_t)sb.st_size);
+    size_t got = out.empty() ? 0 : fread(out.data(), 1, out.size(), f);
+    fclose(f);
+    if (got != out.size()) throw RtError(1, std::string("short read on ") + path);
+    return out;
+  }
+  if (data == nullptr || len == 0) throw RtError(7, std::string("Model not found: Empty model blob! (") + what + ")");
+  out.assign((const uint8_t*)data, (const uint8_t*)data + len);
+  return out;
+}
+
+Blob Blob::from_source(const char* path, const void* data, size_t len, const char* what) {
+  Blob b;
+  b.bytes_ = read_source_bytes(path, data, len, what);
+  b.parse();
+  return b;
+}
+
+void Blob::parse() {
+  const uint8_t* p = bytes_.data();
+  size_t n = bytes_.size();
+  auto need = [&](size_t off, size_t cnt) {
+    if (off + cnt > n) throw RtError(4, "RTWB blob truncated");
+  };
+  need(0, 16);
+  if (memcmp(p, "RTWB", 4) != 0) throw RtError(4, "not an RTWB weight blob");
+  uint32_t ver, cnt;
+  memcpy(&ver, p + 4, 4); memcpy(&cnt, p + 8, 4);
+  if (ver != 1) throw RtError(4, "unsupported RTWB version");
+  size_t off = 16;
+  struct Ent { std::string name; std::vector<int> dims; uint64_t o, nb; };
+  std::vector<Ent> ents;
+  for (uint32_t i = 0; i < cnt; i++) {
+    need(off, 2);
+    uint16_t ln; memcpy(&ln, p + off, 2); off += 2;
+    need(off, ln + 4);
+    Ent e; e.name.assign((const char*)p + off, ln); off += ln;
+    uint8_t ndim = p[off], dt = p[off + 1]; off += 4;
+    if (dt != 0) throw RtError(4, "RTWB: only f32 tensors supported");
+    need(off, 4u * ndim + 16);
+    for (int d = 0; d < ndim; d++) { uint32_t v; memcpy(&v, p + off, 4); off += 4; e.dims.push_back((int)v); }
+    memcpy(&e.o, p + off, 8); memcpy(&e.nb, p + off + 8, 8); off += 16;
+    ents.push_back(std::move(e));
+  }
+  size_t base = (off + 63) / 64 * 64;
+  for (auto& e : ents) {
+    need(base + e.o, e.nb);
+    BlobTensor t; t.dims = e.dims; t.data = reinterpret_cast<const float*>(p + base + e.o);
+    if (t.numel() * 4 != e.nb) throw RtError(4, "RTWB: size mismatch for " + e.name);
+    t_[e.name] = t;
+  }
+}
+
+const BlobTensor& Blob::get(const std::string& name) const {
+  auto it = t_.find(name);
+  if (it == t_.end()) throw RtError(4, "RTWB: missing tensor " + name);
+  return it->second;
+}
+
+// ---- arena ------------------------------------------------------------------------
+Arena::~Arena() {
+  if (base_) (void)hipFree(base_);
+  for (void* p : old_) (void)hipFree(p);
+}
+void Arena::reserve(size_t bytes) {
+  if (bytes <= cap_) return;
+  if (base_) old_.push_back(base_);
+  void* p = nullptr;
+  RT_HIP_CHECK(hipMalloc(&p, bytes));
+  base_ = (char*)p; cap_ = bytes; off_ = 0;
+}
+void* Arena::alloc_bytes(size_t bytes) {
+  bytes = (bytes + 255) & ~(size_t)255;
+  if (off_ + bytes > cap_) {
+    // allocations made earlier in this pass stay valid in the superseded block
+    size_t want = std::max<size_t>(std::max<size_t>(cap_ * 2, bytes * 2), (size_t)64 << 20);
+    reserve(want);
+  }
+  void* p = base_ + off_;
+  off_ += bytes;
+  if (off_ > peak_) peak_ = off_;
+  return p;
+}
+
+Pinned::~Pinned() { for (auto& b : blocks_) (void)hipHostFree(b.p); }
+void* Pinned::alloc_bytes(size_t bytes) {
+  bytes = (bytes + 63) & ~(size_t)63;
+  while (true) {
+    if (cur_ < blocks_.size() && off_ + bytes <= blocks_[cur_].cap) {
+      void* p = blocks_[cur_].p + off_;
+      off_ += bytes;
+      return p;
+    }
+    if (cur_ + 1 < blocks_.size()) { cur_++; off_ = 0; continue; }
+    size_t cap = std::max<size_t>(bytes, (size_t)4 << 20);
+    void* p = nullptr;
+    RT_HIP_CHECK(hipHostMalloc(&p, cap, hipHostMallocDefault));
+    blocks_.push_back(Block{(char*)p, cap});
+    cur_ = blocks_.size() - 1; off_ = 0;
+  }
+}
+
+// ---- profiler ---------------------------------------------------------------------
+Profiler::~Profiler() {
+  for (auto& r : recs_) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+  for (auto e : pool_) (void)hipEventDestroy(e);
+}
+int Profiler::id_of(const char* name) {
+  for (size_t i = 0; i < name_store_.size(); i++) if (name_store_[i] == name) return (int)i;
+  name_store_.reserve(256);
+  name_store_.push_back(name);
+  ms.push_back(0.f); calls.push_back(0);
+  names.clear();
+  for (auto& s : name_store_) names.push_back(s.c_str());
+  return (int)name_store_.size() - 1;
+}
+hipEvent_t Profiler::get_event() {
+  if (!pool_.empty()) { hipEvent_t e = pool_.back(); pool_.pop_back(); return e; }
+  hipEvent_t e; RT_HIP_CHECK(hipEventCreate(&e)); return e;
+}
+void Profiler::begin(hipStream_t st, const char* name) {
+  cur_ = id_of(name);
+  cur_a_ = get_event();
+  RT_HIP_CHECK(hipEventRecord(cur_a_, st));
+}
+void Profiler::end(hipStream_t st) {
+  hipEvent_t b = get_event();
+  RT_HIP_CHECK(hipEventRecord(b, st));
+  recs_.push_back(Rec{cur_, cur_a_, b});
+}
+void Profiler::collect() {
+  for (auto& r : recs_) {
+    float t = 0.f;
+    if (hipEventElapsedTime(&t, r.a, r.b) == hipSuccess) { ms[r.id] += t; calls[r.id] += 1; }
+    pool_.push_back(r.a); pool_.push_back(r.b);
+  }
+  recs_.clear();
+}
+void Profiler::clear() {
+  collect();
+  for (auto& v : ms) v = 0.f;
+  for (auto& c : calls) c = 0;
+}
+
+}  // namespace rt

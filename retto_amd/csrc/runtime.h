@@ -1,0 +1,99 @@
+// Small device runtime pieces shared by the nets and the session: a growing bump
+// arena for activations, a pinned staging buffer for descriptor tables, an RTWB blob
+// reader, and a per-kernel-family HIP-event profiler.
+#pragma once
+#include <map>
+#include <string>
+#include <vector>
+
+#include "common.h"
+
+namespace rt {
+
+// ---- RTWB weight blob (format: retto_amd/synth.py) -------------------------------
+struct BlobTensor {
+  std::vector<int> dims;
+  const float* data;  // points into the owning Blob's bytes
+  size_t numel() const { size_t n = 1; for (int d : dims) n *= (size_t)d; return n; }
+};
+class Blob {
+ public:
+  // worker.rs:30-56: Path must exist / Blob must be non-empty, else ModelNotFound
+  static Blob from_source(const char* path, const void* data, size_t len, const char* what);
+  const BlobTensor& get(const std::string& name) const;
+  bool has(const std::string& name) const { return t_.count(name) != 0; }
+  const std::vector<uint8_t>& bytes() const { return bytes_; }
+ private:
+  void parse();
+  std::vector<uint8_t> bytes_;
+  std::map<std::string, BlobTensor> t_;
+};
+std::vector<uint8_t> read_source_bytes(const char* path, const void* data, size_t len, const char* what);
+
+// ---- device bump arena --------------------------------------------------------------
+// alloc() never frees; reset() rewinds.  When a run needs more than the current
+// capacity the arena records the shortfall, and the owner re-runs after grow().
+class Arena {
+ public:
+  explicit Arena(size_t initial = 0) { if (initial) reserve(initial); }
+  ~Arena();
+  Arena(const Arena&) = delete;
+  Arena& operator=(const Arena&) = delete;
+  void reserve(size_t bytes);
+  void reset() { off_ = 0; }
+  size_t used() const { return off_; }
+  size_t peak() const { return peak_; }
+  size_t capacity() const { return cap_; }
+  template <typename T>
+  T* alloc(size_t count) { return reinterpret_cast<T*>(alloc_bytes(count * sizeof(T))); }
+  void* alloc_bytes(size_t bytes);
+ private:
+  char* base_ = nullptr;
+  size_t cap_ = 0, off_ = 0, peak_ = 0;
+  std::vector<void*> old_;  // superseded blocks, kept until destruction (in-flight kernels may still read them)
+};
+
+// ---- pinned host staging (descriptor tables, results) -------------------------------
+class Pinned {
+ public:
+  ~Pinned();
+  void reset() { off_ = 0; }
+  void* alloc_bytes(size_t bytes);
+  template <typename T>
+  T* alloc(size_t count) { return reinterpret_cast<T*>(alloc_bytes(count * sizeof(T))); }
+ private:
+  struct Block { char* p; size_t cap; };
+  std::vector<Block> blocks_;
+  size_t cur_ = 0, off_ = 0;
+};
+
+// ---- profiler -----------------------------------------------------------------------
+class Profiler {
+ public:
+  ~Profiler();
+  bool on = false;
+  void begin(hipStream_t st, const char* name);
+  void end(hipStream_t st);
+  void collect();  // after a stream sync: fold event pairs into the totals
+  void clear();
+  std::vector<const char*> names;
+  std::vector<float> ms;
+  std::vector<int> calls;
+ private:
+  struct Rec { int id; hipEvent_t a, b; };
+  std::vector<Rec> recs_;
+  std::vector<hipEvent_t> pool_;
+  std::vector<std::string> name_store_;
+  int id_of(const char* name);
+  hipEvent_t get_event();
+  int cur_ = -1;
+  hipEvent_t cur_a_{};
+};
+
+struct ProfScope {
+  Profiler* p; hipStream_t st;
+  ProfScope(Profiler* p_, hipStream_t s, const char* name) : p(p_), st(s) { if (p && p->on) p->begin(st, name); }
+  ~ProfScope() { if (p && p->on) p->end(st); }
+};
+
+}  // namespace rt

@@ -1,0 +1,646 @@
+#include "session.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <numeric>
+#include <sstream>
+
+#include "geom_math.h"
+
+using namespace rt;
+
+// ---------------------------------------------------------------------------
+// construction (RettoSession::new, session.rs:62-73; RettoWorker::new, worker.rs:91-98)
+// ---------------------------------------------------------------------------
+rt_session* rt_session_create(const rt_config* cfg) {
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+    throw RtError(RT_ERR_BACKEND, "no HIP device visible: libretto_hip has no CPU fallback");
+  if (cfg->device_id < 0 || cfg->device_id >= ndev) throw RtError(RT_ERR_INVALID, "device_id out of range");
+  RT_HIP_CHECK(hipSetDevice(cfg->device_id));
+  hipDeviceProp_t prop;
+  RT_HIP_CHECK(hipGetDeviceProperties(&prop, cfg->device_id));
+  if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0)
+    throw RtError(RT_ERR_BACKEND, std::string("libretto_hip is built for gfx950 only, found ") + prop.gcnArchName);
+  std::unique_ptr<rt_session> s(new rt_session());
+  s->cfg = *cfg;
+  s->device = cfg->device_id;
+  // model sources are consumed here; do not keep caller pointers
+  Blob bd = Blob::from_source(cfg->det.path, cfg->det.data, cfg->det.len, "det");
+  Blob bc = Blob::from_source(cfg->cls.path, cfg->cls.data, cfg->cls.len, "cls");
+  Blob br = Blob::from_source(cfg->rec.path, cfg->rec.data, cfg->rec.len, "rec");
+  std::vector<uint8_t> dict = read_source_bytes(cfg->dict.path, cfg->dict.data, cfg->dict.len, "dict");
+  s->cfg.det = s->cfg.cls = s->cfg.rec = s->cfg.dict = rt_model_source{nullptr, nullptr, 0};
+  RT_HIP_CHECK(hipStreamCreateWithFlags(&s->st, hipStreamNonBlocking));
+  s->det.reset(new DetNet(bd));
+  s->cls.reset(new ClsNet(bc));
+  s->rec.reset(new RecNet(br));
+  // RecCharacter::new: lines().map(trim), push " ", insert "blank" at 0
+  {
+    std::string txt((const char*)dict.data(), dict.size());
+    // String::from_utf8 validation (error.rs Utf8Error)
+    for (size_t i = 0; i < txt.size();) {
+      unsigned char c = (unsigned char)txt[i];
+      int len = c < 0x80 ? 1 : (c >> 5) == 6 ? 2 : (c >> 4) == 14 ? 3 : (c >> 3) == 30 ? 4 : 0;
+      if (len == 0 || i + len > txt.size()) throw RtError(RT_ERR_UTF8, "dictionary is not valid UTF-8");
+      for (int k = 1; k < len; k++)
+        if (((unsigned char)txt[i + k] >> 6) != 2) throw RtError(RT_ERR_UTF8, "dictionary is not valid UTF-8");
+      i += len;
+    }
+    s->dict.push_back("blank");
+    size_t pos = 0;
+    while (pos < txt.size()) {
+      size_t e = txt.find('\n', pos);
+      std::string line = txt.substr(pos, e == std::string::npos ? std::string::npos : e - pos);
+      if (!line.empty() && line.back() == '\r') line.pop_back();
+      size_t a = line.find_first_not_of(" \t\r\n\v\f"), b = line.find_last_not_of(" \t\r\n\v\f");
+      s->dict.push_back(a == std::string::npos ? std::string() : line.substr(a, b - a + 1));
+      if (e == std::string::npos) break;
+      pos = e + 1;
+    }
+    s->dict.push_back(" ");
+  }
+  if ((int)s->dict.size() != s->rec->classes())
+    throw RtError(RT_ERR_SHAPE, "dictionary has " + std::to_string(s->dict.size()) + " entries but the rec head has " +
+                                    std::to_string(s->rec->classes()) + " classes");
+  RT_HIP_CHECK(hipMalloc((void**)&s->d_flags, 64));
+  RT_HIP_CHECK(hipMemset(s->d_flags, 0, 64));
+  return s.release();
+}
+
+void rt_session::begin_call() {
+  RT_HIP_CHECK(hipSetDevice(device));
+  arena.reset(); scratch.reset(); pinned.reset();
+  last_error.clear();
+}
+void rt_session::sync() {
+  RT_HIP_CHECK(hipStreamSynchronize(st));
+  if (prof.on) prof.collect();
+}
+void rt_session::check_flags() {
+  int f[2] = {0, 0};
+  RT_HIP_CHECK(hipMemcpy(f, d_flags, sizeof(f), hipMemcpyDeviceToHost));
+  if (f[0]) {
+    RT_HIP_CHECK(hipMemset(d_flags, 0, 64));
+    throw RtError(RT_ERR_IMAGE, "thumbnail sampled outside the source image (the reference panics here)");
+  }
+}
+
+static std::vector<std::pair<int, int>> uniform_hw(int n, int h, int w) {
+  return std::vector<std::pair<int, int>>((size_t)n, std::make_pair(h, w));
+}
+
+// ---------------------------------------------------------------------------
+// L1 worker functions
+// ---------------------------------------------------------------------------
+void rt_session::det_forward(const float* nchw, int n, int h, int w, float* out) {
+  begin_call();
+  size_t ne = (size_t)n * 3 * h * w;
+  float* d_in = arena.alloc<float>(ne);
+  RT_HIP_CHECK(hipMemcpyAsync(d_in, nchw, ne * 4, hipMemcpyHostToDevice, st));
+  float* x = arena.alloc<float>((size_t)n * h * w * 4);
+  nn::nchw3_to_nhwc4(st, d_in, n, h, w, x);
+  Level L0 = make_level(uniform_hw(n, h, w));
+  RunCtx c = ctx(&scratch);
+  float* map = det->run(c, x, L0);
+  RT_HIP_CHECK(hipMemcpyAsync(out, map, (size_t)n * h * w * 4, hipMemcpyDeviceToHost, st));
+  sync();
+}
+void rt_session::cls_forward(const float* nchw, int n, int h, int w, float* out) {
+  begin_call();
+  size_t ne = (size_t)n * 3 * h * w;
+  float* d_in = arena.alloc<float>(ne);
+  RT_HIP_CHECK(hipMemcpyAsync(d_in, nchw, ne * 4, hipMemcpyHostToDevice, st));
+  float* x = arena.alloc<float>((size_t)n * h * w * 4);
+  nn::nchw3_to_nhwc4(st, d_in, n, h, w, x);
+  Level L0 = make_level(uniform_hw(n, h, w));
+  RunCtx c = ctx(&scratch);
+  float* probs = cls->run(c, x, L0);
+  RT_HIP_CHECK(hipMemcpyAsync(out, probs, (size_t)n * 2 * 4, hipMemcpyDeviceToHost, st));
+  sync();
+}
+void rt_session::rec_forward(const float* nchw, int n, int h, int w, float* out, int* t_out) {
+  int T = RecNet::tokens_for_width(w);
+  if (t_out) *t_out = T;
+  if (!out) return;
+  begin_call();
+  size_t ne = (size_t)n * 3 * h * w;
+  float* d_in = arena.alloc<float>(ne);
+  RT_HIP_CHECK(hipMemcpyAsync(d_in, nchw, ne * 4, hipMemcpyHostToDevice, st));
+  float* x = arena.alloc<float>((size_t)n * h * w * 4);
+  nn::nchw3_to_nhwc4(st, d_in, n, h, w, x);
+  Level L0 = make_level(uniform_hw(n, h, w)), Lt;
+  RunCtx c = ctx(&scratch);
+  float* logits = rec->run(c, x, L0, Lt);
+  const int C = rec->classes();
+  float* probs = scratch.alloc<float>((size_t)Lt.total * C);
+  nn::softmax_rows(st, logits, rec->logits_ld(), Lt.total, C, probs);
+  RT_HIP_CHECK(hipMemcpyAsync(out, probs, (size_t)Lt.total * C * 4, hipMemcpyDeviceToHost, st));
+  sync();
+}
+
+// ---------------------------------------------------------------------------
+// stage functions
+// ---------------------------------------------------------------------------
+// image_helper.rs:106-148 on a device image; returns the (possibly new) device buffer
+static const uint8_t* dev_resize_both(rt_session* s, const uint8_t* img, int h, int w, int* oh, int* ow) {
+  int plan[4];
+  int n = gm::resize_both_plan(h, w, s->cfg.max_side_len, s->cfg.min_side_len, plan);
+  const uint8_t* cur = img; int ch = h, cw = w;
+  for (int i = 0; i < n; i++) {
+    int nh = plan[2 * i], nw = plan[2 * i + 1];
+    uint8_t* dst = s->arena.alloc<uint8_t>(std::max<size_t>((size_t)nh * nw * 3, 4));
+    ProfScope ps(&s->prof, s->st, "thumbnail");
+    pp::thumbnail_rgb8(s->st, cur, ch, cw, dst, nh, nw, s->d_flags);
+    cur = dst; ch = nh; cw = nw;
+  }
+  *oh = ch; *ow = cw;
+  return cur;
+}
+
+void rt_session::resize_both(const uint8_t* rgb, int h, int w, uint8_t* out, int oh, int ow) {
+  begin_call();
+  uint8_t* d = arena.alloc<uint8_t>((size_t)h * w * 3);
+  RT_HIP_CHECK(hipMemcpyAsync(d, rgb, (size_t)h * w * 3, hipMemcpyHostToDevice, st));
+  int rh, rw;
+  const uint8_t* r = dev_resize_both(this, d, h, w, &rh, &rw);
+  if (rh != oh || rw != ow) throw RtError(RT_ERR_SHAPE, "resize_both: output buffer dims do not match rt_resize_both_dims");
+  RT_HIP_CHECK(hipMemcpyAsync(out, r, (size_t)rh * rw * 3, hipMemcpyDeviceToHost, st));
+  sync(); check_flags();
+}
+
+void rt_session::det_preprocess(const uint8_t* rgb, int h, int w, float* out) {
+  begin_call();
+  uint8_t* d = arena.alloc<uint8_t>((size_t)h * w * 3);
+  RT_HIP_CHECK(hipMemcpyAsync(d, rgb, (size_t)h * w * 3, hipMemcpyHostToDevice, st));
+  int dh, dw;
+  gm::resize_either_dims(h, w, cfg.det_limit_type, cfg.det_limit_side_len, &dh, &dw);
+  if (dh <= 0 || dw <= 0) throw RtError(RT_ERR_SHAPE, "det input collapses to zero size");
+  uint8_t* r = arena.alloc<uint8_t>((size_t)dh * dw * 3);
+  pp::thumbnail_rgb8(st, d, h, w, r, dh, dw, d_flags);
+  float* o = arena.alloc<float>((size_t)dh * dw * 3);
+  pp::det_normalize(st, r, dh, dw, cfg.det_scale, cfg.det_mean, cfg.det_std, 1, o);
+  RT_HIP_CHECK(hipMemcpyAsync(out, o, (size_t)dh * dw * 3 * 4, hipMemcpyDeviceToHost, st));
+  sync(); check_flags();
+}
+
+static pp::DbParams db_params(const rt_config& c) {
+  pp::DbParams p;
+  p.thresh = c.det_thresh; p.box_thresh = c.det_box_thresh; p.unclip_ratio = c.det_unclip_ratio;
+  p.min_size = c.det_min_mini_box_size; p.dilate = c.det_dilation;
+  return p;
+}
+static int max_boxes_of(const rt_config& c) { return c.max_boxes_per_page > 0 ? c.max_boxes_per_page : 4096; }
+
+void rt_session::det_postprocess(const float* pred, int h, int w, int ori_h, int ori_w, float* boxes, float* scores,
+                                 int max_out, int* n_out) {
+  begin_call();
+  float* d = arena.alloc<float>((size_t)h * w);
+  RT_HIP_CHECK(hipMemcpyAsync(d, pred, (size_t)h * w * 4, hipMemcpyHostToDevice, st));
+  const int mb = max_boxes_of(cfg);
+  dbws.reset();
+  void* ws = dbws.alloc_bytes(pp::db_workspace_bytes(h, w, mb));
+  pp::DbBox* db = arena.alloc<pp::DbBox>(mb);
+  int* cnt = arena.alloc<int>(2);
+  pp::db_postprocess(st, d, h, w, ori_h, ori_w, db_params(cfg), ws, mb, db, cnt);
+  int hc[2];
+  RT_HIP_CHECK(hipMemcpyAsync(hc, cnt, 8, hipMemcpyDeviceToHost, st));
+  sync();
+  if (hc[1]) throw RtError(RT_ERR_CAPACITY, "DB post-processing work list overflow (raise max_boxes_per_page)");
+  *n_out = hc[0];
+  int n = std::min(hc[0], max_out);
+  std::vector<pp::DbBox> hb((size_t)std::max(n, 1));
+  if (n > 0) RT_HIP_CHECK(hipMemcpy(hb.data(), db, (size_t)n * sizeof(pp::DbBox), hipMemcpyDeviceToHost));
+  for (int i = 0; i < n; i++) { memcpy(boxes + 8 * i, hb[i].pts, 32); scores[i] = hb[i].score; }
+}
+
+struct CropPlan {
+  std::vector<pp::CropDesc> descs;
+  std::vector<pp::CropRef> refs;
+  size_t pool_bytes = 0;
+  int max_pix = 0;
+};
+// image_helper.rs:223-249 planning for the boxes of one page (src = device page after resize_both)
+static void plan_crops(CropPlan& plan, const uint8_t* src, int sh, int sw, const float* boxes, int n) {
+  for (int i = 0; i < n; i++) {
+    const float* b = boxes + 8 * i;
+    gm::CropDims d = gm::crop_dims(b);
+    if (d.w <= 0 || d.h <= 0) throw RtError(RT_ERR_IMAGE, "zero-sized crop");
+    pp::CropDesc cd;
+    cd.src = src; cd.sh = sh; cd.sw = sw; cd.w = d.w; cd.h = d.h; cd.rot = d.rot;
+    if (!gm::projection_inverse(b, d.cw, d.ch, cd.inv))
+      throw RtError(RT_ERR_IMAGE, "singular crop homography (Projection::from_control_points -> None; the reference unwraps)");
+    cd.out_off = (long long)plan.pool_bytes;
+    pp::CropRef r; r.off = cd.out_off; r.h = d.rot ? d.w : d.h; r.w = d.rot ? d.h : d.w; r.pad_ = 0;
+    plan.descs.push_back(cd); plan.refs.push_back(r);
+    plan.pool_bytes += ((size_t)d.w * d.h * 3 + 63) & ~(size_t)63;
+    plan.max_pix = std::max(plan.max_pix, d.w * d.h);
+  }
+}
+
+void rt_session::crop_images(const uint8_t* rgb, int h, int w, const float* boxes, int n, uint8_t* out, size_t out_cap) {
+  begin_call();
+  uint8_t* d = arena.alloc<uint8_t>((size_t)h * w * 3);
+  RT_HIP_CHECK(hipMemcpyAsync(d, rgb, (size_t)h * w * 3, hipMemcpyHostToDevice, st));
+  CropPlan plan;
+  plan_crops(plan, d, h, w, boxes, n);
+  size_t need = 0;
+  for (auto& r : plan.refs) need += (size_t)r.h * r.w * 3;
+  if (need > out_cap) throw RtError(RT_ERR_INVALID, "crop_images: output buffer too small");
+  uint8_t* pool = arena.alloc<uint8_t>(std::max<size_t>(plan.pool_bytes, 64));
+  pp::CropDesc* dd = arena.alloc<pp::CropDesc>(std::max(n, 1));
+  if (n > 0) RT_HIP_CHECK(hipMemcpyAsync(dd, plan.descs.data(), (size_t)n * sizeof(pp::CropDesc), hipMemcpyHostToDevice, st));
+  pp::warp_crops(st, dd, n, plan.max_pix, pool);
+  size_t o = 0;
+  for (int i = 0; i < n; i++) {
+    size_t bytes = (size_t)plan.refs[i].h * plan.refs[i].w * 3;
+    RT_HIP_CHECK(hipMemcpyAsync(out + o, pool + plan.refs[i].off, bytes, hipMemcpyDeviceToHost, st));
+    o += bytes;
+  }
+  sync();
+}
+
+void rt_session::resize_norm_image(const uint8_t* crop, int h, int w, int ori_h, int ori_w, int img_h, int img_w,
+                                   float ratio, float* out) {
+  begin_call();
+  uint8_t* d = arena.alloc<uint8_t>(std::max<size_t>((size_t)h * w * 3, 4));
+  RT_HIP_CHECK(hipMemcpyAsync(d, crop, (size_t)h * w * 3, hipMemcpyHostToDevice, st));
+  pp::LineDesc L;
+  L.crop_off = 0; L.h = h; L.w = w;
+  L.W = gm::resize_norm_width(img_h, img_w, ratio);
+  L.resized_w = gm::resize_norm_resized_w(img_h, L.W, ori_h, ori_w);
+  L.out_off = 0;
+  pp::LineDesc* dl = arena.alloc<pp::LineDesc>(1);
+  RT_HIP_CHECK(hipMemcpyAsync(dl, &L, sizeof(L), hipMemcpyHostToDevice, st));
+  float* o = arena.alloc<float>((size_t)3 * img_h * std::max(L.W, 1));
+  pp::resize_norm(st, dl, 1, img_h, L.W, d, 1, o, d_flags);
+  RT_HIP_CHECK(hipMemcpyAsync(out, o, (size_t)3 * img_h * L.W * 4, hipMemcpyDeviceToHost, st));
+  sync(); check_flags();
+}
+
+void rt_session::ctc_decode(const float* probs, int n, int t, int c, int32_t* idx, float* prob, int32_t* tokens,
+                            int32_t* n_tokens, float* scores) {
+  begin_call();
+  size_t rows = (size_t)n * t;
+  float* d = arena.alloc<float>(rows * c);
+  RT_HIP_CHECK(hipMemcpyAsync(d, probs, rows * c * 4, hipMemcpyHostToDevice, st));
+  int* di = arena.alloc<int>(rows); float* dp = arena.alloc<float>(rows);
+  int* dt = arena.alloc<int>(rows); int* dn = arena.alloc<int>(n); float* ds = arena.alloc<float>(n);
+  // per (n,t): first argmax and max of the probabilities themselves (rec_processor.rs:198-199)
+  Level Lt = make_level(uniform_hw(n, 1, t));
+  RunCtx cx = ctx(&arena);
+  upload_levels(cx, {&Lt});
+  nn::argmax_rows(st, d, c, (long long)rows, c, di, dp);
+  pp::ctc_decode(st, di, dp, Lt.d, n, dt, dn, ds);
+  RT_HIP_CHECK(hipMemcpyAsync(idx, di, rows * 4, hipMemcpyDeviceToHost, st));
+  RT_HIP_CHECK(hipMemcpyAsync(prob, dp, rows * 4, hipMemcpyDeviceToHost, st));
+  RT_HIP_CHECK(hipMemcpyAsync(tokens, dt, rows * 4, hipMemcpyDeviceToHost, st));
+  RT_HIP_CHECK(hipMemcpyAsync(n_tokens, dn, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+  RT_HIP_CHECK(hipMemcpyAsync(scores, ds, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+  sync();
+}
+
+// ---------------------------------------------------------------------------
+// L2: process_pipeline over a batch of pages
+// ---------------------------------------------------------------------------
+namespace {
+struct PageState {
+  int ori_h, ori_w, after_h, after_w, det_h, det_w;
+  const uint8_t* img;  // device, after resize_both
+  const float* map;    // device det map used for boxes
+  pp::DbBox* d_boxes; int* d_count;
+  int n_boxes = 0; int first_line = 0;
+  std::vector<pp::DbBox> boxes;
+};
+
+std::string json_escape(const std::string& s) {
+  std::string o;
+  for (char ch : s) {
+    switch (ch) {
+      case '"': o += "\\\""; break;
+      case '\\': o += "\\\\"; break;
+      case '\n': o += "\\n"; break;
+      case '\r': o += "\\r"; break;
+      case '\t': o += "\\t"; break;
+      default:
+        if ((unsigned char)ch < 0x20) { char b[8]; snprintf(b, sizeof b, "\\u%04x", ch); o += b; }
+        else o += ch;
+    }
+  }
+  return o;
+}
+std::string fnum(float v) {
+  if (v != v) return "null";  // serde_json writes non-finite f32 as null
+  if (std::isinf(v)) return "null";
+  char b[32]; snprintf(b, sizeof b, "%.9g", (double)v);
+  std::string s(b);
+  if (s.find_first_of(".eEn") == std::string::npos) s += ".0";
+  return s;
+}
+}  // namespace
+
+rt_results* rt_session::run_batch(const uint8_t* const* rgb, const int* hs, const int* ws, int n_pages, int mem,
+                                  const float* const* det_map_override) {
+  begin_call();
+  dbws.reset();
+  std::unique_ptr<rt_results> res(new rt_results());
+  res->pages.resize((size_t)n_pages);
+  if (n_pages == 0) return res.release();
+  std::vector<PageState> pg((size_t)n_pages);
+  const int mb = max_boxes_of(cfg);
+
+  // ---- a2 + a3: size limits, det resize, normalise ---------------------------------
+  std::vector<std::pair<int, int>> det_hw;
+  std::vector<const uint8_t*> det_img((size_t)n_pages);
+  for (int i = 0; i < n_pages; i++) {
+    PageState& p = pg[i];
+    p.ori_h = hs[i]; p.ori_w = ws[i];
+    if (hs[i] <= 0 || ws[i] <= 0 || rgb[i] == nullptr) throw RtError(RT_ERR_IMAGE, "empty page");
+    const uint8_t* raw = rgb[i];
+    if (mem == RT_MEM_HOST) {
+      uint8_t* d = arena.alloc<uint8_t>((size_t)hs[i] * ws[i] * 3);
+      RT_HIP_CHECK(hipMemcpyAsync(d, rgb[i], (size_t)hs[i] * ws[i] * 3, hipMemcpyHostToDevice, st));
+      raw = d;
+    }
+    p.img = dev_resize_both(this, raw, hs[i], ws[i], &p.after_h, &p.after_w);
+    if (p.after_h <= 0 || p.after_w <= 0) throw RtError(RT_ERR_SHAPE, "page collapses to zero size in resize_both");
+    gm::resize_either_dims(p.after_h, p.after_w, cfg.det_limit_type, cfg.det_limit_side_len, &p.det_h, &p.det_w);
+    if (p.det_h <= 0 || p.det_w <= 0) throw RtError(RT_ERR_SHAPE, "det input collapses to zero size");
+    if (p.det_h == p.after_h && p.det_w == p.after_w) det_img[i] = p.img;  // thumbnail at ratio 1 is the identity
+    else {
+      uint8_t* d = arena.alloc<uint8_t>((size_t)p.det_h * p.det_w * 3);
+      ProfScope ps(&prof, st, "thumbnail");
+      pp::thumbnail_rgb8(st, p.img, p.after_h, p.after_w, d, p.det_h, p.det_w, d_flags);
+      det_img[i] = d;
+    }
+    det_hw.push_back({p.det_h, p.det_w});
+  }
+
+  // ---- a4: det network in launch groups -------------------------------------------
+  long long group_px = cfg.det_sub_batch > 0 ? 0 : (long long)8 * 960 * 960;
+  std::vector<double*> sum_parts; std::vector<int> sum_counts;
+  for (int g0 = 0; g0 < n_pages;) {
+    int g1 = g0; long long px = 0;
+    while (g1 < n_pages) {
+      long long add = (long long)det_hw[g1].first * det_hw[g1].second;
+      if (g1 > g0 && ((cfg.det_sub_batch > 0 && g1 - g0 >= cfg.det_sub_batch) || (cfg.det_sub_batch <= 0 && px + add > group_px))) break;
+      px += add; g1++;
+    }
+    std::vector<std::pair<int, int>> hw(det_hw.begin() + g0, det_hw.begin() + g1);
+    Level L0 = make_level(hw);
+    scratch.reset();
+    float* x = scratch.alloc<float>((size_t)L0.total * 4);
+    for (int i = g0; i < g1; i++) {
+      ProfScope ps(&prof, st, "det_normalize");
+      pp::det_normalize(st, det_img[i], pg[i].det_h, pg[i].det_w, cfg.det_scale, cfg.det_mean, cfg.det_std, 0,
+                        x + L0.h[i - g0].off * 4);
+    }
+    RunCtx c = ctx(&scratch);
+    float* map = det->run(c, x, L0);
+    // keep the maps beyond the scratch rewind
+    float* keep = arena.alloc<float>((size_t)L0.total);
+    RT_HIP_CHECK(hipMemcpyAsync(keep, map, (size_t)L0.total * 4, hipMemcpyDeviceToDevice, st));
+    for (int i = g0; i < g1; i++) pg[i].map = keep + L0.h[i - g0].off;
+    int nb = pp::sum_blocks(L0.total);
+    double* parts = arena.alloc<double>(nb);
+    pp::sum_partial(st, keep, L0.total, parts);
+    sum_parts.push_back(parts); sum_counts.push_back(nb);
+    g0 = g1;
+  }
+
+  // ---- a5: DB post-processing per page (on device; stream-ordered workspace reuse) --
+  size_t ws_bytes = 0;
+  for (auto& p : pg) ws_bytes = std::max(ws_bytes, pp::db_workspace_bytes(p.det_h, p.det_w, mb));
+  void* wsp = dbws.alloc_bytes(ws_bytes);
+  for (int i = 0; i < n_pages; i++) {
+    PageState& p = pg[i];
+    const float* pred = p.map;
+    if (det_map_override && det_map_override[i]) {
+      if (mem == RT_MEM_HOST) {
+        float* d = arena.alloc<float>((size_t)p.det_h * p.det_w);
+        RT_HIP_CHECK(hipMemcpyAsync(d, det_map_override[i], (size_t)p.det_h * p.det_w * 4, hipMemcpyHostToDevice, st));
+        pred = d;
+      } else pred = det_map_override[i];
+    }
+    p.d_boxes = arena.alloc<pp::DbBox>(mb);
+    p.d_count = arena.alloc<int>(2);
+    ProfScope ps(&prof, st, "db_postprocess");
+    pp::db_postprocess(st, pred, p.det_h, p.det_w, p.after_h, p.after_w, db_params(cfg), wsp, mb, p.d_boxes, p.d_count);
+  }
+  // metadata round trip #1: box lists (a few KB per page); pixels and tensors stay on the device
+  int* h_counts = pinned.alloc<int>((size_t)2 * n_pages);
+  for (int i = 0; i < n_pages; i++)
+    RT_HIP_CHECK(hipMemcpyAsync(h_counts + 2 * i, pg[i].d_count, 8, hipMemcpyDeviceToHost, st));
+  sync(); check_flags();
+  int total_lines = 0;
+  for (int i = 0; i < n_pages; i++) {
+    if (h_counts[2 * i + 1]) throw RtError(RT_ERR_CAPACITY, "DB post-processing work list overflow (raise max_boxes_per_page)");
+    pg[i].n_boxes = h_counts[2 * i];
+    pg[i].first_line = total_lines;
+    total_lines += pg[i].n_boxes;
+    pg[i].boxes.resize((size_t)pg[i].n_boxes);
+    if (pg[i].n_boxes)
+      RT_HIP_CHECK(hipMemcpyAsync(pg[i].boxes.data(), pg[i].d_boxes, (size_t)pg[i].n_boxes * sizeof(pp::DbBox),
+                                  hipMemcpyDeviceToHost, st));
+  }
+  sync();
+  for (size_t g = 0; g < sum_parts.size(); g++) {
+    std::vector<double> hp((size_t)sum_counts[g]);
+    RT_HIP_CHECK(hipMemcpy(hp.data(), sum_parts[g], hp.size() * 8, hipMemcpyDeviceToHost));
+    for (double v : hp) res->det_checksum += v;
+  }
+
+  // ---- a6: crops --------------------------------------------------------------------
+  CropPlan plan;
+  for (int i = 0; i < n_pages; i++) {
+    std::vector<float> b((size_t)pg[i].n_boxes * 8);
+    for (int k = 0; k < pg[i].n_boxes; k++) memcpy(&b[8 * k], pg[i].boxes[k].pts, 32);
+    plan_crops(plan, pg[i].img, pg[i].after_h, pg[i].after_w, b.data(), pg[i].n_boxes);
+  }
+  const int NL = total_lines;
+  std::vector<int> h_label(std::max(NL, 1)), h_ntok(std::max(NL, 1));
+  std::vector<float> h_cscore(std::max(NL, 1)), h_rscore(std::max(NL, 1));
+  std::vector<int> h_tokens; std::vector<long long> tok_off((size_t)NL + 1, 0);
+  if (NL > 0) {
+    uint8_t* pool = arena.alloc<uint8_t>(plan.pool_bytes + 64);
+    pp::CropDesc* d_desc = arena.alloc<pp::CropDesc>(NL);
+    pp::CropRef* d_refs = arena.alloc<pp::CropRef>(NL);
+    {
+      pp::CropDesc* hd = pinned.alloc<pp::CropDesc>(NL);
+      pp::CropRef* hr = pinned.alloc<pp::CropRef>(NL);
+      memcpy(hd, plan.descs.data(), (size_t)NL * sizeof(pp::CropDesc));
+      memcpy(hr, plan.refs.data(), (size_t)NL * sizeof(pp::CropRef));
+      RT_HIP_CHECK(hipMemcpyAsync(d_desc, hd, (size_t)NL * sizeof(pp::CropDesc), hipMemcpyHostToDevice, st));
+      RT_HIP_CHECK(hipMemcpyAsync(d_refs, hr, (size_t)NL * sizeof(pp::CropRef), hipMemcpyHostToDevice, st));
+    }
+    { ProfScope ps(&prof, st, "warp_crops");
+      pp::warp_crops(st, d_desc, NL, plan.max_pix, pool); }
+
+    // ---- a8 + a9: angle classifier over every crop -------------------------------
+    // (cls_processor.rs:127-172: batches of 6 sorted by aspect; the classifier is
+    //  per-crop independent, so batch composition does not change any value)
+    const int ch = cfg.cls_image_shape[1], cw = cfg.cls_image_shape[2];
+    int* d_label = arena.alloc<int>(NL); float* d_cscore = arena.alloc<float>(NL);
+    {
+      const int CG = 2048;
+      for (int c0 = 0; c0 < NL; c0 += CG) {
+        int cn = std::min(CG, NL - c0);
+        scratch.reset();
+        pp::LineDesc* hl = pinned.alloc<pp::LineDesc>(cn);
+        int* hrow = pinned.alloc<int>(cn);
+        for (int k = 0; k < cn; k++) {
+          const pp::CropRef& r = plan.refs[c0 + k];
+          pp::LineDesc L;
+          L.crop_off = r.off; L.h = r.h; L.w = r.w; L.W = cw;
+          L.resized_w = gm::resize_norm_resized_w(ch, cw, r.h, r.w);
+          L.out_off = (long long)k * ch * cw * 4;
+          hl[k] = L; hrow[k] = c0 + k;
+        }
+        pp::LineDesc* dl = scratch.alloc<pp::LineDesc>(cn);
+        int* drow = scratch.alloc<int>(cn);
+        RT_HIP_CHECK(hipMemcpyAsync(dl, hl, (size_t)cn * sizeof(pp::LineDesc), hipMemcpyHostToDevice, st));
+        RT_HIP_CHECK(hipMemcpyAsync(drow, hrow, (size_t)cn * 4, hipMemcpyHostToDevice, st));
+        float* x = scratch.alloc<float>((size_t)cn * ch * cw * 4);
+        { ProfScope ps(&prof, st, "resize_norm");
+          pp::resize_norm(st, dl, cn, ch, cw, pool, 0, x, d_flags); }
+        Level L0 = make_level(uniform_hw(cn, ch, cw));
+        RunCtx c = ctx(&scratch);
+        float* probs = cls->run(c, x, L0);
+        ProfScope ps(&prof, st, "cls_post_rotate");
+        pp::cls_post_rotate(st, probs, drow, cn, cfg.cls_thresh, d_refs, pool, plan.max_pix, d_label, d_cscore);
+      }
+    }
+
+    // ---- a10 + a11 + a12: recognition ----------------------------------------------
+    // per page: order by h/w descending (stable), chunks of batch_num, running max_wh_ratio
+    const int rh = cfg.rec_image_shape[1], rw = cfg.rec_image_shape[2];
+    std::vector<pp::LineDesc> lines((size_t)NL);
+    std::vector<int> line_W((size_t)NL);
+    for (int i = 0; i < n_pages; i++) {
+      int nb = pg[i].n_boxes, f = pg[i].first_line;
+      std::vector<int> order((size_t)nb);
+      std::iota(order.begin(), order.end(), 0);
+      std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
+        double ra = (double)plan.refs[f + a].h / (double)plan.refs[f + a].w;
+        double rb = (double)plan.refs[f + b].h / (double)plan.refs[f + b].w;
+        return ra > rb;  // Reverse(OrderedFloat(ori_ratio))
+      });
+      float max_wh_ratio = (float)rw / (float)rh;
+      for (int s0 = 0; s0 < nb; s0 += cfg.rec_batch_num) {
+        int s1 = std::min(nb, s0 + cfg.rec_batch_num);
+        for (int k = s0; k < s1; k++) {
+          const pp::CropRef& r = plan.refs[f + order[k]];
+          float wh = (float)r.w / (float)r.h;
+          if (wh > max_wh_ratio) max_wh_ratio = wh;
+        }
+        int W = gm::resize_norm_width(rh, rw, max_wh_ratio);
+        for (int k = s0; k < s1; k++) {
+          int li = f + order[k];
+          const pp::CropRef& r = plan.refs[li];
+          pp::LineDesc L;
+          L.crop_off = r.off; L.h = r.h; L.w = r.w; L.W = W;
+          L.resized_w = gm::resize_norm_resized_w(rh, W, r.h, r.w);
+          L.out_off = 0;
+          lines[li] = L; line_W[li] = W;
+        }
+      }
+    }
+    for (int l = 0; l < NL; l++) tok_off[l + 1] = tok_off[l] + RecNet::tokens_for_width(line_W[l]);
+    const long long total_tok = tok_off[NL];
+    int* d_idx = arena.alloc<int>(std::max<long long>(total_tok, 1));
+    float* d_prob = arena.alloc<float>(std::max<long long>(total_tok, 1));
+    int* d_tok = arena.alloc<int>(std::max<long long>(total_tok, 1));
+    int* d_ntok = arena.alloc<int>(NL); float* d_rscore = arena.alloc<float>(NL);
+    const long long REC_GROUP_PX = (long long)48 * 320 * 768;
+    for (int l0 = 0; l0 < NL;) {
+      int l1 = l0; long long px = 0;
+      while (l1 < NL) { long long add = (long long)rh * line_W[l1]; if (l1 > l0 && px + add > REC_GROUP_PX) break; px += add; l1++; }
+      int ln = l1 - l0;
+      scratch.reset();
+      std::vector<std::pair<int, int>> hw;
+      pp::LineDesc* hl = pinned.alloc<pp::LineDesc>(ln);
+      long long off = 0;
+      for (int k = 0; k < ln; k++) {
+        hl[k] = lines[l0 + k];
+        hl[k].out_off = off * 4;
+        off += (long long)rh * line_W[l0 + k];
+        hw.push_back({rh, line_W[l0 + k]});
+      }
+      pp::LineDesc* dl = scratch.alloc<pp::LineDesc>(ln);
+      RT_HIP_CHECK(hipMemcpyAsync(dl, hl, (size_t)ln * sizeof(pp::LineDesc), hipMemcpyHostToDevice, st));
+      float* x = scratch.alloc<float>((size_t)off * 4);
+      int maxW = 0; for (auto& p : hw) maxW = std::max(maxW, p.second);
+      { ProfScope ps(&prof, st, "resize_norm");
+        pp::resize_norm(st, dl, ln, rh, maxW, pool, 0, x, d_flags); }
+      Level L0 = make_level(hw), Lt;
+      RunCtx c = ctx(&scratch);
+      float* logits = rec->run(c, x, L0, Lt);
+      if (Lt.total != tok_off[l1] - tok_off[l0]) throw RtError(RT_ERR_SHAPE, "token count mismatch");
+      { ProfScope ps(&prof, st, "ctc_argmax");
+        nn::argmax_prob_rows(st, logits, rec->logits_ld(), Lt.total, rec->classes(), d_idx + tok_off[l0], d_prob + tok_off[l0]); }
+      { ProfScope ps(&prof, st, "ctc_decode");
+        pp::ctc_decode(st, d_idx + tok_off[l0], d_prob + tok_off[l0], Lt.d, ln, d_tok + tok_off[l0], d_ntok + l0, d_rscore + l0); }
+      l0 = l1;
+    }
+    // metadata round trip #2: labels, scores, token ids
+    h_tokens.resize((size_t)std::max<long long>(total_tok, 1));
+    RT_HIP_CHECK(hipMemcpyAsync(h_label.data(), d_label, (size_t)NL * 4, hipMemcpyDeviceToHost, st));
+    RT_HIP_CHECK(hipMemcpyAsync(h_cscore.data(), d_cscore, (size_t)NL * 4, hipMemcpyDeviceToHost, st));
+    RT_HIP_CHECK(hipMemcpyAsync(h_ntok.data(), d_ntok, (size_t)NL * 4, hipMemcpyDeviceToHost, st));
+    RT_HIP_CHECK(hipMemcpyAsync(h_rscore.data(), d_rscore, (size_t)NL * 4, hipMemcpyDeviceToHost, st));
+    if (total_tok > 0) RT_HIP_CHECK(hipMemcpyAsync(h_tokens.data(), d_tok, (size_t)total_tok * 4, hipMemcpyDeviceToHost, st));
+    sync(); check_flags();
+  }
+
+  // ---- results (session.rs:94-105) ---------------------------------------------------
+  static const uint16_t LABELS[2] = {0, 180};
+  for (int i = 0; i < n_pages; i++) {
+    rt_results::Page& P = res->pages[i];
+    const PageState& p = pg[i];
+    int nb = p.n_boxes;
+    P.boxes.resize((size_t)nb * 8); P.det_scores.resize(nb); P.cls_labels.resize(nb); P.cls_scores.resize(nb);
+    P.rec_scores.resize(nb); P.tokens.resize(nb); P.text.resize(nb);
+    for (int k = 0; k < nb; k++) {
+      float b[8]; memcpy(b, p.boxes[k].pts, 32);
+      gm::scale_and_clip(b, (double)p.after_w, (double)p.after_h, (double)p.ori_w, (double)p.ori_h);
+      memcpy(&P.boxes[8 * k], b, 32);
+      P.det_scores[k] = p.boxes[k].score;
+      int li = p.first_line + k;
+      P.cls_labels[k] = LABELS[h_label[li] ? 1 : 0]; P.cls_scores[k] = h_cscore[li];
+      P.rec_scores[k] = h_rscore[li];
+      P.tokens[k].assign(h_tokens.begin() + tok_off[li], h_tokens.begin() + tok_off[li] + h_ntok[li]);
+      std::string t;
+      for (int id : P.tokens[k]) t += dict[(size_t)id];
+      P.text[k] = t;
+    }
+  }
+  return res.release();
+}
+
+// RettoWorkerStageResult JSON (serde derive shapes; retto-wasm/fe/index.ts:5-42)
+const char* rt_results_json_impl(rt_results* r, int page, int stage) {
+  rt_results::Page& P = r->pages[(size_t)page];
+  std::ostringstream o;
+  size_t n = P.det_scores.size();
+  if (stage == 0) {
+    o << "[";
+    for (size_t k = 0; k < n; k++) {
+      if (k) o << ",";
+      o << "{\"boxes\":{\"inner\":[";
+      for (int q = 0; q < 4; q++) { if (q) o << ","; o << "{\"x\":" << fnum(P.boxes[8 * k + 2 * q]) << ",\"y\":" << fnum(P.boxes[8 * k + 2 * q + 1]) << "}"; }
+      o << "]},\"score\":" << fnum(P.det_scores[k]) << "}";
+    }
+    o << "]";
+  } else if (stage == 1) {
+    o << "[";
+    for (size_t k = 0; k < n; k++) { if (k) o << ","; o << "{\"label\":{\"label\":" << P.cls_labels[k] << ",\"score\":" << fnum(P.cls_scores[k]) << "}}"; }
+    o << "]";
+  } else {
+    o << "[";
+    for (size_t k = 0; k < n; k++) { if (k) o << ","; o << "{\"text\":\"" << json_escape(P.text[k]) << "\",\"score\":" << fnum(P.rec_scores[k]) << "}"; }
+    o << "]";
+  }
+  P.json[stage] = o.str();
+  return P.json[stage].c_str();
+}

@@ -1,0 +1,69 @@
+// Host scheduler: the MI355X counterpart of RettoSession::process_pipeline
+// (/root/reference/retto-core/src/session.rs:75-106) over a batch of pages, plus the
+// tensor-level worker entry points (worker.rs:69-73) and the stage functions.
+#pragma once
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/retto_hip.h"
+#include "nets.h"
+#include "prepost.h"
+#include "runtime.h"
+
+struct rt_results {
+  struct Page {
+    std::vector<float> boxes;        // n x 8, original-image coordinates
+    std::vector<float> det_scores;
+    std::vector<uint16_t> cls_labels;
+    std::vector<float> cls_scores;
+    std::vector<float> rec_scores;
+    std::vector<std::vector<int32_t>> tokens;
+    std::vector<std::string> text;
+    std::string json[3];
+  };
+  std::vector<Page> pages;
+  double det_checksum = 0.0;
+};
+
+struct rt_session {
+  rt_config cfg{};
+  int device = 0;
+  hipStream_t st = nullptr;
+  rt::Arena arena;      // lives for one API call: pages, maps, crops, descriptors, outputs
+  rt::Arena scratch;    // network activations; rewound per launch group
+  rt::Arena dbws;       // DB post-processing workspace (stream-ordered reuse across pages)
+  rt::Pinned pinned;
+  rt::Profiler prof;
+  std::unique_ptr<rt::DetNet> det;
+  std::unique_ptr<rt::ClsNet> cls;
+  std::unique_ptr<rt::RecNet> rec;
+  std::vector<std::string> dict;  // RecCharacter (rec_processor.rs:29-46)
+  std::string last_error;
+  int* d_flags = nullptr;         // [0] thumbnail/resize error flag
+
+  rt::RunCtx ctx(rt::Arena* a) { return rt::RunCtx{st, a, &pinned, &prof}; }
+  void begin_call();
+  void sync();
+  void check_flags();
+
+  // L1
+  void det_forward(const float* nchw, int n, int h, int w, float* out);
+  void cls_forward(const float* nchw, int n, int h, int w, float* out);
+  void rec_forward(const float* nchw, int n, int h, int w, float* out, int* t_out);
+  // stages
+  void resize_both(const uint8_t* rgb, int h, int w, uint8_t* out, int oh, int ow);
+  void det_preprocess(const uint8_t* rgb, int h, int w, float* out);
+  void det_postprocess(const float* pred, int h, int w, int ori_h, int ori_w, float* boxes, float* scores, int max_out,
+                       int* n_out);
+  void crop_images(const uint8_t* rgb, int h, int w, const float* boxes, int n, uint8_t* out, size_t out_cap);
+  void resize_norm_image(const uint8_t* crop, int h, int w, int ori_h, int ori_w, int img_h, int img_w, float ratio,
+                         float* out);
+  void ctc_decode(const float* probs, int n, int t, int c, int32_t* idx, float* prob, int32_t* tokens,
+                  int32_t* n_tokens, float* scores);
+  // L2
+  rt_results* run_batch(const uint8_t* const* rgb, const int* hs, const int* ws, int n_pages, int mem,
+                        const float* const* det_map_override);
+};
+
+rt_session* rt_session_create(const rt_config* cfg);

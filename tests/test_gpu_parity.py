@@ -1,0 +1,184 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle on the
+same seeded inputs.  Integer / byte / index results must be bit-exact; floating-point
+network outputs are compared with the tolerance written at each test."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import nets_torch as N
+from oracle import ref_lib as R
+from retto_amd import workload
+
+pytestmark = pytest.mark.gpu
+
+# fp32 tolerance on network outputs (<= 1e-4 on the DB probability map)
+DET_ATOL = 1e-4
+
+
+def _rand_page(h, w, seed):
+    return np.random.default_rng(seed).integers(0, 256, (h, w, 3), dtype=np.uint8)
+
+
+# ---------------------------------------------------------------- a4 / a9 / a11 networks
+@pytest.mark.parametrize("n,h,w", [(1, 64, 96), (2, 160, 128), (1, 320, 320)])
+def test_det_net(hip_session, oracle_session, n, h, w):
+    x = np.random.default_rng(h + w).uniform(-1, 1, (n, 3, h, w)).astype(np.float32)
+    got = hip_session.worker.det(x)
+    ref = N.det_forward(oracle_session.wd, torch.from_numpy(x)).numpy()
+    assert got.shape == ref.shape == (n, 1, h, w)
+    assert np.isfinite(got).all()
+    err = np.abs(got - ref).max()
+    assert err <= DET_ATOL, f"det map max abs err {err}"
+
+
+def test_cls_net(hip_session, oracle_session):
+    x = np.random.default_rng(5).uniform(-1, 1, (7, 3, 48, 192)).astype(np.float32)
+    x[3] *= 0.1
+    got = hip_session.worker.cls(x)
+    ref = N.cls_forward(oracle_session.wc, torch.from_numpy(x)).numpy()
+    assert got.shape == (7, 2)
+    assert np.abs(got - ref).max() <= 1e-4
+
+
+@pytest.mark.parametrize("n,w", [(1, 320), (3, 321), (2, 487), (1, 960)])
+def test_rec_net(hip_session, oracle_session, n, w):
+    x = np.random.default_rng(w).uniform(-1, 1, (n, 3, 48, w)).astype(np.float32)
+    x[:, :, :, w // 2:] = 0.0  # zero padding like resize_norm_image
+    got = hip_session.worker.rec(x)
+    ref = N.rec_forward(oracle_session.wr, torch.from_numpy(x)).numpy()
+    assert got.shape == ref.shape
+    assert np.abs(got - ref).max() <= 2e-4
+    # token ids: bit-exact wherever the oracle's top-2 margin is not a rounding tie
+    ga, ra = got.argmax(-1), ref.argmax(-1)
+    top2 = np.sort(ref, -1)[..., -2:]
+    decisive = (top2[..., 1] - top2[..., 0]) > 1e-4
+    assert (ga[decisive] == ra[decisive]).all()
+    assert decisive.mean() > 0.9
+
+
+# ---------------------------------------------------------------- a2 / a3 preprocessing
+@pytest.mark.parametrize("h,w", [(640, 640), (96, 160), (2100, 1300), (20, 300), (50, 200)])
+def test_resize_both(hip_session, h, w):
+    img = _rand_page(h, w, 1)
+    got = hip_session.resize_both(img)
+    ref = R.resize_both(img)
+    assert got.shape == ref.shape
+    assert np.array_equal(got, ref)
+
+
+@pytest.mark.parametrize("h,w", [(640, 640), (960, 960), (96, 160), (736, 1312), (50, 200)])
+def test_det_preprocess(hip_session, h, w):
+    img = _rand_page(h, w, 2)
+    got = hip_session.det_preprocess(img)
+    ref = R.det_preprocess(img)
+    assert got.shape == ref.shape
+    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+
+
+# ---------------------------------------------------------------- a5 DB post-processing
+def _planted_cases():
+    cases = []
+    page, rects = workload.planted_page(320, 480, lines=6, seed=3)
+    cases.append(("axis", workload.planted_map(320, 480, 320, 480, rects), 320, 480))
+    cases.append(("rot", workload.planted_map_rotated(384, 512, [(256, 100, 150, 14, 12.0), (200, 250, 120, 10, -31.0),
+                                                                   (400, 200, 100, 12, 83.0), (90, 330, 60, 9, 45.0)]), 384, 512))
+    m = workload.planted_map(256, 256, 256, 256, [(0, 0, 120, 30), (200, 100, 256, 140), (10, 230, 200, 256)])
+    cases.append(("border", m, 256, 256))
+    m = workload.planted_map(256, 320, 256, 320, [(20, 20, 300, 120)], shrink=0.0)
+    m[50:90, 60:260] = 0.02  # a hole
+    m[60:80, 100:200] = 0.9  # an island inside the hole
+    cases.append(("nested", m, 256, 320))
+    m = workload.planted_map(736, 736, 640, 640, workload.planted_page(640, 640, 12, 4)[1])
+    cases.append(("scaled", m, 640, 640))
+    rng = np.random.default_rng(7)
+    cases.append(("noise", rng.uniform(0, 1, (160, 192)).astype(np.float32), 160, 192))
+    blobs = (rng.uniform(0, 1, (40, 48)) > 0.6).astype(np.float32)
+    cases.append(("blobs", np.kron(blobs, np.ones((6, 6), np.float32)) * 0.9 + 0.01, 240, 288))
+    return cases
+
+
+@pytest.mark.parametrize("name,pred,oh,ow", _planted_cases(), ids=lambda v: v if isinstance(v, str) else None)
+def test_det_postprocess(hip_session, name, pred, oh, ow):
+    gb, gs = hip_session.det_postprocess(pred, oh, ow)
+    rb, rs = R.det_postprocess(pred, oh, ow)
+    assert len(gb) == len(rb), f"{name}: {len(gb)} boxes vs oracle {len(rb)}"
+    assert np.array_equal(gb, rb), f"{name}: box coordinates differ"
+    assert np.array_equal(gs.view(np.uint32), rs.view(np.uint32)), f"{name}: scores differ"
+    if name in ("axis", "rot", "scaled"):
+        assert len(gb) > 0
+
+
+# ---------------------------------------------------------------- a6 crops, a8/a10 resize-norm
+def test_crops_and_resize_norm(hip_session):
+    img = _rand_page(384, 512, 11)
+    pred = workload.planted_map_rotated(384, 512, [(256, 100, 150, 14, 12.0), (200, 250, 120, 10, -31.0),
+                                                   (400, 200, 100, 12, 83.0), (90, 330, 60, 9, 0.0)])
+    boxes, _ = R.det_postprocess(pred, 384, 512)
+    assert len(boxes) >= 3
+    got = hip_session.crop_images(img, boxes)
+    for b, g in zip(boxes, got):
+        ref = R.get_crop_img(img, b)
+        assert g.shape == ref.shape
+        assert np.array_equal(g, ref)
+        for (img_w, ratio) in ((192, 0.0), (320, 320 / 48), (320, 11.3)):
+            a = hip_session.resize_norm_image(g, g.shape[0], g.shape[1], 48, img_w, ratio)
+            r = R.resize_norm_image(ref, ref.shape[0], ref.shape[1], 48, img_w, ratio)
+            assert a.shape == r.shape
+            assert np.array_equal(a.view(np.uint32), r.view(np.uint32))
+
+
+def test_resize_norm_upscale(hip_session):
+    crop = _rand_page(17, 140, 12)  # h < 48: fractional (upscaling) thumbnail paths
+    a = hip_session.resize_norm_image(crop, 17, 140, 48, 320, 320 / 48)
+    r = R.resize_norm_image(crop, 17, 140, 48, 320, 320 / 48)
+    assert np.array_equal(a.view(np.uint32), r.view(np.uint32))
+
+
+# ---------------------------------------------------------------- a12 CTC
+def test_ctc_decode(hip_session):
+    rng = np.random.default_rng(13)
+    n, t, c = 5, 40, 6625
+    p = rng.uniform(0, 1e-4, (n, t, c)).astype(np.float32)
+    ids = rng.integers(0, 50, (n, t))
+    ids[0] = 0                      # all blank -> NaN score
+    ids[1, 5:15] = 7                # repeats collapse
+    ids[2, ::2] = 0                 # blanks between repeats keep both
+    for i in range(n):
+        for k in range(t):
+            p[i, k, ids[i, k]] = 0.5 + 0.4 * rng.random()
+    p[3, 4, 9] = p[3, 4, 3] = 0.95  # tie: first index wins
+    gi, gp, gt, gs = hip_session.ctc_decode(p)
+    ri, rp, rt, rs = R.ctc_decode(p)
+    assert np.array_equal(gi, ri)
+    assert np.array_equal(gp.view(np.uint32), rp.view(np.uint32))
+    assert all(np.array_equal(a, b) for a, b in zip(gt, rt))
+    assert np.array_equal(gs.view(np.uint32), rs.view(np.uint32))
+    assert np.isnan(gs[0])
+
+
+# ---------------------------------------------------------------- a1 whole pipeline
+def test_pipeline_teacher_forced(hip_session, oracle_session):
+    """Full session: boxes / cls labels / token ids bit-exact when the oracle's three
+    workers are fed by the HIP worker (so both sides see identical fp32 tensors)."""
+    pages, maps = [], []
+    for seed, (h, w, L) in enumerate([(640, 640, 8), (480, 704, 5)]):
+        page, rects = workload.planted_page(h, w, L, seed + 20)
+        dh, dw = R.resize_either_dims(h, w)
+        pages.append(page); maps.append(workload.planted_map(dh, dw, h, w, rects))
+    res = hip_session.run_batch(pages, det_map_override=maps)
+    oracle_session.det_worker = hip_session.worker.det
+    oracle_session.cls_worker = hip_session.worker.cls
+    oracle_session.rec_worker = hip_session.worker.rec
+    for page, m, r in zip(pages, maps, res):
+        o = oracle_session.run(page, det_map_override=m)
+        assert len(r.det_result) == len(o.det_boxes) > 0
+        gb = np.stack([d.boxes.as_array() for d in r.det_result])
+        assert np.array_equal(gb, o.det_boxes)
+        assert np.array_equal(np.array([d.score for d in r.det_result], np.float32).view(np.uint32),
+                              o.det_scores.view(np.uint32))
+        assert [c.label.label for c in r.cls_result] == list(o.cls_labels)
+        np.testing.assert_allclose([c.label.score for c in r.cls_result], o.cls_scores, atol=1e-5)
+        for k, (g, ot) in enumerate(zip(r.rec_result, o.rec_tokens)):
+            assert np.array_equal(g.tokens, ot), f"line {k} tokens differ"
+            assert g.text == o.rec_text[k]
+        np.testing.assert_allclose([g.score for g in r.rec_result], o.rec_scores, rtol=1e-4, equal_nan=True)
