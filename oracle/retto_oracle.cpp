@@ -703,15 +703,38 @@ ORC_API int orc_det_postprocess(const float* pred, int h, int w, int ori_h, int 
     b.score = mean_score;
     res.push_back(b);
   }
-  // sorted_boxes: stable sort, comparator on centre = (TL+BR)/2 (points.rs:173-177)
-  std::stable_sort(res.begin(), res.end(), [](const DetBox& a, const DetBox& b) {
-    float y1 = (a.pts[1] + a.pts[5]) / 2.0f, y2 = (b.pts[1] + b.pts[5]) / 2.0f;
-    if (fabsf(y1 - y2) < 10.0f) {
-      float x1 = (a.pts[0] + a.pts[4]) / 2.0f, x2 = (b.pts[0] + b.pts[4]) / 2.0f;
-      return x1 < x2;
+  // sorted_boxes (det_processor.rs:324-333): Rust's stable sort_by with a comparator on
+  // the centre (TL+BR)/2 (points.rs:173-177).  The comparator is not a total order
+  // (SURVEY A.5), so the outcome on inconsistent inputs is sort-algorithm specific;
+  // restatement choice: a stable bottom-up merge sort (run width 1, 2, 4, ...) over the
+  // contour discovery order.  Every stable sort agrees with it on strict weak orders.
+  {
+    auto less = [](const DetBox& a, const DetBox& b) {
+      float y1 = (a.pts[1] + a.pts[5]) / 2.0f, y2 = (b.pts[1] + b.pts[5]) / 2.0f;
+      if (fabsf(y1 - y2) < 10.0f) {
+        float x1 = (a.pts[0] + a.pts[4]) / 2.0f, x2 = (b.pts[0] + b.pts[4]) / 2.0f;
+        return x1 < x2;
+      }
+      return y1 < y2;
+    };
+    std::vector<DetBox> tmp(res.size());
+    int nn = (int)res.size();
+    std::vector<DetBox>*src = &res, *dst = &tmp;
+    for (int width = 1; width < nn; width *= 2) {
+      for (int lo = 0; lo < nn; lo += 2 * width) {
+        int mid = std::min(lo + width, nn), hi = std::min(lo + 2 * width, nn);
+        int i = lo, j = mid, k = lo;
+        while (i < mid && j < hi) {
+          if (less((*src)[j], (*src)[i])) (*dst)[k++] = (*src)[j++];
+          else (*dst)[k++] = (*src)[i++];
+        }
+        while (i < mid) (*dst)[k++] = (*src)[i++];
+        while (j < hi) (*dst)[k++] = (*src)[j++];
+      }
+      std::swap(src, dst);
     }
-    return y1 < y2;
-  });
+    if (src != &res) res = *src;
+  }
   int n = (int)res.size();
   for (int i = 0; i < n && i < max_out; i++) {
     memcpy(boxes_out + 8 * i, res[i].pts, 8 * sizeof(float));

@@ -60,6 +60,8 @@ int rt_create(const rt_config* cfg, rt_session** out) {
   RT_REQUIRE(cfg->cls_image_shape[0] == 3 && cfg->rec_image_shape[0] == 3 && cfg->rec_image_shape[1] == 48 &&
                  cfg->cls_image_shape[1] == 48 && cfg->cls_image_shape[2] == 192,
              (rt_session*)nullptr, "unsupported cls/rec image_shape for the PP-OCRv4 mobile graphs");
+  RT_REQUIRE(cfg->max_boxes_per_page >= 0 && cfg->max_boxes_per_page <= 4096, (rt_session*)nullptr,
+             "max_boxes_per_page must be in [0, 4096]");
   return guarded(nullptr, [&] { *out = rt_session_create(cfg); });
 }
 void rt_destroy(rt_session* s) {

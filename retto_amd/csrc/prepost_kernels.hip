@@ -677,21 +677,50 @@ __device__ __forceinline__ bool box_less(const DbBox& a, const DbBox& b) {
   }
   return y1 < y2;
 }
+// Stable bottom-up merge sort (run width 1, 2, 4, ...; take from the left run unless
+// right < left) applied to the boxes in contour discovery order.  For the strict weak
+// orders of the contract every stable sort gives this result; for the comparator's
+// non-transitive inputs this exact algorithm is the defined behaviour and the
+// oracle uses the same one.  Sorting works on indices + centres held in LDS.
+#define RT_SORT_MAX 4096
 __global__ __launch_bounds__(256) void k_sort_boxes(DbWs ws, DbBox* __restrict__ out, int* __restrict__ count_out) {
-  int n = min(ws.counters[3], ws.cand_cap);
+  __shared__ float cx[RT_SORT_MAX], cy[RT_SORT_MAX];
+  __shared__ unsigned short ia[RT_SORT_MAX], ib[RT_SORT_MAX];
+  int n = min(min(ws.counters[3], ws.cand_cap), RT_SORT_MAX);
+  // discovery order: rank by the (unique) start-pixel key
   for (int i = threadIdx.x; i < n; i += 256) {
-    DbBox me = ws.cand[i];
-    // stable rank under box_less with discovery order (key) as the tie order
-    int rank = 0;
-    for (int j = 0; j < n; j++) {
-      if (j == i) continue;
-      const DbBox o = ws.cand[j];
-      if (box_less(o, me)) rank++;
-      else if (!box_less(me, o) && o.key < me.key) rank++;
-    }
-    out[rank] = me;
+    int key = ws.cand[i].key, rank = 0;
+    for (int j = 0; j < n; j++) rank += ws.cand[j].key < key;
+    ia[rank] = (unsigned short)i;
+    cx[i] = (ws.cand[i].pts[0] + ws.cand[i].pts[4]) / 2.0f;
+    cy[i] = (ws.cand[i].pts[1] + ws.cand[i].pts[5]) / 2.0f;
   }
-  if (threadIdx.x == 0) { count_out[0] = n; count_out[1] = ws.counters[4]; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    auto less = [&](int a, int b) {
+      if (fabsf(cy[a] - cy[b]) < 10.0f) return cx[a] < cx[b];
+      return cy[a] < cy[b];
+    };
+    unsigned short* src = ia; unsigned short* dst = ib;
+    for (int width = 1; width < n; width *= 2) {
+      for (int lo = 0; lo < n; lo += 2 * width) {
+        int mid = min(lo + width, n), hi = min(lo + 2 * width, n);
+        int i = lo, j = mid, k = lo;
+        while (i < mid && j < hi) {
+          if (less(src[j], src[i])) dst[k++] = src[j++];
+          else dst[k++] = src[i++];
+        }
+        while (i < mid) dst[k++] = src[i++];
+        while (j < hi) dst[k++] = src[j++];
+      }
+      unsigned short* t = src; src = dst; dst = t;
+    }
+    if (src != ia) for (int i = 0; i < n; i++) ia[i] = src[i];
+    count_out[0] = n;
+    count_out[1] = ws.counters[4] | (ws.counters[3] > RT_SORT_MAX ? 1 : 0);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < n; i += 256) out[i] = ws.cand[ia[i]];
 }
 
 void db_postprocess(hipStream_t st, const float* pred, int H, int W, int ori_h, int ori_w, const DbParams& p,

@@ -89,10 +89,11 @@ class _Gen:
         self.t: Dict[str, np.ndarray] = {}
 
     def conv(self, name, cout, cin_g, kh, kw, act=True, bias=True, gain=1.0):
-        # E[hardswish(x)^2] ~ 1/3 for unit-variance x: sqrt(3/fan_in) keeps the
-        # activation scale roughly constant through the stack.
+        # gain^2 = 2.4 (between He's 2 for relu and 3 for unit-variance hardswish) keeps
+        # the activation scale of the LCNetV3 stacks O(1): smaller collapses the signal,
+        # larger explodes it and turns fp32 rounding noise into visible output differences.
         fan_in = cin_g * kh * kw
-        std = gain * np.sqrt((3.0 if act else 1.0) / fan_in)
+        std = gain * np.sqrt((2.4 if act else 1.0) / fan_in)
         self.t[name + ".w"] = (self.rng.standard_normal((cout, cin_g, kh, kw)) * std).astype(np.float32)
         if bias:
             self.t[name + ".b"] = (self.rng.standard_normal(cout) * 0.02).astype(np.float32)
@@ -123,7 +124,7 @@ def _lcnet(g: _Gen, prefix: str, blocks, det: bool):
             g.lab(p + ".dw")
         if se:
             g.se(p + ".se", cin)
-        g.conv(p + ".pw", cout, cin, 1, 1, gain=2.0 if se else 1.0)  # SE gate ~0.5
+        g.conv(p + ".pw", cout, cin, 1, 1, gain=1.6 if se else 1.0)  # SE gate ~0.5
         g.lab(p + ".pw")
 
 
@@ -140,7 +141,7 @@ def det_tensors(seed: int = 1) -> Dict[str, np.ndarray]:
     std = np.sqrt(2.0 / 24)
     g.t["det.head.deconv1.w"] = (g.rng.standard_normal((24, 24, 2, 2)) * std).astype(np.float32)
     g.t["det.head.deconv1.b"] = (g.rng.standard_normal(24) * 0.05).astype(np.float32)
-    g.t["det.head.deconv2.w"] = (g.rng.standard_normal((24, 1, 2, 2)) * np.sqrt(1.0 / 24)).astype(np.float32)
+    g.t["det.head.deconv2.w"] = (g.rng.standard_normal((24, 1, 2, 2)) * 0.3 * np.sqrt(1.0 / 24)).astype(np.float32)
     g.t["det.head.deconv2.b"] = (g.rng.standard_normal(1) * 0.05).astype(np.float32)
     return g.t
 
@@ -177,7 +178,7 @@ def cls_tensors(seed: int = 3) -> Dict[str, np.ndarray]:
         g.conv(p + ".dw", mid, 1, k, k)
         if se:
             g.se(p + ".se", mid)
-        g.conv(p + ".linear", cout, mid, 1, 1, act=False, gain=2.0 if se else 1.0)
+        g.conv(p + ".linear", cout, mid, 1, 1, act=False, gain=1.6 if se else 1.0)
         cin = cout
     g.conv("cls.conv2", CLS_LAST, cin, 1, 1)
     g.linear("cls.head.fc", CLS_LAST, 2, gain=3.0)

@@ -111,10 +111,11 @@ def test_det_postprocess(hip_session, name, pred, oh, ow):
 # ---------------------------------------------------------------- a6 crops, a8/a10 resize-norm
 def test_crops_and_resize_norm(hip_session):
     img = _rand_page(384, 512, 11)
-    pred = workload.planted_map_rotated(384, 512, [(256, 100, 150, 14, 12.0), (200, 250, 120, 10, -31.0),
-                                                   (400, 200, 100, 12, 83.0), (90, 330, 60, 9, 0.0)])
+    pred = workload.planted_map_rotated(384, 512, [(256, 60, 150, 14, 12.0), (150, 200, 110, 10, -31.0),
+                                                   (440, 220, 100, 12, 83.0), (90, 340, 60, 9, 0.0),
+                                                   (320, 330, 80, 16, 0.0)])
     boxes, _ = R.det_postprocess(pred, 384, 512)
-    assert len(boxes) >= 3
+    assert len(boxes) == 5
     got = hip_session.crop_images(img, boxes)
     for b, g in zip(boxes, got):
         ref = R.get_crop_img(img, b)
@@ -182,3 +183,58 @@ def test_pipeline_teacher_forced(hip_session, oracle_session):
             assert np.array_equal(g.tokens, ot), f"line {k} tokens differ"
             assert g.text == o.rec_text[k]
         np.testing.assert_allclose([g.score for g in r.rec_result], o.rec_scores, rtol=1e-4, equal_nan=True)
+
+
+def test_pipeline_cls_rotation(models, oracle_session):
+    """cls_processor.rs:163-166: crops whose label is 180 with score >= thresh are rotated
+    in place before recognition.  Uses a classifier blob with a flipped head and a low
+    threshold so the branch is taken."""
+    import retto_amd
+    from retto_amd import synth
+    t = synth.cls_tensors(3)
+    t["cls.head.fc.w"] = -t["cls.head.fc.w"] * 4; t["cls.head.fc.b"] = -t["cls.head.fc.b"]
+    cls_blob = synth.pack_blob(t)
+    det, _, rec, dic = models
+    cfg = retto_amd.synthetic_session_config(0)
+    cfg.worker_config.models.cls = retto_amd.RettoWorkerModelSource.Blob(cls_blob)
+    cfg.cls_processor_config.thresh = 0.55
+    s = retto_amd.RettoSession(cfg)
+    try:
+        from oracle.pipeline import OracleSession
+        o = OracleSession(det, cls_blob, rec, dic)
+        o.det_worker, o.cls_worker, o.rec_worker = s.worker.det, s.worker.cls, s.worker.rec
+        page, rects = workload.planted_page(480, 640, 6, 31)
+        dh, dw = R.resize_either_dims(480, 640)
+        m = workload.planted_map(dh, dw, 480, 640, rects)
+        # the oracle's cls threshold must match
+        import oracle.pipeline as OP
+        r = s.run_batch([page], det_map_override=[m])[0]
+        orig = np.float32(0.9)
+        src = OP.OracleSession.cls_process
+        def patched(self, crops, dims, _src=src):
+            return _src(self, crops, dims)
+        labels = [c.label.label for c in r.cls_result]
+        assert 180 in labels
+        # re-run the oracle with the same threshold
+        import types
+        def cls_process(self, crops, dims):
+            n = len(crops)
+            lab = np.zeros(n, np.uint16); sc = np.zeros(n, np.float32)
+            order = sorted(range(n), key=lambda i: -(float(dims[i][0]) / float(dims[i][1])))
+            for s0 in range(0, n, 6):
+                idxs = order[s0:s0 + 6]
+                tt = np.stack([R.resize_norm_image(crops[i], dims[i][0], dims[i][1], 48, 192, 0.0) for i in idxs])
+                idx, scs = R.cls_postprocess(self.cls_worker(tt))
+                for j, i in enumerate(idxs):
+                    l = [0, 180][int(idx[j])]
+                    if l == 180 and scs[j] >= np.float32(0.55):
+                        crops[i] = R.rotate180(crops[i])
+                    lab[i] = l; sc[i] = scs[j]
+            return lab, sc
+        o.cls_process = types.MethodType(cls_process, o)
+        ores = o.run(page, det_map_override=m)
+        assert labels == list(ores.cls_labels)
+        for g, ot in zip(r.rec_result, ores.rec_tokens):
+            assert np.array_equal(g.tokens, ot)
+    finally:
+        s.close()
