@@ -1,0 +1,250 @@
+#!/usr/bin/env python3
+"""bench.py -- images/sec of the end-to-end PP-OCRv4 det+cls+rec path on MI355X.
+
+Metric (BASELINE.json): images/sec end-to-end PP-OCRv4 det+rec @960x960; 1 -> 8 GPU scaling.
+Workload at every N: BASELINE config C3 -- 32 synthetic 960x960 RGB pages per GPU per
+step (weak scaling), 32 planted text lines per page, full pipeline
+(resize/normalise -> DBNet -> DB post -> crops -> angle cls -> SVTR/CTC rec) through
+libretto_hip's rt_run_batch with pages resident in HBM.  One process per GPU; weights are
+broadcast once over RCCL (torch.distributed "nccl"); there is no per-step collective.
+
+Prints ONE JSON line on rank 0 (see the driver contract) with `roofline` for the dominant
+kernel family (HIP-event times measured live on the session's stream during the timed
+region) and `cpu_baseline` (the CPU oracle timed on a bounded sample, rank 0, N=1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+FP32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: f32 MFMA / vector peak
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--pages", type=int, default=32, help="pages per GPU per step (C3: 32)")
+    ap.add_argument("--size", type=int, default=960)
+    ap.add_argument("--lines", type=int, default=32, help="planted text lines per page")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-pages", type=int, default=1, help="pages of the same workload timed on the CPU oracle")
+    ap.add_argument("--profile-all", action="store_true", help="print the per-family table to stderr")
+    return ap.parse_args()
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            print("bench.py: --gpus %d needs torch.distributed.run with %d ranks" % (a.gpus, a.gpus), file=sys.stderr)
+            sys.exit(2)
+    import torch
+    import torch.distributed as dist
+    dist_on = world > 1
+    if dist_on:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    device = local_rank if dist_on else 0
+
+    import retto_amd
+    from retto_amd import synth, workload, workmodel
+
+    # ---- weights: generated on rank 0, RCCL-broadcast once -------------------------------
+    if rank == 0:
+        blobs = list(synth.synth_models(0))
+    else:
+        blobs = [None] * 4
+    if dist_on:
+        sizes = torch.tensor([len(b) for b in blobs] if rank == 0 else [0] * 4, dtype=torch.int64, device="cuda")
+        dist.broadcast(sizes, 0)
+        out = []
+        for i, n in enumerate(sizes.tolist()):
+            t = torch.empty(n, dtype=torch.uint8, device="cuda")
+            if rank == 0:
+                t.copy_(torch.frombuffer(bytearray(blobs[i]), dtype=torch.uint8))
+            dist.broadcast(t, 0)
+            out.append(t.cpu().numpy().tobytes())
+        blobs = out
+    det_b, cls_b, rec_b, dict_b = blobs
+    cfg = retto_amd.RettoSessionConfig()
+    cfg.worker_config = retto_amd.RettoHipWorkerConfig(device=device, models=retto_amd.RettoWorkerModelProvider(
+        det=retto_amd.RettoWorkerModelSource.Blob(det_b), rec=retto_amd.RettoWorkerModelSource.Blob(rec_b),
+        cls=retto_amd.RettoWorkerModelSource.Blob(cls_b)))
+    cfg.rec_processor_config.character_source = retto_amd.RettoWorkerModelSource.Blob(dict_b)
+    sess = retto_amd.RettoSession(cfg)
+    lib, h = sess._hd.lib, sess._hd.h
+
+    # ---- synthetic pages + planted maps, staged to HBM once -------------------------------
+    import ctypes as C
+    S = a.size
+    pages, maps, d_pages, d_maps = [], [], [], []
+    for i in range(a.pages):
+        page, rects = workload.planted_page(S, S, a.lines, seed=1000 * rank + i)
+        m = workload.planted_map(S, S, S, S, rects)
+        pages.append(page); maps.append(m)
+        for arr, lst in ((page, d_pages), (m, d_maps)):
+            p = C.c_void_p()
+            assert lib.rt_device_malloc(h, arr.nbytes, C.byref(p)) == 0
+            assert lib.rt_memcpy_h2d(h, p, arr.ctypes.data, arr.nbytes) == 0
+            lst.append(p.value)
+    hs = [S] * a.pages; ws = [S] * a.pages
+
+    def step():
+        r = sess.run_batch_raw(d_pages, hs, ws, retto_amd.RT_MEM_DEVICE, d_maps)
+        return r
+
+    def barrier():
+        if dist_on:
+            dist.barrier()
+            torch.cuda.synchronize()
+        lib.rt_synchronize(h)
+
+    # warmup (also sizes the arenas)
+    n_lines = 0
+    checksum = 0.0
+    for _ in range(max(a.warmup, 1)):
+        r = step()
+        n_lines = sum(lib.rt_results_count(r, i) for i in range(a.pages))
+        checksum = lib.rt_results_det_checksum(r)
+        widths_probe = r
+        lib.rt_results_free(r)
+    sess.profile_enable(True)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        r = step()
+        lib.rt_results_free(r)
+    barrier()
+    t1 = time.perf_counter()
+    elapsed = t1 - t0
+    prof = sess.profile_get()
+    sess.profile_enable(False)
+    if dist_on:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        cnt = torch.tensor([n_lines], dtype=torch.int64, device="cuda")
+        dist.all_reduce(cnt)
+        n_lines_total = int(cnt.item())
+    else:
+        n_lines_total = n_lines
+
+    if rank != 0:
+        if dist_on:
+            dist.destroy_process_group()
+        return
+
+    total_pages = world * a.pages * a.steps
+    value = total_pages / elapsed
+    ms_per_step = 1000.0 * elapsed / a.steps
+
+    # ---- roofline of the dominant kernel family -------------------------------------------
+    # rec line widths of this rank's pages, from the same planning rule as the pipeline
+    from retto_amd import _lib as L
+    res = sess.run_batch(pages[:a.pages], det_map_override=maps[:a.pages])
+    widths = []
+    for pr in res:
+        dims = []
+        for d in pr.det_result:
+            b = d.boxes.as_array().reshape(1, 8).astype(np.float32)
+            wv = np.zeros(1, np.int32); hv = np.zeros(1, np.int32)
+            lib.rt_crop_dims(b.ctypes.data, 1, wv.ctypes.data, hv.ctypes.data)
+            dims.append((int(hv[0]), int(wv[0])))
+        order = sorted(range(len(dims)), key=lambda i: -(dims[i][0] / dims[i][1]))
+        ratio = np.float32(320) / np.float32(48)
+        for s0 in range(0, len(order), 6):
+            idx = order[s0:s0 + 6]
+            for i in idx:
+                ratio = max(ratio, np.float32(dims[i][1]) / np.float32(dims[i][0]))
+            widths += [lib.rt_resize_norm_width(48, 320, float(ratio))] * len(idx)
+    work = workmodel.det_work([(S, S)] * a.pages)
+    for k, v in workmodel.rec_work(widths).items():
+        if k in work:
+            work[k]["bytes"] += v["bytes"]; work[k]["flops"] += v["flops"]
+        else:
+            work[k] = dict(v)
+    fams = sorted(((ms, calls, name) for name, (ms, calls) in prof.items() if calls), reverse=True)
+    total_ms = sum(f[0] for f in fams)
+    if a.profile_all:
+        for ms, calls, name in fams:
+            wk = work.get(name, {"bytes": 0.0, "flops": 0.0})
+            per_step_ms = ms / a.steps
+            print("%-16s %9.3f ms/step %6d launches/step  %8.1f GB/s  %7.2f TFLOP/s" % (
+                name, per_step_ms, calls // a.steps, wk["bytes"] / per_step_ms / 1e6 if per_step_ms else 0,
+                wk["flops"] / per_step_ms / 1e9 if per_step_ms else 0), file=sys.stderr)
+        print("sum of kernel families: %.2f ms/step; wall %.2f ms/step" % (total_ms / a.steps, ms_per_step), file=sys.stderr)
+    roofline = None
+    for ms, calls, name in fams:
+        if name in work:
+            wk = work[name]
+            launches_per_step = calls / a.steps
+            avg_ms = ms / calls
+            bytes_per_launch = wk["bytes"] / launches_per_step
+            flops_per_launch = wk["flops"] / launches_per_step
+            gbs = bytes_per_launch / (avg_ms * 1e-3) / 1e9
+            tfs = flops_per_launch / (avg_ms * 1e-3) / 1e12
+            hbm_frac, mfma_frac = gbs / HBM_PEAK_GBS, tfs / FP32_PEAK_TFLOPS
+            if hbm_frac >= mfma_frac:
+                roofline = {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                            "frac": round(hbm_frac, 4), "traffic": None}
+            else:
+                roofline = {"bound": "mfma", "achieved": round(tfs, 2), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                            "frac": round(mfma_frac, 4), "traffic": None}
+            roofline.update({"kernel": name, "avg_launch_ms": round(avg_ms, 4), "launches_per_step": launches_per_step,
+                             "share_of_kernel_time": round(ms / total_ms, 3),
+                             "algorithmic_bytes_per_launch": int(bytes_per_launch),
+                             "algorithmic_flops_per_launch": int(flops_per_launch)})
+            break
+
+    # ---- CPU baseline: the oracle on a bounded sample of the same workload -------------------
+    cpu_baseline = None
+    if world == 1 and not a.no_cpu_baseline:
+        import torch as _t
+        from oracle.pipeline import OracleSession
+        o = OracleSession(det_b, cls_b, rec_b, dict_b)
+        k = max(1, min(a.cpu_pages, a.pages))
+        t0c = time.perf_counter()
+        for i in range(k):
+            o.run(pages[i], det_map_override=maps[i])
+        dt = time.perf_counter() - t0c
+        cpu_baseline = {"value": round(k / dt, 4), "unit": "images/s", "cores": _t.get_num_threads(), "kind": "port",
+                        "sample": "%d page(s) of the same %dx%d / %d-line workload through the CPU oracle "
+                                  "(oracle/pipeline.py: torch-CPU fp32 nets + C++ pre/post restatement); "
+                                  "reference ort-CPU itself is not runnable here" % (k, S, S, a.lines)}
+
+    out = {
+        "metric": "images/sec end-to-end PP-OCRv4 det+rec @960x960",
+        "value": round(value, 3), "unit": "images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "C3: PP-OCRv4 mobile det+cls+rec full pipeline, batch=%d pages of %dx%d per GPU, "
+                               "%d planted lines/page (planted DB map drives box extraction; det net fully executed, "
+                               "checksum %.6g)" % (a.pages, S, S, a.lines, checksum),
+                   "pages_per_gpu_per_step": a.pages, "lines_per_step_all_gpus": n_lines_total,
+                   "weights": "seeded synthetic, PP-OCRv4 mobile shapes", "parallelism": "dp%d (pages sharded, no per-step collective)" % world},
+        "roofline": roofline,
+        "cpu_baseline": cpu_baseline,
+    }
+    print(json.dumps(out))
+    sess.close()
+    if dist_on:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

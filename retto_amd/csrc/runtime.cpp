@@ -95,8 +95,25 @@ void* Arena::alloc_bytes(size_t bytes) {
   }
   void* p = base_ + off_;
   off_ += bytes;
-  if (off_ > peak_) peak_ = off_;
+  pass_ += bytes;
   return p;
+}
+void Arena::reset() {
+  if (pass_ > need_) need_ = pass_;
+  if (!old_.empty()) {
+    (void)hipDeviceSynchronize();
+    for (void* q : old_) (void)hipFree(q);
+    old_.clear();
+    size_t want = need_ + need_ / 8 + ((size_t)1 << 20);
+    if (want > cap_) {
+      (void)hipFree(base_);
+      base_ = nullptr; cap_ = 0;
+      void* q = nullptr;
+      RT_HIP_CHECK(hipMalloc(&q, want));
+      base_ = (char*)q; cap_ = want;
+    }
+  }
+  pass_ = 0; off_ = 0;
 }
 
 Pinned::~Pinned() { for (auto& b : blocks_) (void)hipHostFree(b.p); }

@@ -40,16 +40,20 @@ class Arena {
   Arena(const Arena&) = delete;
   Arena& operator=(const Arena&) = delete;
   void reserve(size_t bytes);
-  void reset() { off_ = 0; }
+  // Rewinds.  If the last pass had to chain blocks, the caller has synchronised the
+  // stream (end of an API call), so the chain is replaced by one block that fits the
+  // largest pass seen; steady state never allocates.
+  void reset();
+  void rewind() { if (pass_ > need_) need_ = pass_; pass_ = 0; off_ = 0; }  // stream-ordered reuse inside a call
   size_t used() const { return off_; }
-  size_t peak() const { return peak_; }
+  size_t peak() const { return need_; }
   size_t capacity() const { return cap_; }
   template <typename T>
   T* alloc(size_t count) { return reinterpret_cast<T*>(alloc_bytes(count * sizeof(T))); }
   void* alloc_bytes(size_t bytes);
  private:
   char* base_ = nullptr;
-  size_t cap_ = 0, off_ = 0, peak_ = 0;
+  size_t cap_ = 0, off_ = 0, pass_ = 0, need_ = 0;
   std::vector<void*> old_;  // superseded blocks, kept until destruction (in-flight kernels may still read them)
 };
 

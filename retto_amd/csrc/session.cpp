@@ -389,7 +389,7 @@ rt_results* rt_session::run_batch(const uint8_t* const* rgb, const int* hs, cons
     }
     std::vector<std::pair<int, int>> hw(det_hw.begin() + g0, det_hw.begin() + g1);
     Level L0 = make_level(hw);
-    scratch.reset();
+    scratch.rewind();
     float* x = scratch.alloc<float>((size_t)L0.total * 4);
     for (int i = g0; i < g1; i++) {
       ProfScope ps(&prof, st, "det_normalize");
@@ -486,7 +486,7 @@ rt_results* rt_session::run_batch(const uint8_t* const* rgb, const int* hs, cons
       const int CG = 2048;
       for (int c0 = 0; c0 < NL; c0 += CG) {
         int cn = std::min(CG, NL - c0);
-        scratch.reset();
+        scratch.rewind();
         pp::LineDesc* hl = pinned.alloc<pp::LineDesc>(cn);
         int* hrow = pinned.alloc<int>(cn);
         for (int k = 0; k < cn; k++) {
@@ -557,7 +557,7 @@ rt_results* rt_session::run_batch(const uint8_t* const* rgb, const int* hs, cons
       int l1 = l0; long long px = 0;
       while (l1 < NL) { long long add = (long long)rh * line_W[l1]; if (l1 > l0 && px + add > REC_GROUP_PX) break; px += add; l1++; }
       int ln = l1 - l0;
-      scratch.reset();
+      scratch.rewind();
       std::vector<std::pair<int, int>> hw;
       pp::LineDesc* hl = pinned.alloc<pp::LineDesc>(ln);
       long long off = 0;

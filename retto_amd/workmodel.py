@@ -1,0 +1,95 @@
+"""Algorithmic work (bytes moved, FLOPs) of each kernel family, derived from the layer
+tables: for every launch, input activations read
+once + output activations written once (fp32, real channel counts) + weights once.
+This is the `B_layer` accounting of BASELINE.md, split per kernel family so that the
+roofline line in bench.py can price the dominant kernel.  Pure arithmetic; no GPU.
+"""
+from __future__ import annotations
+
+from collections import defaultdict
+from typing import Dict, Iterable, Tuple
+
+from . import synth
+
+F = 4  # bytes per fp32
+
+
+def _down(v: int, s: int) -> int:
+    return (v - 1) // s + 1
+
+
+def det_work(pages: Iterable[Tuple[int, int]]) -> Dict[str, Dict[str, float]]:
+    """pages: det-input (H, W) per page.  Returns family -> {bytes, flops}."""
+    w = defaultdict(lambda: {"bytes": 0.0, "flops": 0.0})
+
+    def add(fam, b, f=0.0):
+        w[fam]["bytes"] += b; w[fam]["flops"] += f
+
+    for (H, W) in pages:
+        add("det_normalize", H * W * 3 + H * W * 4 * F)
+        h, ww = _down(H, 2), _down(W, 2)
+        add("stem", H * W * 3 * F + h * ww * 16 * F, 2 * h * ww * 27 * 16)
+        taps = {}
+        for name, k, cin, cout, sh, sw, se in synth.DET_BLOCKS:
+            ho, wo = _down(h, sh), _down(ww, sw)
+            add("dwconv%d" % k, (h * ww + ho * wo) * cin * F + k * k * cin * F, 2 * ho * wo * cin * k * k)
+            if se:
+                add("se_pool_fc", ho * wo * cin * F)
+                add("scale_channels", 2 * ho * wo * cin * F)
+            add("gemm_pw", ho * wo * (cin + cout) * F + cin * cout * F, 2 * ho * wo * cin * cout)
+            h, ww = ho, wo
+            for j, (tn, tc, oc) in enumerate(synth.DET_TAPS):
+                if tn == name:
+                    add("gemm_misc", h * ww * (tc + oc) * F + tc * oc * F, 2 * h * ww * tc * oc)
+                    taps[j] = (h, ww, oc)
+        for j in range(4):
+            h, ww, oc = taps[j]
+            add("gemm_misc", h * ww * (oc + 96) * F + oc * 96 * F, 2 * h * ww * oc * 96)
+            add("se_pool_fc", h * ww * 96 * F); add("scale_channels", 2 * h * ww * 96 * F)
+            if j < 3:
+                h2, w2, _ = taps[j + 1]
+                add("upsample_add", (2 * h * ww + h2 * w2) * 96 * F)
+            add("conv3x3", h * ww * (96 + 24) * F + 9 * 96 * 24 * F, 2 * h * ww * 9 * 96 * 24)
+            add("se_pool_fc", h * ww * 24 * F); add("scale_channels", 2 * h * ww * 24 * F)
+        h4, w4, _ = taps[0]
+        add("fpn_concat", sum(taps[j][0] * taps[j][1] for j in range(4)) * 24 * F + h4 * w4 * 96 * F)
+        add("conv3x3", h4 * w4 * (96 + 24) * F + 9 * 96 * 24 * F, 2 * h4 * w4 * 9 * 96 * 24)
+        add("db_head_tail", h4 * w4 * 24 * F + H * W * F, 2 * h4 * w4 * 4 * (24 * 24 + 4 * 24))
+    return dict(w)
+
+
+def rec_work(widths: Iterable[int], classes: int = synth.REC_CLASSES) -> Dict[str, Dict[str, float]]:
+    """widths: padded width W of every 48-high line tensor."""
+    w = defaultdict(lambda: {"bytes": 0.0, "flops": 0.0})
+
+    def add(fam, b, f=0.0):
+        w[fam]["bytes"] += b; w[fam]["flops"] += f
+
+    for W in widths:
+        H = 48
+        h, ww = _down(H, 2), _down(W, 2)
+        add("stem", H * W * 3 * F + h * ww * 16 * F, 2 * h * ww * 27 * 16)
+        for name, k, cin, cout, sh, sw, se in synth.REC_BLOCKS:
+            ho, wo = _down(h, sh), _down(ww, sw)
+            add("dwconv%d" % k, (h * ww + ho * wo) * cin * F + k * k * cin * F, 2 * ho * wo * cin * k * k)
+            if se:
+                add("se_pool_fc", ho * wo * cin * F); add("scale_channels", 2 * ho * wo * cin * F)
+            add("gemm_pw", ho * wo * (cin + cout) * F + cin * cout * F, 2 * ho * wo * cin * cout)
+            h, ww = ho, wo
+        T = (ww - 2) // 2 + 1
+        add("avgpool", (h * ww + T) * 480 * F)
+        add("conv1x3", T * (480 + 60) * F + 3 * 480 * 60 * F, 2 * T * 3 * 480 * 60)
+        add("conv1x3", T * (960 + 60) * F + 3 * 960 * 60 * F, 2 * T * 3 * 960 * 60)
+        for cin, cout, cnt in ((60, 120, 2), (120, 360, 2), (120, 120, 2), (120, 240, 2), (240, 120, 2), (120, 480, 1)):
+            add("gemm_neck", cnt * (T * (cin + cout) * F + cin * cout * F), cnt * 2 * T * cin * cout)
+        add("attention", 2 * T * (360 + 120) * F, 2 * 2 * 2 * T * T * 120)
+        add("layernorm", 5 * 3 * T * 120 * F)
+        add("gemm_ctc_fc", T * (120 + classes) * F + 120 * classes * F, 2 * T * 120 * classes)
+        add("ctc_argmax", T * classes * F)
+    return dict(w)
+
+
+def page_flops(det_hw: Tuple[int, int], widths: Iterable[int]) -> float:
+    d = sum(v["flops"] for v in det_work([det_hw]).values())
+    r = sum(v["flops"] for v in rec_work(widths).values())
+    return d + r
