@@ -70,16 +70,8 @@ def main():
     else:
         blobs = [None] * 4
     if dist_on:
-        sizes = torch.tensor([len(b) for b in blobs] if rank == 0 else [0] * 4, dtype=torch.int64, device="cuda")
-        dist.broadcast(sizes, 0)
-        out = []
-        for i, n in enumerate(sizes.tolist()):
-            t = torch.empty(n, dtype=torch.uint8, device="cuda")
-            if rank == 0:
-                t.copy_(torch.frombuffer(bytearray(blobs[i]), dtype=torch.uint8))
-            dist.broadcast(t, 0)
-            out.append(t.cpu().numpy().tobytes())
-        blobs = out
+        from retto_amd.dist import broadcast_blobs
+        blobs = broadcast_blobs(blobs, 4, rank, device="cuda")  # RCCL over xGMI, once
     det_b, cls_b, rec_b, dict_b = blobs
     cfg = retto_amd.RettoSessionConfig()
     cfg.worker_config = retto_amd.RettoHipWorkerConfig(device=device, models=retto_amd.RettoWorkerModelProvider(

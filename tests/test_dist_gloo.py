@@ -1,0 +1,53 @@
+"""world_size-2 gloo test of the multi-GPU plumbing: weight broadcast and page
+sharding.  The data path has no collective, so this is all the distributed logic there is."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from retto_amd import dist as rdist
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    blobs = [bytes([i]) * (1000 + 37 * i) for i in range(4)] if rank == 0 else None
+    got = rdist.broadcast_blobs(blobs, 4, rank, device="cpu")
+    sizes = [(960, 960)] * 5 + [(2000, 1400), (640, 640), (1088, 1920)]
+    mine = rdist.shard_pages(sizes, world, rank)
+    t = torch.tensor([len(mine)], dtype=torch.int64)
+    dist.all_reduce(t)
+    q.put((rank, rdist.digest(got), mine, int(t.item())))
+    dist.destroy_process_group()
+
+
+def test_broadcast_and_sharding_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    [p.start() for p in ps]
+    res = sorted(q.get(timeout=120) for _ in range(2))
+    [p.join(30) for p in ps]
+    assert all(p.exitcode == 0 for p in ps)
+    assert res[0][1] == res[1][1] == rdist.digest([bytes([i]) * (1000 + 37 * i) for i in range(4)])
+    a, b = res[0][2], res[1][2]
+    assert sorted(a + b) == list(range(8)) and not set(a) & set(b)
+    assert res[0][3] == 8
+    cost = lambda idx: sum([(960 * 960)] * 5 + [2000 * 1400, 640 * 640, 1088 * 1920][i - 5:i - 4] or [960 * 960] for i in idx)  # noqa
+    sizes = [(960, 960)] * 5 + [(2000, 1400), (640, 640), (1088, 1920)]
+    la = sum(sizes[i][0] * sizes[i][1] for i in a); lb = sum(sizes[i][0] * sizes[i][1] for i in b)
+    assert abs(la - lb) / max(la, lb) < 0.25          # LPT keeps the two shards balanced
+
+
+def test_sharding_uniform_is_even():
+    for world in (1, 2, 4, 8):
+        shards = [rdist.shard_pages([(960, 960)] * 32, world, r) for r in range(world)]
+        assert sorted(sum(shards, [])) == list(range(32))
+        assert all(len(s) == 32 // world for s in shards)

@@ -1,0 +1,102 @@
+"""GPU tests against the committed golden fixtures (tests/golden, produced by the CPU oracle)
+and of the error behaviour of the boundary."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def test_golden_preprocess(hip_session):
+    import retto_amd
+    d = np.load(os.path.join(G, "preprocess.npz"))
+    cfg = retto_amd.synthetic_session_config(0)
+    cfg.det_processor_config.limit_side_len = 64
+    s = retto_amd.RettoSession(cfg)
+    try:
+        assert np.array_equal(s.det_preprocess(d["img"]).view(np.uint32), d["det_input"].view(np.uint32))
+    finally:
+        s.close()
+
+
+def test_golden_dbpost(hip_session):
+    d = np.load(os.path.join(G, "dbpost.npz"))
+    for k in ("rot", "nested"):
+        m = d["map_" + k]
+        b, s = hip_session.det_postprocess(m, *m.shape)
+        assert np.array_equal(b, d["boxes_" + k])
+        assert np.array_equal(s.view(np.uint32), d["scores_" + k].view(np.uint32))
+
+
+def test_golden_crops(hip_session):
+    c = np.load(os.path.join(G, "crops.npz"))
+    crops = hip_session.crop_images(c["page"], c["boxes"])
+    for i, crop in enumerate(crops):
+        assert np.array_equal(crop, c["crop%d" % i])
+        a = hip_session.resize_norm_image(crop, crop.shape[0], crop.shape[1], 48, 192, 0.0)
+        b = hip_session.resize_norm_image(crop, crop.shape[0], crop.shape[1], 48, 320, 9.5)
+        assert np.array_equal(a.view(np.uint32), c["cls%d" % i].view(np.uint32))
+        assert np.array_equal(b.view(np.uint32), c["rec%d" % i].view(np.uint32))
+
+
+def test_golden_ctc(hip_session):
+    d = np.load(os.path.join(G, "ctc.npz"))
+    ids, top = d["ids"], d["top"]
+    n, t = ids.shape
+    probs = np.full((n, t, 6625), 1e-5, np.float32)
+    for i in range(n):
+        for k in range(t):
+            probs[i, k, ids[i, k]] = top[i, k]
+    i_, k_, a_, b_ = d["tie"]
+    probs[i_, k_, a_] = probs[i_, k_, b_]
+    idx, pr, toks, sc = hip_session.ctc_decode(probs)
+    assert np.array_equal(idx, d["idx"]) and np.array_equal(pr.view(np.uint32), d["prob"].view(np.uint32))
+    for i in range(3):
+        assert np.array_equal(toks[i], d["tok%d" % i])
+    assert np.array_equal(sc.view(np.uint32), d["score"].view(np.uint32))
+
+
+def test_errors_mirror_reference(models):
+    """worker.rs:33-47: missing path / empty blob -> ModelNotFoundError; shape errors are ShapeError."""
+    import retto_amd
+    cfg = retto_amd.synthetic_session_config(0)
+    cfg.worker_config.models.det = retto_amd.RettoWorkerModelSource.Path("/nonexistent/ch_PP-OCRv4_det_infer.rtwb")
+    with pytest.raises(retto_amd.ModelNotFoundError):
+        retto_amd.RettoSession(cfg)
+    cfg = retto_amd.synthetic_session_config(0)
+    cfg.worker_config.models.rec = retto_amd.RettoWorkerModelSource.Blob(b"")
+    with pytest.raises(retto_amd.ModelNotFoundError):
+        retto_amd.RettoSession(cfg)
+    cfg = retto_amd.synthetic_session_config(0)
+    cfg.rec_processor_config.character_source = retto_amd.RettoWorkerModelSource.Blob(b"\xff\xfe\n")
+    with pytest.raises(retto_amd.Utf8Error):
+        retto_amd.RettoSession(cfg)
+    s = retto_amd.RettoSession(retto_amd.synthetic_session_config(0))
+    try:
+        with pytest.raises(retto_amd.ShapeError):
+            s.worker.det(np.zeros((1, 3, 100, 100), np.float32))      # not a multiple of 32
+        with pytest.raises(retto_amd.ShapeError):
+            s.worker.cls(np.zeros((1, 3, 48, 100), np.float32))
+        assert s.run_batch([]) == []
+        r = s.run(np.zeros((64, 64, 3), np.uint8))                     # nothing detected -> empty results
+        assert isinstance(r.det_result, list)
+    finally:
+        s.close()
+
+
+def test_stage_json_shape(hip_session):
+    import json
+    from retto_amd import workload
+    from oracle import ref_lib as R
+    page, rects = workload.planted_page(160, 320, 2, seed=1)
+    js = hip_session.stage_json(page)
+    det, cls, rec = (json.loads(j) for j in js)
+    assert isinstance(det, list) and isinstance(cls, list) and isinstance(rec, list)
+    for d in det:
+        assert set(d) == {"boxes", "score"} and len(d["boxes"]["inner"]) == 4 and set(d["boxes"]["inner"][0]) == {"x", "y"}
+    for c in cls:
+        assert set(c) == {"label"} and set(c["label"]) == {"label", "score"}
+    for r in rec:
+        assert set(r) == {"text", "score"}

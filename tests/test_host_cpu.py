@@ -1,0 +1,118 @@
+"""CPU tests of the host-side pieces: the C-ABI library loads and exports every symbol of
+include/retto_hip.h, the pure host entry points agree with the oracle, the model-blob
+format round-trips, and the product path fails loudly without a GPU (no fallback)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import retto_amd
+from oracle import ref_lib as R
+from retto_amd import _lib, synth, workmodel
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = _lib.load()
+    hdr = open(os.path.join(ROOT, "include", "retto_hip.h")).read()
+    declared = sorted(set(re.findall(r"RT_API\s+[\w\s\*]+?\b(rt_\w+)\s*\(", hdr)))
+    assert len(declared) >= 35
+    assert sorted(_lib.EXPORTS) == declared, "retto_amd/_lib.py EXPORTS is out of sync with the header"
+    for name in declared:
+        assert hasattr(lib, name), name
+
+
+def test_config_defaults_match_reference():
+    # session.rs:28-39, det_processor.rs:75-93, cls_processor.rs:27-36, rec_processor.rs:130-134
+    c = _lib.Config()
+    _lib.load().rt_config_default(C.byref(c))
+    assert (c.max_side_len, c.min_side_len) == (2000, 30)
+    assert (c.det_limit_side_len, c.det_limit_type, c.det_min_mini_box_size, c.det_dilation) == (736, 0, 3, 1)
+    assert list(c.det_mean) == [0.5] * 3 and list(c.det_std) == [0.5] * 3
+    assert np.float32(c.det_scale) == np.float32(1.0) / np.float32(255.0)
+    assert np.float32(c.det_thresh) == np.float32(0.3) and np.float32(c.det_box_thresh) == np.float32(0.5)
+    assert np.float32(c.det_unclip_ratio) == np.float32(1.6)
+    assert list(c.cls_image_shape) == [3, 48, 192] and c.cls_batch_num == 6 and np.float32(c.cls_thresh) == np.float32(0.9)
+    assert list(c.rec_image_shape) == [3, 48, 320] and c.rec_batch_num == 6
+
+
+def test_no_cpu_fallback():
+    """Without a gfx950 device rt_create must fail with a backend error; with one it works."""
+    try:
+        s = retto_amd.RettoSession(retto_amd.synthetic_session_config(0))
+    except retto_amd.BackendError as e:
+        assert "no CPU fallback" in str(e) or "gfx950" in str(e)
+    else:
+        s.close()
+
+
+def test_create_rejects_bad_arguments():
+    lib = _lib.load()
+    h = C.c_void_p()
+    assert lib.rt_create(None, C.byref(h)) == 8
+    c = _lib.Config(); lib.rt_config_default(C.byref(c)); c.max_boxes_per_page = 100000
+    assert lib.rt_create(C.byref(c), C.byref(h)) == 8
+    assert b"max_boxes_per_page" in lib.rt_last_error(None)
+
+
+def test_host_geometry_matches_oracle():
+    lib = _lib.load()
+    rng = np.random.default_rng(0)
+    for _ in range(200):
+        c = rng.uniform(20, 400, 2); L = rng.uniform(4, 150); T = rng.uniform(2, 40); a = rng.uniform(-np.pi, np.pi)
+        u = np.array([np.cos(a), np.sin(a)]); v = np.array([-u[1], u[0]])
+        box = np.round(np.stack([c - L * u - T * v, c + L * u - T * v, c + L * u + T * v, c - L * u + T * v])).astype(np.float32)
+        ws, hs = np.zeros(1, np.int32), np.zeros(1, np.int32)
+        assert lib.rt_crop_dims(box.ctypes.data, 1, ws.ctypes.data, hs.ctypes.data) == 0
+        ow, oh, _ = R.crop_dims(box)
+        assert (int(ws[0]), int(hs[0])) == (ow, oh)
+        b2 = box.reshape(8).copy()
+        lib.rt_scale_and_clip(b2.ctypes.data, 1, 736.0, 736.0, 640.0, 640.0)
+        assert np.array_equal(b2.reshape(4, 2), R.scale_and_clip(box, 736, 736, 640, 640))
+    for ratio in (0.0, 320 / 48, 7.3, 19.99):
+        assert lib.rt_resize_norm_width(48, 320, ratio) == R.lib().orc_resize_norm_width(48, 320, C.c_float(ratio))
+
+
+def test_blob_roundtrip_and_shapes():
+    t = synth.det_tensors(1)
+    back = synth.unpack_blob(synth.pack_blob(t))
+    assert set(back) == set(t)
+    assert all(np.array_equal(back[k], t[k]) for k in t)
+    n = lambda d: sum(v.size for v in d.values())
+    # parameter counts reproduce the published model sizes (det ~4.7 MB, rec ~10.7 MB fp32)
+    assert abs(n(t) * 4 / 1e6 - 4.7) < 0.1
+    assert abs(n(synth.rec_tensors(2)) * 4 / 1e6 - 10.7) < 0.2
+    d = synth.synth_dict().decode().splitlines()
+    assert len(d) == synth.REC_CLASSES - 2 and len(set(d)) == len(d)
+
+
+def test_work_model_matches_survey():
+    det = workmodel.det_work([(960, 960)])
+    assert abs(sum(v["flops"] for v in det.values()) / 1e9 - 10.36) < 0.02      # 10.36 GFLOP
+    rec = workmodel.rec_work([320])
+    assert abs(sum(v["flops"] for v in rec.values()) / 1e9 - 1.405) < 0.005     # 1.405 GFLOP per 320-wide line
+    assert abs(sum(v["flops"] for v in workmodel.det_work([(736, 736)]).values()) / 1e9 - 6.09) < 0.02
+
+
+def test_python_mirror_validates_config():
+    cfg = retto_amd.synthetic_session_config(0)
+    cfg.det_processor_config.dilation_kernel = np.ones((3, 3))
+    with pytest.raises(retto_amd.InvalidArgument):
+        retto_amd.RettoSession(cfg)
+    cfg = retto_amd.RettoSessionConfig()
+    with pytest.raises(retto_amd.ModelNotFoundError):
+        retto_amd.RettoSession(cfg)
+
+
+def test_decode_image_png():
+    from PIL import Image
+    import io
+    rng = np.random.default_rng(1)
+    a = rng.integers(0, 256, (9, 13, 3), dtype=np.uint8)
+    buf = io.BytesIO(); Image.fromarray(a).save(buf, format="PNG")
+    assert np.array_equal(retto_amd.decode_image(buf.getvalue()), a)
+    with pytest.raises(retto_amd.ImageError):
+        retto_amd.decode_image(b"not an image")
