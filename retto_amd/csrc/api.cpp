@@ -1,4 +1,5 @@
 // extern "C" surface of libretto_hip.so (include/retto_hip.h).
+#include <cmath>
 #include <cstring>
 #include <new>
 
@@ -209,6 +210,47 @@ int rt_profile_get(rt_session* s, const char* const** names, const float** ms, c
   RT_REQUIRE(s && names && ms && calls && n, s, "rt_profile_get: null argument");
   *names = s->prof.names.data(); *ms = s->prof.ms.data(); *calls = s->prof.calls.data(); *n = (int)s->prof.names.size();
   return RT_OK;
+}
+
+// Kernel micro-benchmark (not part of the drop-in surface): times nn::gemm on random data.
+RT_API int rt_bench_gemm(rt_session* s, long long M, int K, int N, int variant, int iters, float* ms_out, float* maxdiff_out) {
+  RT_REQUIRE(s && ms_out, s, "rt_bench_gemm: null argument");
+  return guarded(s, [&] {
+    RT_HIP_CHECK(hipSetDevice(s->device));
+    const int Kp = round_up(K, 4), Np = round_up(N, 16), ldc = round_up(N, 4), nkc = (Kp + nn::KC - 1) / nn::KC;
+    std::vector<float> ha((size_t)M * Kp), hw((size_t)nkc * Np * nn::KC, 0.f), hb(Np, 0.1f);
+    uint32_t st = 12345;
+    auto rnd = [&]() { st = st * 1664525u + 1013904223u; return ((st >> 8) & 0xffff) / 32768.0f - 1.0f; };
+    for (auto& v : ha) v = rnd();
+    for (int k = 0; k < K; k++) for (int n = 0; n < N; n++) hw[((size_t)(k / nn::KC) * Np + n) * nn::KC + k % nn::KC] = rnd() * 0.1f;
+    float *dA, *dW, *dB, *dC, *dC0;
+    RT_HIP_CHECK(hipMalloc((void**)&dA, ha.size() * 4)); RT_HIP_CHECK(hipMalloc((void**)&dW, hw.size() * 4));
+    RT_HIP_CHECK(hipMalloc((void**)&dB, hb.size() * 4)); RT_HIP_CHECK(hipMalloc((void**)&dC, (size_t)M * ldc * 4));
+    RT_HIP_CHECK(hipMalloc((void**)&dC0, (size_t)M * ldc * 4));
+    RT_HIP_CHECK(hipMemcpy(dA, ha.data(), ha.size() * 4, hipMemcpyHostToDevice));
+    RT_HIP_CHECK(hipMemcpy(dW, hw.data(), hw.size() * 4, hipMemcpyHostToDevice));
+    RT_HIP_CHECK(hipMemcpy(dB, hb.data(), hb.size() * 4, hipMemcpyHostToDevice));
+    Epilogue e{dB, ACT_HSWISH, 1, 1.01f, 0.02f, nullptr, 0};
+    nn::g_gemm_variant = 1; nn::gemm(s->st, dA, Kp, M, Kp, dW, N, Np, dC0, ldc, 0, e);
+    nn::g_gemm_variant = variant;
+    nn::gemm(s->st, dA, Kp, M, Kp, dW, N, Np, dC, ldc, 0, e);
+    hipEvent_t a, b; RT_HIP_CHECK(hipEventCreate(&a)); RT_HIP_CHECK(hipEventCreate(&b));
+    RT_HIP_CHECK(hipEventRecord(a, s->st));
+    for (int i = 0; i < iters; i++) nn::gemm(s->st, dA, Kp, M, Kp, dW, N, Np, dC, ldc, 0, e);
+    RT_HIP_CHECK(hipEventRecord(b, s->st));
+    RT_HIP_CHECK(hipStreamSynchronize(s->st));
+    nn::g_gemm_variant = 0;
+    float ms = 0; RT_HIP_CHECK(hipEventElapsedTime(&ms, a, b)); *ms_out = ms / iters;
+    if (maxdiff_out) {
+      size_t cnt = std::min<size_t>((size_t)M * ldc, (size_t)1 << 22);
+      std::vector<float> c0(cnt), c1(cnt);
+      RT_HIP_CHECK(hipMemcpy(c0.data(), dC0, cnt * 4, hipMemcpyDeviceToHost)); RT_HIP_CHECK(hipMemcpy(c1.data(), dC, cnt * 4, hipMemcpyDeviceToHost));
+      float md = 0; for (size_t i = 0; i < cnt; i++) md = std::max(md, std::fabs(c0[i] - c1[i]));
+      *maxdiff_out = md;
+    }
+    (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+    (void)hipFree(dA); (void)hipFree(dW); (void)hipFree(dB); (void)hipFree(dC); (void)hipFree(dC0);
+  });
 }
 
 }  // extern "C"

@@ -138,9 +138,288 @@ __global__ __launch_bounds__(256) void k_gemm(const float* __restrict__ A, int l
                      epi.residual ? epi.residual + mb * epi.ld_res : nullptr, q);
 }
 
+// ---------------------------------------------------------------------------
+// Wide GEMM for N > 128: block tile (16*MT*WM) rows x (16*NT*WN) cols so that a pass reads
+// each activation row once (the narrow kernel re-reads A once per 128 columns), WM x WN waves,
+// and the next K-slab is prefetched into registers while the MFMAs of the current one run.
+// ---------------------------------------------------------------------------
+template <int MT, int NT, int WM, int WN, int RASTER = 0, int DBG = 0>
+__global__ __launch_bounds__(64 * WM * WN) void k_gemm_wide(const float* __restrict__ A, int lda, long long M, int K,
+                                                             const float* __restrict__ Wp, int N, int Npad,
+                                                             float* __restrict__ C, int ldc, int coff, Epilogue epi) {
+  constexpr int NTHR = 64 * WM * WN, BM = 16 * MT * WM, BN = 16 * NT * WN;
+  constexpr int A_LD = (BM * 8 + NTHR - 1) / NTHR, W_LD = (BN * 8 + NTHR - 1) / NTHR;
+  __shared__ __attribute__((aligned(16))) float lds[(BM + BN) * LROW];
+  float* xs = lds;
+  float* ws = lds + BM * LROW;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, q = lane >> 4;
+  const int wm = wave / WN, wn = wave % WN;
+  long long mb = blockIdx.x;
+  int nb = blockIdx.y;
+  if (RASTER) {
+    // XCD-aware order: block ids are dealt round-robin to the 8 XCDs, so the column blocks of
+    // one row block are given consecutive slots on the SAME XCD and share its L2 for the A rows.
+    const int ncol = (Npad + BN - 1) / BN;
+    const long long id = blockIdx.x, slot = id >> 3;
+    mb = (slot / ncol) * 8 + (id & 7);
+    nb = (int)(slot % ncol);
+    if (mb * BM >= M) return;
+  }
+  const long long m0 = mb * BM;
+  const int n0 = nb * BN;
+  const int nt_valid = max(0, min(NT, (Npad - n0) / 16 - wn * NT));
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; i++)
+#pragma unroll
+    for (int j = 0; j < NT; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x4 pa[A_LD], pw[W_LD];
+  const int nkc = (K + KC - 1) / KC;
+  auto fetch = [&](int kc) {
+    const int k0 = kc * KC;
+#pragma unroll
+    for (int i = 0; i < A_LD; i++) {
+      int idx = tid + NTHR * i, row = idx >> 3, c4 = idx & 7;
+      long long m = m0 + row;
+      pa[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (row < BM && m < M && k0 + c4 * 4 < K) pa[i] = *reinterpret_cast<const f32x4*>(A + m * lda + k0 + c4 * 4);
+    }
+#pragma unroll
+    for (int i = 0; i < W_LD; i++) {
+      int idx = tid + NTHR * i, row = idx >> 3, c4 = idx & 7;
+      pw[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (row < BN && n0 + row < Npad)
+        pw[i] = *reinterpret_cast<const f32x4*>(Wp + ((long long)kc * Npad + n0 + row) * KC + c4 * 4);
+    }
+  };
+  auto stash = [&]() {
+#pragma unroll
+    for (int i = 0; i < A_LD; i++) {
+      int idx = tid + NTHR * i, row = idx >> 3, c4 = idx & 7;
+      if (row < BM) *reinterpret_cast<f32x4*>(xs + row * LROW + c4 * 4) = pa[i];
+    }
+#pragma unroll
+    for (int i = 0; i < W_LD; i++) {
+      int idx = tid + NTHR * i, row = idx >> 3, c4 = idx & 7;
+      if (row < BN) *reinterpret_cast<f32x4*>(ws + row * LROW + c4 * 4) = pw[i];
+    }
+  };
+  fetch(0);
+  stash();
+  __syncthreads();
+  for (int kc = 0; kc < nkc; kc++) {
+    if (DBG == 0 && kc + 1 < nkc) fetch(kc + 1);
+    const float* xr = xs + (wm * MT * 16 + r) * LROW;
+    const float* wr = ws + (wn * NT * 16 + r) * LROW;
+    // Fragments of both 16-deep groups are requested up front; the MFMA block of group 0 only
+    // waits for its own reads (in-order LDS returns), hiding group 1's latency.  Branch-free:
+    // padding tiles multiply zero weights (W rows past Npad are zero in LDS) and are dropped at
+    // the store.
+    f32x4 a[KC / 16][MT], b[KC / 16][NT];
+#pragma unroll
+    for (int g = 0; g < KC / 16; g++) {
+#pragma unroll
+      for (int mt = 0; mt < MT; mt++) a[g][mt] = *reinterpret_cast<const f32x4*>(xr + mt * 16 * LROW + g * 16 + 4 * q);
+#pragma unroll
+      for (int nt = 0; nt < NT; nt++) b[g][nt] = *reinterpret_cast<const f32x4*>(wr + nt * 16 * LROW + g * 16 + 4 * q);
+    }
+#pragma unroll
+    for (int g = 0; g < KC / 16; g++)
+#pragma unroll
+      for (int s = 0; s < 4; s++)
+#pragma unroll
+        for (int nt = 0; nt < NT; nt++)
+#pragma unroll
+          for (int mt = 0; mt < MT; mt++)
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[g][nt][s], a[g][mt][s], acc[mt][nt], 0, 0, 0);
+    if (DBG != 2) __syncthreads();
+    if (DBG == 0 && kc + 1 < nkc) { stash(); __syncthreads(); }
+    if (DBG == 1) __syncthreads();
+  }
+  const int nstore = (N + 3) & ~3;
+#pragma unroll
+  for (int nt = 0; nt < NT; nt++) {
+    if (nt >= nt_valid) continue;
+    int col = n0 + (wn * NT + nt) * 16 + q * 4;
+    if (col >= nstore) continue;
+    f32x4 bias = {0.f, 0.f, 0.f, 0.f};
+    if (epi.bias) bias = *reinterpret_cast<const f32x4*>(epi.bias + col);
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++) {
+      long long m = m0 + (wm * MT + mt) * 16 + r;
+      if (m >= M) continue;
+      f32x4 o;
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        float t = act_apply(acc[mt][nt][j] + bias[j], epi.act);
+        if (epi.has_lab) t = fmaf(t, epi.lab_a, epi.lab_c);
+        if (epi.residual) t += epi.residual[m * epi.ld_res + col + j];
+        o[j] = (col + j < N) ? t : 0.0f;
+      }
+      *reinterpret_cast<f32x4*>(C + m * ldc + coff + col) = o;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// 32x32x2 variant: block 128 rows x 128 cols, 4 waves as 2x2, each wave 64x64 = 2x2 tiles of
+// v_mfma_f32_32x32x2_f32 (half the operand reads per FLOP of the 16x16x4 form).
+// Lane l: c = l & 31, h = l >> 5; in a 32-deep K slab half h reads k = 16h..16h+15 and feeds
+// element s to step s (same map for both operands).
+// ---------------------------------------------------------------------------
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+__global__ __launch_bounds__(256) void k_gemm_32(const float* __restrict__ A, int lda, long long M, int K,
+                                                 const float* __restrict__ Wp, int N, int Npad, float* __restrict__ C,
+                                                 int ldc, int coff, Epilogue epi) {
+  constexpr int BM = 128, BN = 128, NTHR = 256;
+  __shared__ __attribute__((aligned(16))) float lds[(BM + BN) * LROW];
+  float* xs = lds;
+  float* ws = lds + BM * LROW;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = lane & 31, h = lane >> 5;
+  const int wm = wave >> 1, wn = wave & 1;
+  const long long m0 = (long long)blockIdx.x * BM;
+  const int n0 = blockIdx.y * BN;
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+      for (int e = 0; e < 16; e++) acc[i][j][e] = 0.f;
+  f32x4 pa[4], pw[4];
+  const int nkc = (K + KC - 1) / KC;
+  auto fetch = [&](int kc) {
+    const int k0 = kc * KC;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      int idx = tid + NTHR * i, row = idx >> 3, c4 = idx & 7;
+      long long m = m0 + row;
+      pa[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (m < M && k0 + c4 * 4 < K) pa[i] = *reinterpret_cast<const f32x4*>(A + m * lda + k0 + c4 * 4);
+      pw[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (n0 + row < Npad) pw[i] = *reinterpret_cast<const f32x4*>(Wp + ((long long)kc * Npad + n0 + row) * KC + c4 * 4);
+    }
+  };
+  auto stash = [&]() {
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      int idx = tid + NTHR * i, row = idx >> 3, c4 = idx & 7;
+      *reinterpret_cast<f32x4*>(xs + row * LROW + c4 * 4) = pa[i];
+      *reinterpret_cast<f32x4*>(ws + row * LROW + c4 * 4) = pw[i];
+    }
+  };
+  fetch(0); stash(); __syncthreads();
+  for (int kc = 0; kc < nkc; kc++) {
+    if (kc + 1 < nkc) fetch(kc + 1);
+    const float* xr = xs + (wm * 64 + c) * LROW + 16 * h;
+    const float* wr = ws + (wn * 64 + c) * LROW + 16 * h;
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+      f32x4 a0 = *reinterpret_cast<const f32x4*>(xr + g * 4);
+      f32x4 a1 = *reinterpret_cast<const f32x4*>(xr + 32 * LROW + g * 4);
+      f32x4 b0 = *reinterpret_cast<const f32x4*>(wr + g * 4);
+      f32x4 b1 = *reinterpret_cast<const f32x4*>(wr + 32 * LROW + g * 4);
+#pragma unroll
+      for (int s = 0; s < 4; s++) {
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(b0[s], a0[s], acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(b1[s], a0[s], acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(b0[s], a1[s], acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(b1[s], a1[s], acc[1][1], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+    if (kc + 1 < nkc) { stash(); __syncthreads(); }
+  }
+  // D: col (pixel) = lane & 31, row (cout) = 8*(reg>>2) + 4*h + (reg&3)
+  const int nstore = (N + 3) & ~3;
+#pragma unroll
+  for (int mt = 0; mt < 2; mt++) {
+    long long m = m0 + wm * 64 + mt * 32 + c;
+    if (m >= M) continue;
+#pragma unroll
+    for (int nt = 0; nt < 2; nt++)
+#pragma unroll
+      for (int gq = 0; gq < 4; gq++) {
+        int col = n0 + wn * 64 + nt * 32 + 8 * gq + 4 * h;
+        if (col >= nstore) continue;
+        f32x4 bias = {0.f, 0.f, 0.f, 0.f};
+        if (epi.bias) bias = *reinterpret_cast<const f32x4*>(epi.bias + col);
+        f32x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          float t = act_apply(acc[mt][nt][gq * 4 + j] + bias[j], epi.act);
+          if (epi.has_lab) t = fmaf(t, epi.lab_a, epi.lab_c);
+          if (epi.residual) t += epi.residual[m * epi.ld_res + col + j];
+          o[j] = (col + j < N) ? t : 0.0f;
+        }
+        *reinterpret_cast<f32x4*>(C + m * ldc + coff + col) = o;
+      }
+  }
+}
+
+int g_gemm_variant = 0;  // 0 = production choice; others are forced by the kernel micro-benchmark
+
 void gemm(hipStream_t st, const float* A, int lda, long long M, int K, const float* Wp, int N, int Npad16, float* C,
           int ldc, int coff, const Epilogue& epi) {
   if (M <= 0) return;
+  int v = g_gemm_variant;
+  if (v == 0) {  // production dispatch (tools/bench_gemm.py): wide tiles once N and M are large
+    if (Npad16 % 240 == 0 && M >= 16384) v = 10;
+    else if (Npad16 >= 192 && M >= 8192) v = 8;
+  }
+  if (v == 4) {
+    dim3 grid((unsigned)((M + 127) / 128), (unsigned)((Npad16 + 127) / 128));
+    hipLaunchKernelGGL(k_gemm_32, grid, dim3(256), 0, st, A, lda, M, K, Wp, N, Npad16, C, ldc, coff, epi);
+    return;
+  }
+  if (v == 3) {
+    dim3 grid((unsigned)((M + 127) / 128), (unsigned)((Npad16 + 127) / 128));
+    hipLaunchKernelGGL((k_gemm_wide<4, 4, 2, 2>), grid, dim3(256), 0, st, A, lda, M, K, Wp, N, Npad16, C, ldc, coff, epi);
+    return;
+  }
+  if (v == 6 || v == 7) {
+    dim3 grid((unsigned)((M + 127) / 128), (unsigned)((Npad16 + 127) / 128));
+    if (v == 6) hipLaunchKernelGGL((k_gemm_wide<4, 4, 2, 2, 0, 1>), grid, dim3(256), 0, st, A, lda, M, K, Wp, N, Npad16, C, ldc, coff, epi);
+    else hipLaunchKernelGGL((k_gemm_wide<4, 4, 2, 2, 0, 2>), grid, dim3(256), 0, st, A, lda, M, K, Wp, N, Npad16, C, ldc, coff, epi);
+    return;
+  }
+  if (v == 8) {
+    dim3 grid((unsigned)((M + 127) / 128), (unsigned)((Npad16 + 127) / 128));
+    hipLaunchKernelGGL((k_gemm_wide<2, 4, 4, 2>), grid, dim3(512), 0, st, A, lda, M, K, Wp, N, Npad16, C, ldc, coff, epi);
+    return;
+  }
+  if (v == 10) {
+    dim3 grid((unsigned)((M + 127) / 128), (unsigned)((Npad16 + 239) / 240));
+    hipLaunchKernelGGL((k_gemm_wide<2, 5, 4, 3>), grid, dim3(768), 0, st, A, lda, M, K, Wp, N, Npad16, C, ldc, coff, epi);
+    return;
+  }
+  if (v == 11) {
+    dim3 grid((unsigned)((M + 63) / 64), (unsigned)((Npad16 + 239) / 240));
+    hipLaunchKernelGGL((k_gemm_wide<2, 5, 2, 3>), grid, dim3(384), 0, st, A, lda, M, K, Wp, N, Npad16, C, ldc, coff, epi);
+    return;
+  }
+  if (v == 9) {
+    dim3 grid((unsigned)((M + 63) / 64), (unsigned)((Npad16 + 127) / 128));
+    hipLaunchKernelGGL((k_gemm_wide<2, 4, 2, 2>), grid, dim3(256), 0, st, A, lda, M, K, Wp, N, Npad16, C, ldc, coff, epi);
+    return;
+  }
+  if (v == 5) {
+    long long mblocks = (M + 127) / 128; int ncol = (Npad16 + 127) / 128;
+    dim3 grid((unsigned)(((mblocks + 7) / 8) * 8 * ncol));
+    hipLaunchKernelGGL((k_gemm_wide<4, 4, 2, 2, 1>), grid, dim3(256), 0, st, A, lda, M, K, Wp, N, Npad16, C, ldc, coff, epi);
+    return;
+  }
+  if (v == 2) {
+    int waste240 = round_up(Npad16, 240) - Npad16, waste192 = round_up(Npad16, 192) - Npad16;
+    if (waste240 <= waste192) {
+      dim3 grid((unsigned)((M + 127) / 128), (unsigned)((Npad16 + 239) / 240));
+      hipLaunchKernelGGL((k_gemm_wide<4, 5, 2, 3>), grid, dim3(384), 0, st, A, lda, M, K, Wp, N, Npad16, C, ldc, coff, epi);
+    } else {
+      dim3 grid((unsigned)((M + 127) / 128), (unsigned)((Npad16 + 191) / 192));
+      hipLaunchKernelGGL((k_gemm_wide<4, 4, 2, 3>), grid, dim3(384), 0, st, A, lda, M, K, Wp, N, Npad16, C, ldc, coff, epi);
+    }
+    return;
+  }
   int ntiles = Npad16 / 16;
   int NT = ntiles >= 8 ? 8 : ntiles;
   if (ntiles > 8) {  // pick the split with least padding among 8 / 6 / 5
@@ -298,10 +577,69 @@ __global__ __launch_bounds__(256) void k_dwconv(int sh, int sw, const float* __r
   *reinterpret_cast<f32x4*>(y + (go.off + p) * Cp + c4 * 4) = o;
 }
 
+// Stride-1 variant: a thread produces a strip of 4 consecutive output pixels (x 4 channels),
+// sliding the K x (K+3) input window through registers: K*(K+3) 16-byte loads per 4 outputs
+// instead of 4*K*K.
+template <int K>
+__global__ __launch_bounds__(256) void k_dwconv_s1(const float* __restrict__ x, const ImgGeom* __restrict__ geom, int Cp,
+                                                   const float* __restrict__ Wd, const float* __restrict__ bias, int act,
+                                                   int has_lab, float lab_a, float lab_c, float* __restrict__ y) {
+  const ImgGeom g = geom[blockIdx.y];
+  const int C4 = Cp >> 2, strips = (g.W + 3) >> 2;
+  long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (long long)g.H * strips * C4) return;
+  int c4 = (int)(idx % C4);
+  long long s = idx / C4;
+  int oy = (int)(s / strips), ox0 = (int)(s % strips) * 4;
+  const f32x4 b = *reinterpret_cast<const f32x4*>(bias + c4 * 4);
+  f32x4 acc[4] = {b, b, b, b};
+#pragma unroll
+  for (int dy = 0; dy < K; dy++) {
+    int iy = oy + dy - K / 2;
+    if (iy < 0 || iy >= g.H) continue;
+    const float* row = x + (g.off + (long long)iy * g.W) * Cp + c4 * 4;
+    f32x4 v[K + 3];
+#pragma unroll
+    for (int j = 0; j < K + 3; j++) {
+      int ix = ox0 + j - K / 2;
+      v[j] = (ix >= 0 && ix < g.W) ? *reinterpret_cast<const f32x4*>(row + (long long)ix * Cp) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int dx = 0; dx < K; dx++) {
+      f32x4 w = *reinterpret_cast<const f32x4*>(Wd + (dy * K + dx) * Cp + c4 * 4);
+#pragma unroll
+      for (int j = 0; j < 4; j++)
+#pragma unroll
+        for (int e = 0; e < 4; e++) acc[j][e] = fmaf(v[j + dx][e], w[e], acc[j][e]);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    if (ox0 + j >= g.W) break;
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+      float t = act_apply(acc[j][e], act);
+      if (has_lab) t = fmaf(t, lab_a, lab_c);
+      o[e] = t;
+    }
+    *reinterpret_cast<f32x4*>(y + (g.off + (long long)oy * g.W + ox0 + j) * Cp + c4 * 4) = o;
+  }
+}
+
 void dwconv(hipStream_t st, int K, int sh, int sw, const float* x, const ImgGeom* gin, const ImgGeom* gout, int n_img,
             int maxHo, int maxWo, int Cp, const float* Wd, const float* bias, int act, int has_lab, float lab_a,
             float lab_c, float* y) {
   if (n_img <= 0) return;
+  if (sh == 1 && sw == 1 && (K == 3 || K == 5)) {
+    long long total = (long long)maxHo * ((maxWo + 3) / 4) * (Cp / 4);
+    dim3 grid((unsigned)((total + 255) / 256), n_img);
+    if (K == 3)
+      hipLaunchKernelGGL(k_dwconv_s1<3>, grid, dim3(256), 0, st, x, gout, Cp, Wd, bias, act, has_lab, lab_a, lab_c, y);
+    else
+      hipLaunchKernelGGL(k_dwconv_s1<5>, grid, dim3(256), 0, st, x, gout, Cp, Wd, bias, act, has_lab, lab_a, lab_c, y);
+    return;
+  }
   long long total = (long long)maxHo * maxWo * (Cp / 4);
   dim3 grid((unsigned)((total + 255) / 256), n_img);
   if (K == 3)

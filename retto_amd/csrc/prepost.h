@@ -23,11 +23,15 @@ struct DbParams {
 struct DbBox { float pts[8]; float score; int key; };
 // Work buffers for one page of H x W; sized by db_workspace_bytes().
 size_t db_workspace_bytes(int H, int W, int max_boxes);
-// Runs the whole post-process of one page on the stream. boxes_out (device, max_boxes
-// entries) receives the sorted boxes in after_* coordinates, count_out[0] the number,
-// count_out[1] != 0 signals a capacity overflow.
-void db_postprocess(hipStream_t st, const float* pred, int H, int W, int ori_h, int ori_w, const DbParams& p,
-                    void* workspace, int max_boxes, DbBox* boxes_out, int* count_out);
+struct DbPageIn { const float* pred; int H, W, ori_h, ori_w; };
+size_t db_page_desc_bytes();
+// Runs the whole post-process for n pages with shared launches (blockIdx.y = page).
+// workspaces[i]: device buffer of db_workspace_bytes(H_i, W_i, max_boxes); boxes_out[i]
+// (device, max_boxes entries) receives the sorted boxes in after_* coordinates,
+// count_out[i][0] the number, count_out[i][1] != 0 signals a capacity overflow.
+// h_desc (pinned host) / d_desc (device): n * db_page_desc_bytes() scratch for the page table.
+void db_postprocess_batch(hipStream_t st, int n, const DbPageIn* in, const DbParams& p, void* const* workspaces,
+                          int max_boxes, DbBox* const* boxes_out, int* const* count_out, void* h_desc, void* d_desc);
 
 // ---- crops -------------------------------------------------------------------------
 struct CropDesc {

@@ -137,606 +137,6 @@ void det_normalize(hipStream_t st, const uint8_t* rgb, int h, int w, float scale
   hipLaunchKernelGGL(k_det_normalize, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, st, rgb, npix, nm, layout, out);
 }
 
-// ===========================================================================
-// DB post-processing
-// ===========================================================================
-struct Contour { int root, type, ymin, rows, base, hbase; };
-struct DbWs {
-  u8* mask; u8* outside;
-  int *parent, *ymin, *ymax, *cidx;
-  int* counters;  // 0 nContours 1 rowUsed 2 hullUsed 3 nCand 4 overflow
-  Contour* contours; int contour_cap;
-  int *rowmin, *rowmax; int row_cap;
-  int2* hull; int hull_cap;
-  DbBox* cand; int cand_cap;
-};
-
-static inline size_t al256(size_t v) { return (v + 255) & ~(size_t)255; }
-static DbWs carve(void* base, int H, int W, int max_boxes, size_t* total) {
-  size_t N = (size_t)H * W, o = 0;
-  DbWs ws;
-  char* b = (char*)base;
-  auto take = [&](size_t bytes) { char* p = b ? b + o : nullptr; o += al256(bytes); return p; };
-  ws.mask = (u8*)take(N); ws.outside = (u8*)take(N);
-  ws.parent = (int*)take(N * 4); ws.ymin = (int*)take(N * 4); ws.ymax = (int*)take(N * 4); ws.cidx = (int*)take(N * 4);
-  ws.counters = (int*)take(64);
-  ws.contour_cap = (int)(N / 2 + 1024);
-  ws.contours = (Contour*)take((size_t)ws.contour_cap * sizeof(Contour));
-  ws.row_cap = (int)(3 * N + 1024);
-  ws.rowmin = (int*)take((size_t)ws.row_cap * 4); ws.rowmax = (int*)take((size_t)ws.row_cap * 4);
-  ws.hull_cap = (int)(2 * (size_t)ws.row_cap + 4 * (size_t)ws.contour_cap);
-  ws.hull = (int2*)take((size_t)ws.hull_cap * sizeof(int2));
-  ws.cand_cap = max_boxes;
-  ws.cand = (DbBox*)take((size_t)max_boxes * sizeof(DbBox));
-  *total = o;
-  return ws;
-}
-size_t db_workspace_bytes(int H, int W, int max_boxes) { size_t t; carve(nullptr, H, W, max_boxes, &t); return t; }
-
-// det_processor.rs:286-292: mask = pred > thresh; grayscale_dilate with offsets
-// {(-1,-1),(0,-1),(-1,0),(0,0)}
-__global__ __launch_bounds__(256) void k_db_mask(const float* __restrict__ pred, int H, int W, float thresh, int dilate,
-                                                 DbWs ws) {
-  int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= H * W) return;
-  int y = i / W, x = i % W;
-  bool m = pred[i] > thresh;
-  if (dilate) {
-    if (x > 0) m = m || pred[i - 1] > thresh;
-    if (y > 0) m = m || pred[i - W] > thresh;
-    if (x > 0 && y > 0) m = m || pred[i - W - 1] > thresh;
-  }
-  ws.mask[i] = m ? 255 : 0;
-  ws.parent[i] = i; ws.ymin[i] = 0x7fffffff; ws.ymax[i] = -1; ws.cidx[i] = -1; ws.outside[i] = 0;
-  if (i < 8) ws.counters[i] = 0;
-}
-
-__device__ __forceinline__ int uf_find(const int* parent, int x) {
-  int p = parent[x];
-  while (p != x) { x = p; p = parent[x]; }
-  return x;
-}
-__device__ __forceinline__ void uf_union(int* parent, int a, int b) {
-  while (true) {
-    a = uf_find(parent, a); b = uf_find(parent, b);
-    if (a == b) return;
-    if (a > b) { int t = a; a = b; b = t; }
-    int old = atomicMin(&parent[b], a);
-    if (old == b) return;
-    b = old;
-  }
-}
-// foreground: 8-connected, background: 4-connected (Suzuki-Abe border following with
-// 8-connected 1-components, as imageproc::contours::find_contours does)
-__global__ __launch_bounds__(256) void k_ccl_merge(int H, int W, DbWs ws) {
-  int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= H * W) return;
-  int y = i / W, x = i % W;
-  u8 m = ws.mask[i];
-  if (x > 0 && ws.mask[i - 1] == m) uf_union(ws.parent, i, i - 1);
-  if (y > 0 && ws.mask[i - W] == m) uf_union(ws.parent, i, i - W);
-  if (m) {
-    if (y > 0 && x > 0 && ws.mask[i - W - 1]) uf_union(ws.parent, i, i - W - 1);
-    if (y > 0 && x + 1 < W && ws.mask[i - W + 1]) uf_union(ws.parent, i, i - W + 1);
-  }
-}
-__global__ __launch_bounds__(256) void k_ccl_stats(int H, int W, DbWs ws) {
-  int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= H * W) return;
-  int y = i / W, x = i % W;
-  int r = uf_find(ws.parent, i);
-  ws.parent[i] = r;  // flatten (every thread writes only its own slot; readers tolerate either value)
-  if (ws.mask[i]) {
-    if (y == 0 || !ws.mask[i - W]) atomicMin(&ws.ymin[r], y);
-    if (y == H - 1 || !ws.mask[i + W]) atomicMax(&ws.ymax[r], y);
-  } else {
-    if (x == 0 || y == 0 || x == W - 1 || y == H - 1) ws.outside[r] = 1;
-    // border rows of a hole: the fg pixels above its top / below its bottom
-    if (y > 0 && ws.mask[i - W]) atomicMin(&ws.ymin[r], y - 1);
-    if (y < H - 1 && ws.mask[i + W]) atomicMax(&ws.ymax[r], y + 1);
-  }
-}
-// one contour per fg component (outer border) and per hole (bg component not touching
-// the frame); discovery key = raster index of the border-following start pixel
-__global__ __launch_bounds__(256) void k_contour_alloc(int H, int W, DbWs ws) {
-  int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= H * W) return;
-  if (ws.parent[i] != i) return;
-  int type;
-  if (ws.mask[i]) type = 0;
-  else { if (ws.outside[i]) return; type = 1; }
-  int y0 = ws.ymin[i], y1 = ws.ymax[i];
-  if (y1 < y0) return;
-  int rows = y1 - y0 + 1;
-  int idx = atomicAdd(&ws.counters[0], 1);
-  if (idx >= ws.contour_cap) { ws.counters[4] = 1; return; }
-  int base = atomicAdd(&ws.counters[1], rows);
-  int hbase = atomicAdd(&ws.counters[2], 2 * rows + 4);
-  if (base + rows > ws.row_cap || hbase + 2 * rows + 4 > ws.hull_cap) { ws.counters[4] = 1; return; }
-  for (int r = 0; r < rows; r++) { ws.rowmin[base + r] = 0x7fffffff; ws.rowmax[base + r] = -1; }
-  Contour c; c.root = i; c.type = type; c.ymin = y0; c.rows = rows; c.base = base; c.hbase = hbase;
-  ws.contours[idx] = c;
-  ws.cidx[i] = idx;
-}
-__global__ __launch_bounds__(256) void k_row_extents(int H, int W, DbWs ws) {
-  int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= H * W) return;
-  int y = i / W, x = i % W;
-  int r = ws.parent[i];
-  int ci = ws.cidx[r];
-  if (ws.mask[i]) {
-    if (ci < 0) return;
-    const Contour c = ws.contours[ci];
-    int row = c.base + (y - c.ymin);
-    if (x == 0 || !ws.mask[i - 1]) atomicMin(&ws.rowmin[row], x);
-    if (x == W - 1 || !ws.mask[i + 1]) atomicMax(&ws.rowmax[row], x);
-  } else {
-    if (ci < 0) return;  // outside background
-    const Contour c = ws.contours[ci];
-    if (x > 0 && ws.mask[i - 1]) { int row = c.base + (y - c.ymin); atomicMin(&ws.rowmin[row], x - 1); atomicMax(&ws.rowmax[row], x - 1); }
-    if (x + 1 < W && ws.mask[i + 1]) { int row = c.base + (y - c.ymin); atomicMin(&ws.rowmin[row], x + 1); atomicMax(&ws.rowmax[row], x + 1); }
-    if (y > 0 && ws.mask[i - W]) { int row = c.base + (y - 1 - c.ymin); atomicMin(&ws.rowmin[row], x); atomicMax(&ws.rowmax[row], x); }
-    if (y + 1 < H && ws.mask[i + W]) { int row = c.base + (y + 1 - c.ymin); atomicMin(&ws.rowmin[row], x); atomicMax(&ws.rowmax[row], x); }
-  }
-}
-
-// ---- per-contour geometry ----------------------------------------------------------
-struct DP { double x, y; };
-
-// imageproc geometry::rotating_calipers on a hull of >= 3 points.
-// get(i) returns hull point i as doubles.  out: 4 corners TL,TR,BR,BL, floor()ed.
-template <typename Get>
-__device__ void rotating_calipers(int n, Get get, double* out8) {
-  const double PI = 3.14159265358979323846264338327950288;
-  double min_area = 1.7976931348623157e308;
-  DP res[4] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};
-  double prev_angle = 0.0;
-  for (int e = 0; e + 1 < n; e++) {  // points.windows(2): the closing edge is not visited
-    DP a = get(e), b = get(e + 1);
-    double ex = b.x - a.x, ey = b.y - a.y;
-    double angle = fabs(fmod(atan2(ey, ex) + PI, PI / 2.0));
-    if (e > 0 && angle == prev_angle) continue;  // Vec::dedup
-    prev_angle = angle;
-    double s = sin(angle), c = cos(angle);
-    double min_x = 1.7976931348623157e308, max_x = -1.7976931348623157e308;
-    double min_y = 1.7976931348623157e308, max_y = -1.7976931348623157e308;
-    for (int i = 0; i < n; i++) {
-      DP p = get(i);
-      double rx = p.x * c + p.y * s;
-      double ry = p.y * c - p.x * s;
-      min_x = fmin(min_x, rx); max_x = fmax(max_x, rx);
-      min_y = fmin(min_y, ry); max_y = fmax(max_y, ry);
-    }
-    double area = (max_x - min_x) * (max_y - min_y);
-    if (area < min_area) {
-      min_area = area;
-      res[0] = DP{max_x * c - min_y * s, min_y * c + max_x * s};
-      res[1] = DP{min_x * c - min_y * s, min_y * c + min_x * s};
-      res[2] = DP{min_x * c - max_y * s, max_y * c + min_x * s};
-      res[3] = DP{max_x * c - max_y * s, max_y * c + max_x * s};
-    }
-  }
-  // stable sort of 4 by x (insertion sort)
-  for (int i = 1; i < 4; i++) {
-    DP k = res[i]; int j = i - 1;
-    while (j >= 0 && res[j].x > k.x) { res[j + 1] = res[j]; j--; }
-    res[j + 1] = k;
-  }
-  int i1 = res[1].y > res[0].y ? 0 : 1;
-  int i2 = res[3].y > res[2].y ? 2 : 3;
-  int i3 = res[3].y > res[2].y ? 3 : 2;
-  int i4 = res[1].y > res[0].y ? 1 : 0;
-  int idx[4] = {i1, i2, i3, i4};
-  for (int i = 0; i < 4; i++) { out8[2 * i] = floor(res[idx[i]].x); out8[2 * i + 1] = floor(res[idx[i]].y); }
-}
-
-template <typename Get>
-__device__ void min_area_rect_hull(int n, Get get, double* out8) {
-  if (n == 1) { DP p = get(0); for (int i = 0; i < 4; i++) { out8[2 * i] = p.x; out8[2 * i + 1] = p.y; } return; }
-  if (n == 2) {
-    DP a = get(0), b = get(1);
-    out8[0] = a.x; out8[1] = a.y; out8[2] = b.x; out8[3] = b.y; out8[4] = b.x; out8[5] = b.y; out8[6] = a.x; out8[7] = a.y;
-    return;
-  }
-  rotating_calipers(n, get, out8);
-}
-
-__device__ __forceinline__ long long orient_ll(int2 p, int2 q, int2 r) {
-  return (long long)(q.y - p.y) * (long long)(r.x - q.x) - (long long)(q.x - p.x) * (long long)(r.y - q.y);
-}
-
-// Strict convex hull of a contour from its per-row extents, in imageproc's order: start
-// at the top-most then left-most point, then along increasing x (screen-clockwise).
-__device__ int hull_from_rows(const int* rmin, const int* rmax, int rows, int ymin, int2* hs) {
-  int top = 0; while (top < rows && rmax[top] < 0) top++;
-  int bot = rows - 1; while (bot >= 0 && rmax[bot] < 0) bot--;
-  if (top > bot) return 0;
-  int n = 0;
-  // right chain
-  hs[n++] = make_int2(rmin[top], ymin + top);
-  for (int r = top; r <= bot; r++) {
-    if (rmax[r] < 0) continue;
-    int2 p = make_int2(rmax[r], ymin + r);
-    if (hs[n - 1].x == p.x && hs[n - 1].y == p.y) continue;
-    while (n >= 2 && orient_ll(hs[n - 2], hs[n - 1], p) >= 0) n--;
-    hs[n++] = p;
-  }
-  // left chain (back to the start point)
-  int t = n;  // keep hs[t-1] (bottom-right) as the chain base
-  for (int r = bot; r >= top; r--) {
-    if (rmax[r] < 0) continue;
-    int2 p = make_int2(rmin[r], ymin + r);
-    if (hs[n - 1].x == p.x && hs[n - 1].y == p.y) continue;
-    while (n > t && orient_ll(hs[n - 2], hs[n - 1], p) >= 0) n--;
-    hs[n++] = p;
-  }
-  if (n > 1 && hs[n - 1].x == hs[0].x && hs[n - 1].y == hs[0].y) n--;
-  return n;
-}
-
-// imageproc draw_polygon_mut + BresenhamLineIter coverage of one canvas row, as a list of
-// x intervals.  poly: 4 points relative to the canvas origin.
-struct RowCover { int lo[8], hi[8]; int n; };
-__device__ __forceinline__ long long ceil_div_ll(long long a, long long b) { return a >= 0 ? (a + b - 1) / b : -((-a) / b); }
-__device__ __forceinline__ long long floor_div_ll(long long a, long long b) { return a >= 0 ? a / b : -((-a + b - 1) / b); }
-
-__device__ void row_cover(const int2* poly, int bw, int bh, int py_min, int py_max, int y, RowCover& rc) {
-  rc.n = 0;
-  // scan-line fill
-  if (y >= py_min && y <= py_max) {
-    int inter[8]; int ni = 0;
-    for (int e = 0; e < 4; e++) {
-      int2 p0 = poly[e], p1 = poly[(e + 1) & 3];
-      if ((p0.y <= y && p1.y >= y) || (p1.y <= y && p0.y >= y)) {
-        if (p0.y == p1.y) { inter[ni++] = p0.x; inter[ni++] = p1.x; }
-        else if (p0.y == y || p1.y == y) {
-          if (p1.y > y) inter[ni++] = p0.x;
-          if (p0.y > y) inter[ni++] = p1.x;
-        } else {
-          float fraction = (float)(y - p0.y) / (float)(p1.y - p0.y);
-          float in = (float)p0.x + fraction * (float)(p1.x - p0.x);
-          inter[ni++] = gm::f32_as_i32(roundf(in));
-        }
-      }
-    }
-    for (int i = 1; i < ni; i++) { int k = inter[i], j = i - 1; while (j >= 0 && inter[j] > k) { inter[j + 1] = inter[j]; j--; } inter[j + 1] = k; }
-    for (int k = 0; k + 1 < ni; k += 2) {
-      int from = min(inter[k], bw), to = min(inter[k + 1], bw - 1);
-      if (from < bw && to >= 0) {
-        from = max(0, from); to = max(0, to);
-        if (from <= to) { rc.lo[rc.n] = from; rc.hi[rc.n] = to; rc.n++; }
-      }
-    }
-  }
-  // polygon outline: Bresenham pixels of each edge that fall in this row
-  for (int e = 0; e < 4; e++) {
-    int x0 = poly[e].x, y0 = poly[e].y, x1 = poly[(e + 1) & 3].x, y1 = poly[(e + 1) & 3].y;
-    bool steep = abs(y1 - y0) > abs(x1 - x0);
-    if (steep) { int t = x0; x0 = y0; y0 = t; t = x1; x1 = y1; y1 = t; }
-    if (x0 > x1) { int t = x0; x0 = x1; x1 = t; t = y0; y0 = y1; y1 = t; }
-    long long dx = x1 - x0, dy = abs(y1 - y0);
-    int ystep = y0 < y1 ? 1 : -1;
-    // after i steps the minor coordinate has advanced k_i = ceil((2 i dy - dx) / (2 dx)) times
-    if (steep) {
-      long long i = (long long)y - x0;  // major axis is the canvas y
-      if (i < 0 || i > dx) continue;
-      long long k = dx > 0 ? ceil_div_ll(2 * i * dy - dx, 2 * dx) : 0;
-      int x = y0 + ystep * (int)k;
-      if (x >= 0 && x < bw) { rc.lo[rc.n] = x; rc.hi[rc.n] = x; rc.n++; }
-    } else {
-      long long kk = (long long)(y - y0) * ystep;
-      if (kk < 0) continue;
-      long long ilo, ihi;
-      if (dy == 0) { if (kk != 0) continue; ilo = 0; ihi = dx; }
-      else {
-        ilo = kk == 0 ? 0 : floor_div_ll(2 * dx * kk - dx, 2 * dy) + 1;
-        ihi = floor_div_ll(2 * dx * kk + dx, 2 * dy);
-        if (ilo < 0) ilo = 0;
-        if (ihi > dx) ihi = dx;
-      }
-      if (ilo > ihi) continue;
-      int lo = (int)(x0 + ilo), hi = (int)(x0 + ihi);
-      lo = max(lo, 0); hi = min(hi, bw - 1);
-      if (lo <= hi) { rc.lo[rc.n] = lo; rc.hi[rc.n] = hi; rc.n++; }
-    }
-  }
-}
-
-// det_processor.rs:188-221 box_score_fast (sequential f32 accumulation, row-major).
-__device__ float box_score_fast(const float* pred, int H, int W, const int* box) {
-  int x_min = 0x7fffffff, x_max = -0x7fffffff - 1, y_min = 0x7fffffff, y_max = -0x7fffffff - 1;
-  for (int i = 0; i < 4; i++) {
-    x_min = min(x_min, box[2 * i]); x_max = max(x_max, box[2 * i]);
-    y_min = min(y_min, box[2 * i + 1]); y_max = max(y_max, box[2 * i + 1]);
-  }
-  x_min = min(max(x_min, 0), W - 1); x_max = min(max(x_max, 0), W - 1);
-  y_min = min(max(y_min, 0), H - 1); y_max = min(max(y_max, 0), H - 1);
-  int bw = x_max - x_min + 1, bh = y_max - y_min + 1;
-  int2 poly[4];
-  for (int i = 0; i < 4; i++) poly[i] = make_int2(box[2 * i] - x_min, box[2 * i + 1] - y_min);
-  if (poly[0].x == poly[3].x && poly[0].y == poly[3].y) return 0.0f;  // draw_polygon_mut would panic (A.4)
-  int py_min = 0x7fffffff, py_max = -0x7fffffff - 1;
-  for (int i = 0; i < 4; i++) { py_min = min(py_min, poly[i].y); py_max = max(py_max, poly[i].y); }
-  py_min = max(0, min(py_min, bh - 1)); py_max = max(0, min(py_max, bh - 1));
-  float sum = 0.0f; unsigned long long count = 0;
-  RowCover rc;
-  for (int y = 0; y < bh; y++) {
-    row_cover(poly, bw, bh, py_min, py_max, y, rc);
-    if (rc.n == 0) continue;
-    int lo = rc.lo[0], hi = rc.hi[0];
-    for (int k = 1; k < rc.n; k++) { lo = min(lo, rc.lo[k]); hi = max(hi, rc.hi[k]); }
-    const float* prow = pred + (size_t)(y + y_min) * W + x_min;
-    for (int x = lo; x <= hi; x++) {
-      bool in = false;
-      for (int k = 0; k < rc.n; k++) in = in || (x >= rc.lo[k] && x <= rc.hi[k]);
-      if (in) { sum = sum + prow[x]; count++; }
-    }
-  }
-  return count > 0 ? sum / (float)count : 0.0f;
-}
-
-// Clipper 6.4.2 ClipperOffset (jtRound, etClosedPolygon, arc tolerance 0.5) of the
-// 4-point box, det_processor.rs:223-252.  Returns the number of
-// offset vertices written to (ox, oy) (closing duplicate NOT appended: min_area_rect
-// only looks at the hull).  0 = no polygon.
-#define RT_MAX_OFFSET_PTS 384
-__device__ __forceinline__ long long cl_round(double v) { return v < 0 ? (long long)(v - 0.5) : (long long)(v + 0.5); }
-
-__device__ int unclip_box(const int* box, float unclip_ratio, float* ox, float* oy, int* overflow) {
-  float cx[5], cy[5];
-  for (int i = 0; i < 4; i++) { cx[i] = (float)box[2 * i]; cy[i] = (float)box[2 * i + 1]; }
-  cx[4] = cx[0]; cy[4] = cy[0];
-  float sx = cx[0], sy = cy[0], tmp = 0.0f;
-  for (int i = 0; i < 4; i++) {
-    float ax = cx[i] - sx, ay = cy[i] - sy, bx = cx[i + 1] - sx, by = cy[i + 1] - sy;
-    tmp += ax * by - bx * ay;
-  }
-  float area = fabsf(tmp / 2.0f);
-  float perimeter = 0.0f;
-  for (int i = 0; i < 4; i++) {
-    float dx = cx[i] - cx[i + 1], dy = cy[i] - cy[i + 1];
-    perimeter += (float)sqrt((double)dx * (double)dx + (double)dy * (double)dy);
-  }
-  perimeter = perimeter + 0.0f;
-  float distance = area * unclip_ratio / perimeter;
-  double delta = (double)(distance * 1.0f);
-  // ClipperOffset::AddPath: strip closing / consecutive duplicates
-  long long sxp[4], syp[4]; int len = 0;
-  {
-    long long px[5], py[5];
-    for (int i = 0; i < 5; i++) { px[i] = (long long)(cx[i] * 1.0f); py[i] = (long long)(cy[i] * 1.0f); }
-    int highI = 4;
-    while (highI > 0 && px[0] == px[highI] && py[0] == py[highI]) highI--;
-    sxp[0] = px[0]; syp[0] = py[0]; len = 1;
-    for (int i = 1; i <= highI; i++)
-      if (sxp[len - 1] != px[i] || syp[len - 1] != py[i]) { sxp[len] = px[i]; syp[len] = py[i]; len++; }
-  }
-  if (len < 3) return 0;
-  // FixOrientations
-  {
-    double a = 0;
-    for (int i = 0, j = len - 1; i < len; ++i) { a += ((double)sxp[j] + (double)sxp[i]) * ((double)syp[j] - (double)syp[i]); j = i; }
-    double ar = -a * 0.5;
-    if (!(ar >= 0)) {
-      for (int i = 0; i < len / 2; i++) {
-        long long t = sxp[i]; sxp[i] = sxp[len - 1 - i]; sxp[len - 1 - i] = t;
-        t = syp[i]; syp[i] = syp[len - 1 - i]; syp[len - 1 - i] = t;
-      }
-    }
-  }
-  int n = 0;
-  auto push = [&](long long X, long long Y) {
-    if (n < RT_MAX_OFFSET_PTS) { ox[n] = (float)((double)X / 1.0); oy[n] = (float)((double)Y / 1.0); n++; }
-    else *overflow = 1;
-  };
-  const double pi = 3.141592653589793238, two_pi = pi * 2, def_arc_tolerance = 0.25, arc_tolerance = 0.5;
-  if (fabs(delta) < 1.0E-20) { for (int i = 0; i < len; i++) push(sxp[i], syp[i]); return n; }
-  double yv;
-  if (arc_tolerance > fabs(delta) * def_arc_tolerance) yv = fabs(delta) * def_arc_tolerance;
-  else yv = arc_tolerance;
-  double steps = pi / acos(1 - yv / fabs(delta));
-  if (steps > fabs(delta) * pi) steps = fabs(delta) * pi;
-  double m_sin = sin(two_pi / steps), m_cos = cos(two_pi / steps);
-  double steps_per_rad = steps / two_pi;
-  if (delta < 0.0) m_sin = -m_sin;
-  double nx[4], ny[4];
-  for (int j = 0; j < len; j++) {
-    int j2 = (j + 1 == len) ? 0 : j + 1;
-    if (sxp[j2] == sxp[j] && syp[j2] == syp[j]) { nx[j] = 0; ny[j] = 0; continue; }
-    double Dx = (double)(sxp[j2] - sxp[j]), Dy = (double)(syp[j2] - syp[j]);
-    double f = 1 * 1.0 / sqrt(Dx * Dx + Dy * Dy);
-    Dx *= f; Dy *= f;
-    nx[j] = Dy; ny[j] = -Dx;
-  }
-  int k = len - 1;
-  for (int j = 0; j < len; ++j) {
-    double sinA = nx[k] * ny[j] - nx[j] * ny[k];
-    bool done = false;
-    if (fabs(sinA * delta) < 1.0) {
-      double cosA = nx[k] * nx[j] + ny[j] * ny[k];
-      if (cosA > 0) { push(cl_round(sxp[j] + nx[k] * delta), cl_round(syp[j] + ny[k] * delta)); done = true; }
-    } else if (sinA > 1.0) sinA = 1.0;
-    else if (sinA < -1.0) sinA = -1.0;
-    if (!done) {
-      if (sinA * delta < 0) {
-        push(cl_round(sxp[j] + nx[k] * delta), cl_round(syp[j] + ny[k] * delta));
-        push(sxp[j], syp[j]);
-        push(cl_round(sxp[j] + nx[j] * delta), cl_round(syp[j] + ny[j] * delta));
-      } else {
-        double a = atan2(sinA, nx[k] * nx[j] + ny[k] * ny[j]);
-        long long rs = cl_round(steps_per_rad * fabs(a));
-        int nsteps = (int)(rs > 1 ? rs : 1);
-        double X = nx[k], Y = ny[k], X2;
-        for (int i = 0; i < nsteps; ++i) {
-          push(cl_round(sxp[j] + X * delta), cl_round(syp[j] + Y * delta));
-          X2 = X;
-          X = X * m_cos - m_sin * Y;
-          Y = X2 * m_sin + Y * m_cos;
-        }
-        push(cl_round(sxp[j] + nx[j] * delta), cl_round(syp[j] + ny[j] * delta));
-      }
-    }
-    k = j;
-  }
-  if (n < 3) return 0;
-  return n;
-}
-
-// strict convex hull (imageproc order) of <= RT_MAX_OFFSET_PTS integral-valued f32 points
-// by gift wrapping; writes hull indices to hidx.
-__device__ int hull_jarvis(const float* px, const float* py, int n, short* hidx) {
-  int s = 0;
-  for (int i = 1; i < n; i++) if (py[i] < py[s] || (py[i] == py[s] && px[i] < px[s])) s = i;
-  int h = 0, p = s;
-  while (true) {
-    hidx[h++] = (short)p;
-    int q = -1;
-    for (int r = 0; r < n; r++) {
-      if (px[r] == px[p] && py[r] == py[p]) continue;
-      if (q < 0) { q = r; continue; }
-      double val = ((double)py[q] - (double)py[p]) * ((double)px[r] - (double)px[q]) -
-                   ((double)px[q] - (double)px[p]) * ((double)py[r] - (double)py[q]);
-      if (val > 0.0) q = r;  // r lies on the clockwise side: it comes first
-      else if (val == 0.0) {
-        double dq = ((double)px[q] - px[p]) * ((double)px[q] - px[p]) + ((double)py[q] - py[p]) * ((double)py[q] - py[p]);
-        double dr = ((double)px[r] - px[p]) * ((double)px[r] - px[p]) + ((double)py[r] - py[p]) * ((double)py[r] - py[p]);
-        // collinear: keep the farther one if it lies in the same direction
-        double dot = ((double)px[q] - px[p]) * ((double)px[r] - px[p]) + ((double)py[q] - py[p]) * ((double)py[r] - py[p]);
-        if (dot > 0.0 && dr > dq) q = r;
-        else if (dot < 0.0) {
-          // opposite directions from p: p is interior to segment (q, r); the hull edge leaving p
-          // in traversal order is the one keeping every other point on the CCW side - decided
-          // by the remaining points, so leave q unchanged here.
-        }
-      }
-    }
-    if (q < 0) break;  // all points coincide
-    if (px[q] == px[s] && py[q] == py[s]) break;
-    if (h >= n) break;
-    p = q;
-  }
-  return h;
-}
-
-__device__ __forceinline__ float euclid_f32(float ax, float ay, float bx, float by) {
-  float dx = ax - bx, dy = ay - by;
-  return sqrtf(dx * dx + dy * dy);
-}
-
-__global__ __launch_bounds__(64) void k_contour_boxes(const float* __restrict__ pred, int H, int W, int ori_h, int ori_w,
-                                                      DbParams prm, DbWs ws) {
-  int ci = blockIdx.x * 64 + threadIdx.x;
-  int ncont = min(ws.counters[0], ws.contour_cap);
-  if (ci >= ncont) return;
-  const Contour ct = ws.contours[ci];
-  int2* hs = ws.hull + ct.hbase;
-  int hn = hull_from_rows(ws.rowmin + ct.base, ws.rowmax + ct.base, ct.rows, ct.ymin, hs);
-  if (hn == 0) return;
-  double r[8];
-  min_area_rect_hull(hn, [&](int i) { return DP{(double)hs[i].x, (double)hs[i].y}; }, r);
-  int box[8];
-  for (int i = 0; i < 8; i++) box[i] = (int)r[i];
-  float s1 = euclid_f32((float)box[0], (float)box[1], (float)box[2], (float)box[3]);
-  float s2 = euclid_f32((float)box[6], (float)box[7], (float)box[4], (float)box[5]);
-  float sside = fminf(s1, s2);
-  if (sside < (float)prm.min_size) return;
-  float mean_score = box_score_fast(pred, H, W, box);
-  if (mean_score < prm.box_thresh) return;
-  float ox[RT_MAX_OFFSET_PTS], oy[RT_MAX_OFFSET_PTS];
-  short hidx[RT_MAX_OFFSET_PTS];
-  int ovf = 0;
-  int on = unclip_box(box, prm.unclip_ratio, ox, oy, &ovf);
-  if (ovf) { ws.counters[4] = 1; return; }
-  if (on == 0) return;
-  int h2 = hull_jarvis(ox, oy, on, hidx);
-  double r2[8];
-  min_area_rect_hull(h2, [&](int i) { return DP{(double)ox[hidx[i]], (double)oy[hidx[i]]}; }, r2);
-  DbBox b;
-  for (int i = 0; i < 8; i++) b.pts[i] = (float)r2[i];
-  float t1 = euclid_f32(b.pts[0], b.pts[1], b.pts[2], b.pts[3]);
-  float t2 = euclid_f32(b.pts[6], b.pts[7], b.pts[4], b.pts[5]);
-  if (fminf(t1, t2) < (float)(prm.min_size + 2)) return;
-  gm::scale_and_clip(b.pts, (double)W, (double)H, (double)ori_w, (double)ori_h);
-  float pb_h = gm::side_len(&b.pts[0], &b.pts[6]);
-  float pb_w = gm::side_len(&b.pts[0], &b.pts[2]);
-  if (pb_h <= 3.0f || pb_w <= 3.0f) return;
-  b.score = mean_score;
-  b.key = ct.type == 0 ? ct.root : ct.root - 1;
-  int slot = atomicAdd(&ws.counters[3], 1);
-  if (slot >= ws.cand_cap) { ws.counters[4] = 1; return; }
-  ws.cand[slot] = b;
-}
-
-// det_processor.rs:324-333: stable sort (discovery order first) with the reading-order
-// comparator.  One block; rank sort (valid for the strict weak orders the contract covers).
-__device__ __forceinline__ bool box_less(const DbBox& a, const DbBox& b) {
-  float y1 = (a.pts[1] + a.pts[5]) / 2.0f, y2 = (b.pts[1] + b.pts[5]) / 2.0f;
-  if (fabsf(y1 - y2) < 10.0f) {
-    float x1 = (a.pts[0] + a.pts[4]) / 2.0f, x2 = (b.pts[0] + b.pts[4]) / 2.0f;
-    return x1 < x2;
-  }
-  return y1 < y2;
-}
-// Stable bottom-up merge sort (run width 1, 2, 4, ...; take from the left run unless
-// right < left) applied to the boxes in contour discovery order.  For the strict weak
-// orders of the contract every stable sort gives this result; for the comparator's
-// non-transitive inputs this exact algorithm is the defined behaviour and the
-// oracle uses the same one.  Sorting works on indices + centres held in LDS.
-#define RT_SORT_MAX 4096
-__global__ __launch_bounds__(256) void k_sort_boxes(DbWs ws, DbBox* __restrict__ out, int* __restrict__ count_out) {
-  __shared__ float cx[RT_SORT_MAX], cy[RT_SORT_MAX];
-  __shared__ unsigned short ia[RT_SORT_MAX], ib[RT_SORT_MAX];
-  int n = min(min(ws.counters[3], ws.cand_cap), RT_SORT_MAX);
-  // discovery order: rank by the (unique) start-pixel key
-  for (int i = threadIdx.x; i < n; i += 256) {
-    int key = ws.cand[i].key, rank = 0;
-    for (int j = 0; j < n; j++) rank += ws.cand[j].key < key;
-    ia[rank] = (unsigned short)i;
-    cx[i] = (ws.cand[i].pts[0] + ws.cand[i].pts[4]) / 2.0f;
-    cy[i] = (ws.cand[i].pts[1] + ws.cand[i].pts[5]) / 2.0f;
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    auto less = [&](int a, int b) {
-      if (fabsf(cy[a] - cy[b]) < 10.0f) return cx[a] < cx[b];
-      return cy[a] < cy[b];
-    };
-    unsigned short* src = ia; unsigned short* dst = ib;
-    for (int width = 1; width < n; width *= 2) {
-      for (int lo = 0; lo < n; lo += 2 * width) {
-        int mid = min(lo + width, n), hi = min(lo + 2 * width, n);
-        int i = lo, j = mid, k = lo;
-        while (i < mid && j < hi) {
-          if (less(src[j], src[i])) dst[k++] = src[j++];
-          else dst[k++] = src[i++];
-        }
-        while (i < mid) dst[k++] = src[i++];
-        while (j < hi) dst[k++] = src[j++];
-      }
-      unsigned short* t = src; src = dst; dst = t;
-    }
-    if (src != ia) for (int i = 0; i < n; i++) ia[i] = src[i];
-    count_out[0] = n;
-    count_out[1] = ws.counters[4] | (ws.counters[3] > RT_SORT_MAX ? 1 : 0);
-  }
-  __syncthreads();
-  for (int i = threadIdx.x; i < n; i += 256) out[i] = ws.cand[ia[i]];
-}
-
-void db_postprocess(hipStream_t st, const float* pred, int H, int W, int ori_h, int ori_w, const DbParams& p,
-                    void* workspace, int max_boxes, DbBox* boxes_out, int* count_out) {
-  size_t total;
-  DbWs ws = carve(workspace, H, W, max_boxes, &total);
-  int N = H * W;
-  dim3 grid((N + 255) / 256), blk(256);
-  hipLaunchKernelGGL(k_db_mask, grid, blk, 0, st, pred, H, W, p.thresh, p.dilate, ws);
-  hipLaunchKernelGGL(k_ccl_merge, grid, blk, 0, st, H, W, ws);
-  hipLaunchKernelGGL(k_ccl_stats, grid, blk, 0, st, H, W, ws);
-  hipLaunchKernelGGL(k_contour_alloc, grid, blk, 0, st, H, W, ws);
-  hipLaunchKernelGGL(k_row_extents, grid, blk, 0, st, H, W, ws);
-  hipLaunchKernelGGL(k_contour_boxes, dim3((ws.contour_cap + 63) / 64), dim3(64), 0, st, pred, H, W, ori_h, ori_w, p, ws);
-  hipLaunchKernelGGL(k_sort_boxes, dim3(1), dim3(256), 0, st, ws, boxes_out, count_out);
-}
 
 // ===========================================================================
 // crops: imageproc warp_into(Bicubic, default white) + rotate270

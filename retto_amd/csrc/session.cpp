@@ -203,7 +203,12 @@ void rt_session::det_postprocess(const float* pred, int h, int w, int ori_h, int
   void* ws = dbws.alloc_bytes(pp::db_workspace_bytes(h, w, mb));
   pp::DbBox* db = arena.alloc<pp::DbBox>(mb);
   int* cnt = arena.alloc<int>(2);
-  pp::db_postprocess(st, d, h, w, ori_h, ori_w, db_params(cfg), ws, mb, db, cnt);
+  {
+    pp::DbPageIn in{d, h, w, ori_h, ori_w};
+    void* hd = pinned.alloc_bytes(pp::db_page_desc_bytes());
+    void* dd = arena.alloc_bytes(pp::db_page_desc_bytes());
+    pp::db_postprocess_batch(st, 1, &in, db_params(cfg), &ws, mb, &db, &cnt, hd, dd);
+  }
   int hc[2];
   RT_HIP_CHECK(hipMemcpyAsync(hc, cnt, 8, hipMemcpyDeviceToHost, st));
   sync();
@@ -410,23 +415,31 @@ rt_results* rt_session::run_batch(const uint8_t* const* rgb, const int* hs, cons
   }
 
   // ---- a5: DB post-processing per page (on device; stream-ordered workspace reuse) --
-  size_t ws_bytes = 0;
-  for (auto& p : pg) ws_bytes = std::max(ws_bytes, pp::db_workspace_bytes(p.det_h, p.det_w, mb));
-  void* wsp = dbws.alloc_bytes(ws_bytes);
-  for (int i = 0; i < n_pages; i++) {
-    PageState& p = pg[i];
-    const float* pred = p.map;
-    if (det_map_override && det_map_override[i]) {
-      if (mem == RT_MEM_HOST) {
-        float* d = arena.alloc<float>((size_t)p.det_h * p.det_w);
-        RT_HIP_CHECK(hipMemcpyAsync(d, det_map_override[i], (size_t)p.det_h * p.det_w * 4, hipMemcpyHostToDevice, st));
-        pred = d;
-      } else pred = det_map_override[i];
+  {
+    std::vector<pp::DbPageIn> in((size_t)n_pages);
+    std::vector<void*> wsp((size_t)n_pages);
+    std::vector<pp::DbBox*> bo((size_t)n_pages);
+    std::vector<int*> co((size_t)n_pages);
+    for (int i = 0; i < n_pages; i++) {
+      PageState& p = pg[i];
+      const float* pred = p.map;
+      if (det_map_override && det_map_override[i]) {
+        if (mem == RT_MEM_HOST) {
+          float* d = arena.alloc<float>((size_t)p.det_h * p.det_w);
+          RT_HIP_CHECK(hipMemcpyAsync(d, det_map_override[i], (size_t)p.det_h * p.det_w * 4, hipMemcpyHostToDevice, st));
+          pred = d;
+        } else pred = det_map_override[i];
+      }
+      p.d_boxes = arena.alloc<pp::DbBox>(mb);
+      p.d_count = arena.alloc<int>(2);
+      in[i] = pp::DbPageIn{pred, p.det_h, p.det_w, p.after_h, p.after_w};
+      wsp[i] = dbws.alloc_bytes(pp::db_workspace_bytes(p.det_h, p.det_w, mb));
+      bo[i] = p.d_boxes; co[i] = p.d_count;
     }
-    p.d_boxes = arena.alloc<pp::DbBox>(mb);
-    p.d_count = arena.alloc<int>(2);
+    void* hd = pinned.alloc_bytes((size_t)n_pages * pp::db_page_desc_bytes());
+    void* dd = arena.alloc_bytes((size_t)n_pages * pp::db_page_desc_bytes());
     ProfScope ps(&prof, st, "db_postprocess");
-    pp::db_postprocess(st, pred, p.det_h, p.det_w, p.after_h, p.after_w, db_params(cfg), wsp, mb, p.d_boxes, p.d_count);
+    pp::db_postprocess_batch(st, n_pages, in.data(), db_params(cfg), wsp.data(), mb, bo.data(), co.data(), hd, dd);
   }
   // metadata round trip #1: box lists (a few KB per page); pixels and tensors stay on the device
   int* h_counts = pinned.alloc<int>((size_t)2 * n_pages);
