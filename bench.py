@@ -38,6 +38,7 @@ def parse():
     ap.add_argument("--size", type=int, default=960)
     ap.add_argument("--lines", type=int, default=32, help="planted text lines per page")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--det-sub-batch", type=int, default=0)
     ap.add_argument("--cpu-pages", type=int, default=1, help="pages of the same workload timed on the CPU oracle")
     ap.add_argument("--profile-all", action="store_true", help="print the per-family table to stderr")
     return ap.parse_args()
@@ -74,6 +75,7 @@ def main():
         blobs = broadcast_blobs(blobs, 4, rank, device="cuda")  # RCCL over xGMI, once
     det_b, cls_b, rec_b, dict_b = blobs
     cfg = retto_amd.RettoSessionConfig()
+    cfg.det_sub_batch = a.det_sub_batch
     cfg.worker_config = retto_amd.RettoHipWorkerConfig(device=device, models=retto_amd.RettoWorkerModelProvider(
         det=retto_amd.RettoWorkerModelSource.Blob(det_b), rec=retto_amd.RettoWorkerModelSource.Blob(rec_b),
         cls=retto_amd.RettoWorkerModelSource.Blob(cls_b)))

@@ -212,6 +212,7 @@ int rt_profile_get(rt_session* s, const char* const** names, const float** ms, c
   return RT_OK;
 }
 
+RT_API void rt_debug_set_variants(int gemm_variant, int dw_variant, int fuse_dwpw) { nn::g_gemm_variant = gemm_variant; nn::g_dw_variant = dw_variant; nn::g_fuse_dwpw = fuse_dwpw; }
 // Kernel micro-benchmark (not part of the drop-in surface): times nn::gemm on random data.
 RT_API int rt_bench_gemm(rt_session* s, long long M, int K, int N, int variant, int iters, float* ms_out, float* maxdiff_out) {
   RT_REQUIRE(s && ms_out, s, "rt_bench_gemm: null argument");

@@ -204,6 +204,14 @@ static const float HSIG_LCNET = 0.1666667f;  // paddle nn.Hardsigmoid
 static const float HSIG_MBV3 = 0.2f;         // F.hardsigmoid(slope=0.2, offset=0.5)
 
 static float* run_lc(RunCtx& c, const LcBlock& b, const float* x, const Level& Lin, const Level& Lout) {
+  if (nn::g_fuse_dwpw && !b.se && b.sh == 1 && b.sw == 1 && b.dw.Cp % 4 == 0) {
+    int Cpo = round_up(b.cout, 4);
+    float* y2 = c.arena->alloc<float>((size_t)Lout.total * Cpo);
+    ProfScope ps(c.prof, c.st, b.dw.k == 3 ? "dwpw3" : "dwpw5");
+    nn::dwpw(c.st, b.dw.k, x, Lout.d, Lout.n(), Lout.maxH, Lout.maxW, b.dw.Cp, b.dw.w, b.dw.b, b.dw_act, b.dw_lab.has,
+             b.dw_lab.a, b.dw_lab.c, b.pw.w, b.pw.N, b.pw.Npad, y2, Cpo, make_epi(b.pw, ACT_HSWISH, &b.pw_lab));
+    return y2;
+  }
   float* y1 = c.arena->alloc<float>((size_t)Lout.total * b.dw.Cp);
   { ProfScope ps(c.prof, c.st, b.dw.k == 3 ? "dwconv3" : "dwconv5");
     nn::dwconv(c.st, b.dw.k, b.sh, b.sw, x, Lin.d, Lout.d, Lout.n(), Lout.maxH, Lout.maxW, b.dw.Cp, b.dw.w, b.dw.b,

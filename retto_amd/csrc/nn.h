@@ -12,6 +12,7 @@ constexpr int KC = 32;  // K-chunk of the MFMA GEMM / conv kernels (weights are 
 // C[M, ldc] (+coff) = epi(A[M, lda] x W), W packed as [ceil(K/KC)][Npad16][KC].
 void gemm(hipStream_t st, const float* A, int lda, long long M, int K, const float* Wp, int N, int Npad16, float* C,
           int ldc, int coff, const Epilogue& epi);
+extern int g_dw_variant;    // same for dwconv
 extern int g_gemm_variant;  // kernel micro-benchmark hook (0 = production dispatch)
 
 // Dense stride-1 "same" convolution, kernel (KH,KW) in {(3,3),(1,3)}; W packed as
@@ -23,6 +24,12 @@ void conv_sp(hipStream_t st, int KH, int KW, const float* x, int ldx, const ImgG
 void dwconv(hipStream_t st, int K, int sh, int sw, const float* x, const ImgGeom* gin, const ImgGeom* gout, int n_img,
             int maxHo, int maxWo, int Cp, const float* Wd, const float* bias, int act, int has_lab, float lab_a,
             float lab_c, float* y);
+
+// Fused stride-1 depthwise KxK (+bias, act, LAB) -> 1x1 conv (+epilogue); see k_dwpw.
+void dwpw(hipStream_t st, int K, const float* x, const ImgGeom* geom, int n_img, int maxH, int maxW, int Cp,
+          const float* Wd, const float* bd, int dw_act, int dw_has_lab, float dw_a, float dw_c, const float* Wp, int N,
+          int Npad16, float* y, int ldy, const Epilogue& epi);
+extern int g_fuse_dwpw;  // 1 = use the fused kernel where it applies (default)
 
 // 3x3 stride-2 stem on a 3(+1 pad)-channel f32 NHWC input. Ws packed [27][COUT]. COUT in {8,16}.
 void stem_conv(hipStream_t st, const float* x, const ImgGeom* gin, const ImgGeom* gout, int n_img, int maxHo, int maxWo,

@@ -357,6 +357,177 @@ __global__ __launch_bounds__(256) void k_gemm_32(const float* __restrict__ A, in
   }
 }
 
+// ---------------------------------------------------------------------------
+// Fused LCNetV3 block (stride 1, no SE): y = epi_pw( Wpw . lab(act(dw_KxK(x) + b_dw)) ).
+// The depthwise result only ever exists as the GEMM's A tile in LDS, so the block moves
+// input + output through HBM once instead of twice.
+// One workgroup = 12 waves: 8 consumer waves (4 x 2, each 32 pixels x 16*NT columns of
+// v_mfma_f32_16x16x4_f32) and 4 producer waves (one per SIMD) that compute the next
+// 32-channel depthwise slab (1x4 pixel strips x 4 channels per lane) and stage the next weight
+// slab while the consumers run the MFMAs of the current one; LDS is double buffered and there
+// is one barrier per slab.  VALU/TA work of the producers overlaps the matrix pipe.
+// Output tile: TH x (128/TH) pixels of one image.
+// ---------------------------------------------------------------------------
+template <int K, int NT>
+__global__ __launch_bounds__(768) void k_dwpw(const float* __restrict__ x, const ImgGeom* __restrict__ geom, int Cp,
+                                              const float* __restrict__ Wd, const float* __restrict__ bd, int dw_act,
+                                              int dw_has_lab, float dw_a, float dw_c, const float* __restrict__ Wp,
+                                              int N, int Npad, float* __restrict__ y, int ldy, Epilogue epi, int TH) {
+  constexpr int BN = 32 * NT;  // 2 consumer wave columns x 16*NT
+  __shared__ __attribute__((aligned(16))) float lds[2 * (128 + BN) * LROW];
+  constexpr int BUF = (128 + BN) * LROW;  // one buffer: 128 activation rows then BN weight rows
+  const ImgGeom g = geom[blockIdx.y];
+  const int TW = 128 / TH;
+  const int tiles_x = (g.W + TW - 1) / TW, tiles_y = (g.H + TH - 1) / TH;
+  if ((int)blockIdx.x >= tiles_x * tiles_y) return;
+  const int ty0 = (blockIdx.x / tiles_x) * TH, tx0 = (blockIdx.x % tiles_x) * TW;
+  const int n0 = blockIdx.z * BN;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const bool producer = wave >= 8;
+  const int nkc = (Cp + KC - 1) / KC;
+
+  // ---- producer state: lane -> (strip, channel group)
+  const int pl = (wave - 8) * 64 + lane;            // 0..255 among producer lanes
+  const int c4 = pl & 7, strip = pl >> 3;           // 32 strips of 4 pixels
+  const int sp0 = strip * 4;                        // first tile-local pixel of the strip
+  const int spy = sp0 / TW, spx = sp0 % TW;
+  auto produce = [&](int kc, int buf) {
+    const int ch = kc * KC + c4 * 4;
+    const int oy = ty0 + spy, ox0 = tx0 + spx;
+    f32x4 acc[4];
+    const bool live = ch < Cp && oy < g.H && ox0 < g.W;
+    if (live) {
+      const f32x4 b = *reinterpret_cast<const f32x4*>(bd + ch);
+      acc[0] = b; acc[1] = b; acc[2] = b; acc[3] = b;
+      // one input row at a time: keeps the producer's live set small (the consumer accumulators
+      // occupy the same register file) at the cost of per-row load latency, which the producers
+      // can afford (their slab takes ~1/3 of the consumers' MFMA time)
+#pragma unroll 1
+      for (int dy = 0; dy < K; dy++) {
+        int iy = oy + dy - K / 2;
+        if (iy < 0 || iy >= g.H) continue;
+        const float* row = x + (g.off + (long long)iy * g.W) * Cp + ch;
+        f32x4 v[K + 3];
+#pragma unroll
+        for (int j = 0; j < K + 3; j++) {
+          int ix = ox0 + j - K / 2;
+          v[j] = (ix >= 0 && ix < g.W) ? *reinterpret_cast<const f32x4*>(row + (long long)ix * Cp) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int dx = 0; dx < K; dx++) {
+          f32x4 w = *reinterpret_cast<const f32x4*>(Wd + (dy * K + dx) * Cp + ch);
+#pragma unroll
+          for (int j = 0; j < 4; j++)
+#pragma unroll
+            for (int e = 0; e < 4; e++) acc[j][e] = fmaf(v[j + dx][e], w[e], acc[j][e]);
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 4; j++)
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          float t = act_apply(acc[j][e], dw_act);
+          if (dw_has_lab) t = fmaf(t, dw_a, dw_c);
+          acc[j][e] = t;
+        }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; j++) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++) *reinterpret_cast<f32x4*>(lds + buf * BUF + (sp0 + j) * LROW + c4 * 4) = acc[j];
+    // weight slab: BN rows x 8 float4, 256 producer lanes
+#pragma unroll 2
+    for (int i = 0; i < BN / 32; i++) {
+      int idx = pl + 256 * i, row = idx >> 3, cc = idx & 7;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (n0 + row < Npad) v = *reinterpret_cast<const f32x4*>(Wp + ((long long)kc * Npad + n0 + row) * KC + cc * 4);
+      *reinterpret_cast<f32x4*>(lds + buf * BUF + (128 + row) * LROW + cc * 4) = v;
+    }
+  };
+
+  // ---- consumer state
+  const int r = lane & 15, q = lane >> 4, wm = wave >> 1, wn = wave & 1;
+  f32x4 acc[2][NT];
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int j = 0; j < NT; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  if (producer) produce(0, 0);
+  __syncthreads();
+  for (int kc = 0; kc < nkc; kc++) {
+    const int buf = kc & 1;
+    if (producer) {
+      if (kc + 1 < nkc) produce(kc + 1, buf ^ 1);
+    } else {
+      const float* xr = lds + buf * BUF + (wm * 32 + r) * LROW;
+      const float* wr = lds + buf * BUF + (128 + wn * NT * 16 + r) * LROW;
+#pragma unroll
+      for (int gi = 0; gi < KC / 16; gi++) {
+        f32x4 a[2], b[NT];
+#pragma unroll
+        for (int mt = 0; mt < 2; mt++) a[mt] = *reinterpret_cast<const f32x4*>(xr + mt * 16 * LROW + gi * 16 + 4 * q);
+#pragma unroll
+        for (int nt = 0; nt < NT; nt++) b[nt] = *reinterpret_cast<const f32x4*>(wr + nt * 16 * LROW + gi * 16 + 4 * q);
+#pragma unroll
+        for (int s = 0; s < 4; s++)
+#pragma unroll
+          for (int nt = 0; nt < NT; nt++)
+#pragma unroll
+            for (int mt = 0; mt < 2; mt++)
+              acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[nt][s], a[mt][s], acc[mt][nt], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+  if (producer) return;
+  const int nstore = (N + 3) & ~3;
+#pragma unroll
+  for (int mt = 0; mt < 2; mt++) {
+    const int p = wm * 32 + mt * 16 + r;
+    const int oy = ty0 + p / TW, ox = tx0 + p % TW;
+    if (oy >= g.H || ox >= g.W) continue;
+    const long long pix = g.off + (long long)oy * g.W + ox;
+#pragma unroll
+    for (int nt = 0; nt < NT; nt++) {
+      int col = n0 + (wn * NT + nt) * 16 + q * 4;
+      if (col >= nstore) continue;
+      f32x4 bias = {0.f, 0.f, 0.f, 0.f};
+      if (epi.bias) bias = *reinterpret_cast<const f32x4*>(epi.bias + col);
+      f32x4 o;
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        float t = act_apply(acc[mt][nt][j] + bias[j], epi.act);
+        if (epi.has_lab) t = fmaf(t, epi.lab_a, epi.lab_c);
+        o[j] = (col + j < N) ? t : 0.0f;
+      }
+      *reinterpret_cast<f32x4*>(y + pix * ldy + col) = o;
+    }
+  }
+}
+
+void dwpw(hipStream_t st, int K, const float* x, const ImgGeom* geom, int n_img, int maxH, int maxW, int Cp,
+          const float* Wd, const float* bd, int dw_act, int dw_has_lab, float dw_a, float dw_c, const float* Wp, int N,
+          int Npad16, float* y, int ldy, const Epilogue& epi) {
+  if (n_img <= 0) return;
+  int TH = 8;
+  while (TH > 1 && TH > maxH) TH >>= 1;
+  if (maxH == 12 || maxH == 6 || maxH == 3) TH = maxH == 3 ? 2 : (maxH == 6 ? 2 : 4);
+  const int TW = 128 / TH;
+  const int tiles = ((maxW + TW - 1) / TW) * ((maxH + TH - 1) / TH);
+  int NT = Npad16 >= 256 ? 8 : (Npad16 > 64 ? 4 : (Npad16 > 32 ? 2 : 1));
+  if (Npad16 > 128 && Npad16 < 256) NT = 8;
+  const int BN = 32 * NT;
+  dim3 grid(tiles, n_img, (Npad16 + BN - 1) / BN);
+#define RT_DWPW(KK, NN) \
+  hipLaunchKernelGGL((k_dwpw<KK, NN>), grid, dim3(768), 0, st, x, geom, Cp, Wd, bd, dw_act, dw_has_lab, dw_a, dw_c, Wp, N, Npad16, y, ldy, epi, TH)
+  if (K == 3) { switch (NT) { case 1: RT_DWPW(3, 1); break; case 2: RT_DWPW(3, 2); break; case 4: RT_DWPW(3, 4); break; default: RT_DWPW(3, 8); } }
+  else if (K == 5) { switch (NT) { case 1: RT_DWPW(5, 1); break; case 2: RT_DWPW(5, 2); break; case 4: RT_DWPW(5, 4); break; default: RT_DWPW(5, 8); } }
+  else throw RtError(8, "dwpw: unsupported kernel size");
+#undef RT_DWPW
+}
+
 int g_gemm_variant = 0;  // 0 = production choice; others are forced by the kernel micro-benchmark
 
 void gemm(hipStream_t st, const float* A, int lda, long long M, int K, const float* Wp, int N, int Npad16, float* C,
@@ -627,11 +798,85 @@ __global__ __launch_bounds__(256) void k_dwconv_s1(const float* __restrict__ x, 
   }
 }
 
+// Stride-1, LDS-tiled variant: a block stages the halo tile of a 32-channel slab once in LDS
+// (each input element leaves L2 ~(TH+K-1)(TW+K-1)/(TH*TW) times instead of K*(K+3)/4 times),
+// then every thread produces a 1x4 output strip x 4 channels from LDS.
+// Block = 256 threads = CG channel groups x 8 strips x TH rows, tile TH x 32 pixels.
+template <int K, int CG>
+__global__ __launch_bounds__(256) void k_dwconv_lds(const float* __restrict__ x, const ImgGeom* __restrict__ geom, int Cp,
+                                                    const float* __restrict__ Wd, const float* __restrict__ bias, int act,
+                                                    int has_lab, float lab_a, float lab_c, float* __restrict__ y) {
+  constexpr int TH = 256 / (CG * 8), TW = 32, HH = TH + K - 1, HW = TW + K - 1, PS = CG * 4 + 4;  // padded pixel stride
+  __shared__ __attribute__((aligned(16))) float tile[HH * HW * PS];
+  const ImgGeom g = geom[blockIdx.y];
+  const int tiles_x = (g.W + TW - 1) / TW, tiles_y = (g.H + TH - 1) / TH;
+  if ((int)blockIdx.x >= tiles_x * tiles_y) return;
+  const int ty0 = (blockIdx.x / tiles_x) * TH, tx0 = (blockIdx.x % tiles_x) * TW;
+  const int cbase = blockIdx.z * CG * 4;  // first channel of this slab
+  const int tid = threadIdx.x;
+  for (int idx = tid; idx < HH * HW * CG; idx += 256) {
+    int hp = idx / CG, c4 = idx % CG;
+    int gy = ty0 + hp / HW - K / 2, gx = tx0 + hp % HW - K / 2;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (gy >= 0 && gy < g.H && gx >= 0 && gx < g.W && cbase + c4 * 4 < Cp)
+      v = *reinterpret_cast<const f32x4*>(x + (g.off + (long long)gy * g.W + gx) * Cp + cbase + c4 * 4);
+    *reinterpret_cast<f32x4*>(tile + hp * PS + c4 * 4) = v;
+  }
+  __syncthreads();
+  const int c4 = tid % CG, sx = (tid / CG) % 8, ty = tid / (CG * 8);
+  const int ch = cbase + c4 * 4;
+  if (ch >= Cp) return;
+  const int oy = ty0 + ty, ox0 = tx0 + sx * 4;
+  if (oy >= g.H || ox0 >= g.W) return;
+  const f32x4 b = *reinterpret_cast<const f32x4*>(bias + ch);
+  f32x4 acc[4] = {b, b, b, b};
+#pragma unroll
+  for (int dy = 0; dy < K; dy++) {
+    const float* row = tile + ((ty + dy) * HW + sx * 4) * PS + c4 * 4;
+    f32x4 v[K + 3];
+#pragma unroll
+    for (int j = 0; j < K + 3; j++) v[j] = *reinterpret_cast<const f32x4*>(row + j * PS);
+#pragma unroll
+    for (int dx = 0; dx < K; dx++) {
+      f32x4 w = *reinterpret_cast<const f32x4*>(Wd + (dy * K + dx) * Cp + ch);
+#pragma unroll
+      for (int j = 0; j < 4; j++)
+#pragma unroll
+        for (int e = 0; e < 4; e++) acc[j][e] = fmaf(v[j + dx][e], w[e], acc[j][e]);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    if (ox0 + j >= g.W) break;
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+      float t = act_apply(acc[j][e], act);
+      if (has_lab) t = fmaf(t, lab_a, lab_c);
+      o[e] = t;
+    }
+    *reinterpret_cast<f32x4*>(y + (g.off + (long long)oy * g.W + ox0 + j) * Cp + ch) = o;
+  }
+}
+
+int g_dw_variant = 0;  // 0 = production; 1 = generic; 2 = register strip; 3 = LDS tile
+int g_fuse_dwpw = 0;  // experimental: correct, but producer-latency bound; off by default
+
 void dwconv(hipStream_t st, int K, int sh, int sw, const float* x, const ImgGeom* gin, const ImgGeom* gout, int n_img,
             int maxHo, int maxWo, int Cp, const float* Wd, const float* bias, int act, int has_lab, float lab_a,
             float lab_c, float* y) {
   if (n_img <= 0) return;
-  if (sh == 1 && sw == 1 && (K == 3 || K == 5)) {
+  if (sh == 1 && sw == 1 && (K == 3 || K == 5) && g_dw_variant == 3 && Cp >= 16) {  // measured slower than the register strip (tools/), kept for A/B
+    const bool c8 = Cp >= 32;
+    const int TH = c8 ? 4 : 8, CB = c8 ? 32 : 16;
+    dim3 grid(((maxWo + 31) / 32) * ((maxHo + TH - 1) / TH), n_img, (Cp + CB - 1) / CB);
+#define RT_DWL(KK, CG) hipLaunchKernelGGL((k_dwconv_lds<KK, CG>), grid, dim3(256), 0, st, x, gout, Cp, Wd, bias, act, has_lab, lab_a, lab_c, y)
+    if (K == 3) { if (c8) RT_DWL(3, 8); else RT_DWL(3, 4); }
+    else { if (c8) RT_DWL(5, 8); else RT_DWL(5, 4); }
+#undef RT_DWL
+    return;
+  }
+  if (sh == 1 && sw == 1 && (K == 3 || K == 5) && g_dw_variant != 1) {
     long long total = (long long)maxHo * ((maxWo + 3) / 4) * (Cp / 4);
     dim3 grid((unsigned)((total + 255) / 256), n_img);
     if (K == 3)

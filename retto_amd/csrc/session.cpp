@@ -2,13 +2,28 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <numeric>
 #include <sstream>
 
+#include <chrono>
+
 #include "geom_math.h"
 
 using namespace rt;
+
+static const bool g_trace = getenv("RT_TRACE") != nullptr;
+struct HostTick {
+  std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+  void lap(const char* what) {
+    if (!g_trace) return;
+    auto n = std::chrono::steady_clock::now();
+    fprintf(stderr, "[rt host] %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(n - t).count());
+    t = n;
+  }
+};
 
 // ---------------------------------------------------------------------------
 // construction (RettoSession::new, session.rs:62-73; RettoWorker::new, worker.rs:91-98)
@@ -382,8 +397,10 @@ rt_results* rt_session::run_batch(const uint8_t* const* rgb, const int* hs, cons
     det_hw.push_back({p.det_h, p.det_w});
   }
 
+  HostTick tick;
+  tick.lap("pre (resize, upload)");
   // ---- a4: det network in launch groups -------------------------------------------
-  long long group_px = cfg.det_sub_batch > 0 ? 0 : (long long)8 * 960 * 960;
+  long long group_px = cfg.det_sub_batch > 0 ? 0 : (long long)32 * 960 * 960;  // measured: larger launch groups win (launch-bound small layers)
   std::vector<double*> sum_parts; std::vector<int> sum_counts;
   for (int g0 = 0; g0 < n_pages;) {
     int g1 = g0; long long px = 0;
@@ -414,6 +431,7 @@ rt_results* rt_session::run_batch(const uint8_t* const* rgb, const int* hs, cons
     g0 = g1;
   }
 
+  tick.lap("det enqueue");
   // ---- a5: DB post-processing per page (on device; stream-ordered workspace reuse) --
   {
     std::vector<pp::DbPageIn> in((size_t)n_pages);
@@ -441,6 +459,7 @@ rt_results* rt_session::run_batch(const uint8_t* const* rgb, const int* hs, cons
     ProfScope ps(&prof, st, "db_postprocess");
     pp::db_postprocess_batch(st, n_pages, in.data(), db_params(cfg), wsp.data(), mb, bo.data(), co.data(), hd, dd);
   }
+  tick.lap("dbpost enqueue");
   // metadata round trip #1: box lists (a few KB per page); pixels and tensors stay on the device
   int* h_counts = pinned.alloc<int>((size_t)2 * n_pages);
   for (int i = 0; i < n_pages; i++)
@@ -464,6 +483,7 @@ rt_results* rt_session::run_batch(const uint8_t* const* rgb, const int* hs, cons
     for (double v : hp) res->det_checksum += v;
   }
 
+  tick.lap("sync #1 + box D2H");
   // ---- a6: crops --------------------------------------------------------------------
   CropPlan plan;
   for (int i = 0; i < n_pages; i++) {
@@ -490,6 +510,7 @@ rt_results* rt_session::run_batch(const uint8_t* const* rgb, const int* hs, cons
     { ProfScope ps(&prof, st, "warp_crops");
       pp::warp_crops(st, d_desc, NL, plan.max_pix, pool); }
 
+    tick.lap("crop plan + warp enqueue");
     // ---- a8 + a9: angle classifier over every crop -------------------------------
     // (cls_processor.rs:127-172: batches of 6 sorted by aspect; the classifier is
     //  per-crop independent, so batch composition does not change any value)
@@ -525,6 +546,7 @@ rt_results* rt_session::run_batch(const uint8_t* const* rgb, const int* hs, cons
       }
     }
 
+    tick.lap("cls enqueue");
     // ---- a10 + a11 + a12: recognition ----------------------------------------------
     // per page: order by h/w descending (stable), chunks of batch_num, running max_wh_ratio
     const int rh = cfg.rec_image_shape[1], rw = cfg.rec_image_shape[2];
@@ -565,7 +587,7 @@ rt_results* rt_session::run_batch(const uint8_t* const* rgb, const int* hs, cons
     float* d_prob = arena.alloc<float>(std::max<long long>(total_tok, 1));
     int* d_tok = arena.alloc<int>(std::max<long long>(total_tok, 1));
     int* d_ntok = arena.alloc<int>(NL); float* d_rscore = arena.alloc<float>(NL);
-    const long long REC_GROUP_PX = (long long)48 * 320 * 768;
+    static const long long REC_GROUP_PX = getenv("RT_REC_GROUP_PX") ? atoll(getenv("RT_REC_GROUP_PX")) : (long long)24000000;  // measured sweet spot (profiles/README.md)
     for (int l0 = 0; l0 < NL;) {
       int l1 = l0; long long px = 0;
       while (l1 < NL) { long long add = (long long)rh * line_W[l1]; if (l1 > l0 && px + add > REC_GROUP_PX) break; px += add; l1++; }
@@ -596,6 +618,7 @@ rt_results* rt_session::run_batch(const uint8_t* const* rgb, const int* hs, cons
         pp::ctc_decode(st, d_idx + tok_off[l0], d_prob + tok_off[l0], Lt.d, ln, d_tok + tok_off[l0], d_ntok + l0, d_rscore + l0); }
       l0 = l1;
     }
+    tick.lap("rec enqueue");
     // metadata round trip #2: labels, scores, token ids
     h_tokens.resize((size_t)std::max<long long>(total_tok, 1));
     RT_HIP_CHECK(hipMemcpyAsync(h_label.data(), d_label, (size_t)NL * 4, hipMemcpyDeviceToHost, st));
@@ -606,6 +629,7 @@ rt_results* rt_session::run_batch(const uint8_t* const* rgb, const int* hs, cons
     sync(); check_flags();
   }
 
+  tick.lap("sync #2 + D2H");
   // ---- results (session.rs:94-105) ---------------------------------------------------
   static const uint16_t LABELS[2] = {0, 180};
   for (int i = 0; i < n_pages; i++) {
@@ -628,6 +652,7 @@ rt_results* rt_session::run_batch(const uint8_t* const* rgb, const int* hs, cons
       P.text[k] = t;
     }
   }
+  tick.lap("results");
   return res.release();
 }
 
