@@ -528,6 +528,118 @@ void dwpw(hipStream_t st, int K, const float* x, const ImgGeom* geom, int n_img,
 #undef RT_DWPW
 }
 
+// ---------------------------------------------------------------------------
+// LDS-DMA GEMM: both operands go HBM/L2 -> LDS with global_load_lds (no VGPR staging, no
+// ds_write pass), NBUF-deep ring of 32-deep K slabs so two slabs stay in flight behind the
+// MFMAs, one raw s_barrier per slab with a counted vmcnt.  LDS rows are unpadded 128 B
+// (the DMA writes lane-linear), bank conflicts are kept 2-way by an XOR swizzle applied to the
+// per-lane SOURCE address and again on the fragment reads.
+// Block: 128 rows x 256 cols, 8 waves as 4 x 2, each 32 x 128 (MT=2, NT=8).
+// ---------------------------------------------------------------------------
+#define RT_GLDS(gp, lp) \
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gp), \
+                                   (__attribute__((address_space(3))) void*)(lp), 16, 0, 0)
+template <int NBUF>
+__global__ __launch_bounds__(512) void k_gemm_dma(const float* __restrict__ A, int lda, long long M, int K,
+                                                  const float* __restrict__ Wp, int N, int Npad, float* __restrict__ C,
+                                                  int ldc, int coff, Epilogue epi, const float* __restrict__ zeros) {
+  constexpr int BM = 128, BN = 256, NT = 8, SLAB = (BM + BN) * KC;  // floats per ring slot
+  __shared__ __attribute__((aligned(16))) float lds[NBUF * SLAB];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, q = lane >> 4;
+  const int wm = wave >> 1, wn = wave & 1;
+  const long long m0 = (long long)blockIdx.x * BM;
+  const int n0 = blockIdx.y * BN;
+  const int nkc = (K + KC - 1) / KC;
+  const int lrow = lane >> 3, pslot = lane & 7;
+  auto issue = [&](int kc, int buf) {
+    float* base = lds + buf * SLAB;
+#pragma unroll
+    for (int i = 0; i < 2; i++) {  // activations: 16 groups of 8 rows, 2 per wave
+      const int rg = wave * 2 + i, row = rg * 8 + lrow;
+      const int k = kc * KC + ((pslot ^ (row & 7)) << 2);
+      const long long m = m0 + row;
+      const float* src = (m < M && k < K) ? A + m * lda + k : zeros;
+      RT_GLDS(src, base + rg * 8 * KC);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++) {  // weights: 32 groups of 8 rows, 4 per wave
+      const int rg = wave * 4 + i, row = rg * 8 + lrow;
+      const int n = n0 + row;
+      const float* src = n < Npad ? Wp + ((long long)kc * Npad + n) * KC + ((pslot ^ (row & 7)) << 2) : zeros;
+      RT_GLDS(src, base + BM * KC + rg * 8 * KC);
+    }
+  };
+  f32x4 acc[2][NT];
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int j = 0; j < NT; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  issue(0, 0);
+  if (nkc > 1) issue(1, 1);
+  for (int kc = 0; kc < nkc; kc++) {
+    // slab kc has landed once at most the 6 DMAs of slab kc+1 are still outstanding
+    if (kc + 1 < nkc) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (kc + 2 < nkc) issue(kc + 2, (kc + 2) % NBUF);
+    const float* xb = lds + (kc % NBUF) * SLAB;
+    const float* wb = xb + BM * KC;
+#pragma unroll
+    for (int gi = 0; gi < KC / 16; gi++) {
+      f32x4 a[2], b[NT];
+#pragma unroll
+      for (int mt = 0; mt < 2; mt++) {
+        const int row = wm * 32 + mt * 16 + r;
+        a[mt] = *reinterpret_cast<const f32x4*>(xb + row * KC + (((gi * 4 + q) ^ (row & 7)) << 2));
+      }
+#pragma unroll
+      for (int nt = 0; nt < NT; nt++) {
+        const int row = wn * 128 + nt * 16 + r;
+        b[nt] = *reinterpret_cast<const f32x4*>(wb + row * KC + (((gi * 4 + q) ^ (row & 7)) << 2));
+      }
+#pragma unroll
+      for (int s = 0; s < 4; s++)
+#pragma unroll
+        for (int nt = 0; nt < NT; nt++)
+#pragma unroll
+          for (int mt = 0; mt < 2; mt++)
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[nt][s], a[mt][s], acc[mt][nt], 0, 0, 0);
+    }
+    asm volatile("" ::: "memory");
+  }
+  const int nstore = (N + 3) & ~3;
+#pragma unroll
+  for (int nt = 0; nt < NT; nt++) {
+    int col = n0 + (wn * NT + nt) * 16 + q * 4;
+    if (col >= nstore) continue;
+    f32x4 bias = {0.f, 0.f, 0.f, 0.f};
+    if (epi.bias) bias = *reinterpret_cast<const f32x4*>(epi.bias + col);
+#pragma unroll
+    for (int mt = 0; mt < 2; mt++) {
+      long long m = m0 + wm * 32 + mt * 16 + r;
+      if (m >= M) continue;
+      f32x4 o;
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        float t = act_apply(acc[mt][nt][j] + bias[j], epi.act);
+        if (epi.has_lab) t = fmaf(t, epi.lab_a, epi.lab_c);
+        if (epi.residual) t += epi.residual[m * epi.ld_res + col + j];
+        o[j] = (col + j < N) ? t : 0.0f;
+      }
+      *reinterpret_cast<f32x4*>(C + m * ldc + coff + col) = o;
+    }
+  }
+}
+static const float* zero_page() {
+  static float* z = nullptr;
+  if (!z) {
+    RT_HIP_CHECK(hipMalloc((void**)&z, 4096));
+    RT_HIP_CHECK(hipMemset(z, 0, 4096));
+  }
+  return z;
+}
+
 int g_gemm_variant = 0;  // 0 = production choice; others are forced by the kernel micro-benchmark
 
 void gemm(hipStream_t st, const float* A, int lda, long long M, int K, const float* Wp, int N, int Npad16, float* C,
@@ -537,6 +649,11 @@ void gemm(hipStream_t st, const float* A, int lda, long long M, int K, const flo
   if (v == 0) {  // production dispatch (tools/bench_gemm.py): wide tiles once N and M are large
     if (Npad16 % 240 == 0 && M >= 16384) v = 10;
     else if (Npad16 >= 192 && M >= 8192) v = 8;
+  }
+  if (v == 12) {
+    dim3 grid((unsigned)((M + 127) / 128), (unsigned)((Npad16 + 255) / 256));
+    hipLaunchKernelGGL((k_gemm_dma<3>), grid, dim3(512), 0, st, A, lda, M, K, Wp, N, Npad16, C, ldc, coff, epi, zero_page());
+    return;
   }
   if (v == 4) {
     dim3 grid((unsigned)((M + 127) / 128), (unsigned)((Npad16 + 127) / 128));
@@ -859,13 +976,99 @@ __global__ __launch_bounds__(256) void k_dwconv_lds(const float* __restrict__ x,
   }
 }
 
-int g_dw_variant = 0;  // 0 = production; 1 = generic; 2 = register strip; 3 = LDS tile
+// Stride-1, row-streaming variant: a thread owns an R-row x 4-pixel output patch of 4 channels
+// and streams the R+K-1 input rows through registers once: (R+K-1)*(K+3) 16-byte loads per 4R
+// outputs (K=5, R=4: 4 per output instead of 10), and the KxK weights of the block's 32-channel
+// slab sit in LDS (3.2 KB) instead of being re-fetched per thread.  Accumulation order per
+// output is still bias, then taps in (dy, dx) order.
+template <int K, int R>
+__global__ __launch_bounds__(256) void k_dwconv_rows(const float* __restrict__ x, const ImgGeom* __restrict__ geom, int Cp,
+                                                     const float* __restrict__ Wd, const float* __restrict__ bias, int act,
+                                                     int has_lab, float lab_a, float lab_c, float* __restrict__ y) {
+  __shared__ __attribute__((aligned(16))) float wl[K * K * 32];
+  const ImgGeom g = geom[blockIdx.y];
+  const int strips_x = (g.W + 3) >> 2, strips_y = (g.H + R - 1) / R;
+  if ((long long)blockIdx.x * 32 >= (long long)strips_x * strips_y) return;
+  const int cbase = blockIdx.z * 32;
+  const int tid = threadIdx.x;
+  if (tid < K * K * 8) {
+    int t = tid >> 3, cc = tid & 7;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (cbase + cc * 4 < Cp) v = *reinterpret_cast<const f32x4*>(Wd + t * Cp + cbase + cc * 4);
+    *reinterpret_cast<f32x4*>(wl + tid * 4) = v;
+  }
+  __syncthreads();
+  const int c4 = tid & 7, ch = cbase + c4 * 4;
+  const long long strip = (long long)blockIdx.x * 32 + (tid >> 3);
+  if (ch >= Cp || strip >= (long long)strips_x * strips_y) return;
+  const int oy0 = (int)(strip / strips_x) * R, ox0 = (int)(strip % strips_x) * 4;
+  const f32x4 b = *reinterpret_cast<const f32x4*>(bias + ch);
+  f32x4 acc[R][4];
+#pragma unroll
+  for (int r = 0; r < R; r++)
+#pragma unroll
+    for (int j = 0; j < 4; j++) acc[r][j] = b;
+#pragma unroll
+  for (int i = 0; i < R + K - 1; i++) {
+    const int iy = oy0 + i - K / 2;
+    if (iy < 0 || iy >= g.H) continue;
+    const float* row = x + (g.off + (long long)iy * g.W) * Cp + ch;
+    f32x4 v[K + 3];
+#pragma unroll
+    for (int j = 0; j < K + 3; j++) {
+      int ix = ox0 + j - K / 2;
+      v[j] = (ix >= 0 && ix < g.W) ? *reinterpret_cast<const f32x4*>(row + (long long)ix * Cp) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+      const int dy = i - r;  // input row i feeds output row r through tap row dy
+      if (dy < 0 || dy >= K) continue;
+#pragma unroll
+      for (int dx = 0; dx < K; dx++) {
+        const f32x4 w = *reinterpret_cast<const f32x4*>(wl + ((dy * K + dx) * 8 + c4) * 4);
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+#pragma unroll
+          for (int e = 0; e < 4; e++) acc[r][j][e] = fmaf(v[j + dx][e], w[e], acc[r][j][e]);
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < R; r++) {
+    const int oy = oy0 + r;
+    if (oy >= g.H) break;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      if (ox0 + j >= g.W) break;
+      f32x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        float t = act_apply(acc[r][j][e], act);
+        if (has_lab) t = fmaf(t, lab_a, lab_c);
+        o[e] = t;
+      }
+      *reinterpret_cast<f32x4*>(y + (g.off + (long long)oy * g.W + ox0 + j) * Cp + ch) = o;
+    }
+  }
+}
+
+int g_dw_variant = 0;  // 0 = production; 1 = generic; 2 = register strip; 3 = LDS tile; 4 = row streaming
 int g_fuse_dwpw = 0;  // experimental: correct, but producer-latency bound; off by default
 
 void dwconv(hipStream_t st, int K, int sh, int sw, const float* x, const ImgGeom* gin, const ImgGeom* gout, int n_img,
             int maxHo, int maxWo, int Cp, const float* Wd, const float* bias, int act, int has_lab, float lab_a,
             float lab_c, float* y) {
   if (n_img <= 0) return;
+  if (sh == 1 && sw == 1 && (K == 3 || K == 5) && (g_dw_variant == 0 || g_dw_variant == 4)) {
+    constexpr int R = 4;
+    long long strips = (long long)((maxWo + 3) / 4) * ((maxHo + R - 1) / R);
+    dim3 grid((unsigned)((strips + 31) / 32), n_img, (Cp + 31) / 32);
+    if (K == 3)
+      hipLaunchKernelGGL((k_dwconv_rows<3, R>), grid, dim3(256), 0, st, x, gout, Cp, Wd, bias, act, has_lab, lab_a, lab_c, y);
+    else
+      hipLaunchKernelGGL((k_dwconv_rows<5, R>), grid, dim3(256), 0, st, x, gout, Cp, Wd, bias, act, has_lab, lab_a, lab_c, y);
+    return;
+  }
   if (sh == 1 && sw == 1 && (K == 3 || K == 5) && g_dw_variant == 3 && Cp >= 16) {  // measured slower than the register strip (tools/), kept for A/B
     const bool c8 = Cp >= 32;
     const int TH = c8 ? 4 : 8, CB = c8 ? 32 : 16;
