@@ -12,14 +12,15 @@ namespace nn {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// `act` is uniform per launch.  Every case is a handful of VALU ops: no IEEE division (the
+// x/6 of hardswish is a multiply, swish/sigmoid use v_exp + v_rcp), so the fused epilogues stay
+// cheap next to the MFMA / load work.  Differences to the exact forms are <= 2 ulp.
 __device__ __forceinline__ float act_apply(float v, int act) {
-  switch (act) {
-    case ACT_RELU: return fmaxf(v, 0.0f);
-    case ACT_HSWISH: return v * fminf(fmaxf(v + 3.0f, 0.0f), 6.0f) / 6.0f;
-    case ACT_SWISH: return v / (1.0f + expf(-v));
-    case ACT_SIGMOID: return 1.0f / (1.0f + expf(-v));
-    default: return v;
-  }
+  if (act == ACT_HSWISH) return v * fminf(fmaxf(v + 3.0f, 0.0f), 6.0f) * 0.16666667f;
+  if (act == ACT_RELU) return fmaxf(v, 0.0f);
+  if (act == ACT_NONE) return v;
+  const float s = __builtin_amdgcn_rcpf(1.0f + __expf(-v));
+  return act == ACT_SWISH ? v * s : s;
 }
 
 // ---------------------------------------------------------------------------
@@ -976,18 +977,22 @@ __global__ __launch_bounds__(256) void k_dwconv_lds(const float* __restrict__ x,
   }
 }
 
-// Stride-1, row-streaming variant: a thread owns an R-row x 4-pixel output patch of 4 channels
-// and streams the R+K-1 input rows through registers once: (R+K-1)*(K+3) 16-byte loads per 4R
-// outputs (K=5, R=4: 4 per output instead of 10), and the KxK weights of the block's 32-channel
-// slab sit in LDS (3.2 KB) instead of being re-fetched per thread.  Accumulation order per
-// output is still bias, then taps in (dy, dx) order.
-template <int K, int R>
-__global__ __launch_bounds__(256) void k_dwconv_rows(const float* __restrict__ x, const ImgGeom* __restrict__ geom, int Cp,
+// Row-streaming depthwise conv, strides (SH, SW) in {1,2}: a thread owns an R-row x 4-pixel output
+// patch of 4 channels and streams the (R-1)*SH+K input rows through registers once (K=5, R=4,
+// stride 1: 4 16-byte loads per output instead of 25), with the KxK weights of the block's
+// 32-channel slab in LDS (3.2 KB).  Strips are numbered column-major so that the vertically
+// adjacent strips (which share K-SH halo rows) sit in the same workgroup and meet in L1/L2
+// instead of re-reading HBM.  Accumulation order per output: bias, then taps in (dy, dx) order.
+template <int K, int R, int SH, int SW>
+__global__ __launch_bounds__(256) void k_dwconv_rows(const float* __restrict__ x, const ImgGeom* __restrict__ gin,
+                                                     const ImgGeom* __restrict__ gout, int Cp,
                                                      const float* __restrict__ Wd, const float* __restrict__ bias, int act,
                                                      int has_lab, float lab_a, float lab_c, float* __restrict__ y) {
+  constexpr int NV = 3 * SW + K;       // input columns feeding 4 output pixels
+  constexpr int NI = (R - 1) * SH + K; // input rows feeding R output rows
   __shared__ __attribute__((aligned(16))) float wl[K * K * 32];
-  const ImgGeom g = geom[blockIdx.y];
-  const int strips_x = (g.W + 3) >> 2, strips_y = (g.H + R - 1) / R;
+  const ImgGeom gi = gin[blockIdx.y], go = gout[blockIdx.y];
+  const int strips_x = (go.W + 3) >> 2, strips_y = (go.H + R - 1) / R;
   if ((long long)blockIdx.x * 32 >= (long long)strips_x * strips_y) return;
   const int cbase = blockIdx.z * 32;
   const int tid = threadIdx.x;
@@ -1001,27 +1006,29 @@ __global__ __launch_bounds__(256) void k_dwconv_rows(const float* __restrict__ x
   const int c4 = tid & 7, ch = cbase + c4 * 4;
   const long long strip = (long long)blockIdx.x * 32 + (tid >> 3);
   if (ch >= Cp || strip >= (long long)strips_x * strips_y) return;
-  const int oy0 = (int)(strip / strips_x) * R, ox0 = (int)(strip % strips_x) * 4;
+  const int oy0 = (int)(strip % strips_y) * R, ox0 = (int)(strip / strips_y) * 4;  // column-major
   const f32x4 b = *reinterpret_cast<const f32x4*>(bias + ch);
   f32x4 acc[R][4];
 #pragma unroll
   for (int r = 0; r < R; r++)
 #pragma unroll
     for (int j = 0; j < 4; j++) acc[r][j] = b;
+  // (A branch-free form of this loop lets hipcc hoist every load: 256 VGPRs or spills, 2-10x
+  // slower.  The per-row branches keep one input row in flight per wave.)
 #pragma unroll
-  for (int i = 0; i < R + K - 1; i++) {
-    const int iy = oy0 + i - K / 2;
-    if (iy < 0 || iy >= g.H) continue;
-    const float* row = x + (g.off + (long long)iy * g.W) * Cp + ch;
-    f32x4 v[K + 3];
+  for (int i = 0; i < NI; i++) {
+    const int iy = oy0 * SH + i - K / 2;
+    if (iy < 0 || iy >= gi.H) continue;
+    const float* row = x + (gi.off + (long long)iy * gi.W) * Cp + ch;
+    f32x4 v[NV];
 #pragma unroll
-    for (int j = 0; j < K + 3; j++) {
-      int ix = ox0 + j - K / 2;
-      v[j] = (ix >= 0 && ix < g.W) ? *reinterpret_cast<const f32x4*>(row + (long long)ix * Cp) : f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < NV; j++) {
+      int ix = ox0 * SW + j - K / 2;
+      v[j] = (ix >= 0 && ix < gi.W) ? *reinterpret_cast<const f32x4*>(row + (long long)ix * Cp) : f32x4{0.f, 0.f, 0.f, 0.f};
     }
 #pragma unroll
     for (int r = 0; r < R; r++) {
-      const int dy = i - r;  // input row i feeds output row r through tap row dy
+      const int dy = i - r * SH;  // input row i feeds output row r through tap row dy
       if (dy < 0 || dy >= K) continue;
 #pragma unroll
       for (int dx = 0; dx < K; dx++) {
@@ -1029,17 +1036,17 @@ __global__ __launch_bounds__(256) void k_dwconv_rows(const float* __restrict__ x
 #pragma unroll
         for (int j = 0; j < 4; j++)
 #pragma unroll
-          for (int e = 0; e < 4; e++) acc[r][j][e] = fmaf(v[j + dx][e], w[e], acc[r][j][e]);
+          for (int e = 0; e < 4; e++) acc[r][j][e] = fmaf(v[j * SW + dx][e], w[e], acc[r][j][e]);
       }
     }
   }
 #pragma unroll
   for (int r = 0; r < R; r++) {
     const int oy = oy0 + r;
-    if (oy >= g.H) break;
+    if (oy >= go.H) break;
 #pragma unroll
     for (int j = 0; j < 4; j++) {
-      if (ox0 + j >= g.W) break;
+      if (ox0 + j >= go.W) break;
       f32x4 o;
 #pragma unroll
       for (int e = 0; e < 4; e++) {
@@ -1047,7 +1054,7 @@ __global__ __launch_bounds__(256) void k_dwconv_rows(const float* __restrict__ x
         if (has_lab) t = fmaf(t, lab_a, lab_c);
         o[e] = t;
       }
-      *reinterpret_cast<f32x4*>(y + (g.off + (long long)oy * g.W + ox0 + j) * Cp + ch) = o;
+      *reinterpret_cast<f32x4*>(y + (go.off + (long long)oy * go.W + ox0 + j) * Cp + ch) = o;
     }
   }
 }
@@ -1059,14 +1066,20 @@ void dwconv(hipStream_t st, int K, int sh, int sw, const float* x, const ImgGeom
             int maxHo, int maxWo, int Cp, const float* Wd, const float* bias, int act, int has_lab, float lab_a,
             float lab_c, float* y) {
   if (n_img <= 0) return;
-  if (sh == 1 && sw == 1 && (K == 3 || K == 5) && (g_dw_variant == 0 || g_dw_variant == 4)) {
-    constexpr int R = 4;
+  if ((K == 3 || K == 5) && sh >= 1 && sh <= 2 && sw >= 1 && sw <= 2 && (g_dw_variant == 0 || g_dw_variant == 4)) {
+    const int R = sh == 1 ? 4 : 2;  // input rows streamed: stride 1 -> R+K-1, stride 2 -> 2R+K-2
     long long strips = (long long)((maxWo + 3) / 4) * ((maxHo + R - 1) / R);
     dim3 grid((unsigned)((strips + 31) / 32), n_img, (Cp + 31) / 32);
-    if (K == 3)
-      hipLaunchKernelGGL((k_dwconv_rows<3, R>), grid, dim3(256), 0, st, x, gout, Cp, Wd, bias, act, has_lab, lab_a, lab_c, y);
-    else
-      hipLaunchKernelGGL((k_dwconv_rows<5, R>), grid, dim3(256), 0, st, x, gout, Cp, Wd, bias, act, has_lab, lab_a, lab_c, y);
+#define RT_DWR(KK, RR, SH_, SW_) \
+  hipLaunchKernelGGL((k_dwconv_rows<KK, RR, SH_, SW_>), grid, dim3(256), 0, st, x, gin, gout, Cp, Wd, bias, act, has_lab, lab_a, lab_c, y)
+    const int code = (K == 5 ? 4 : 0) + (sh == 2 ? 2 : 0) + (sw == 2 ? 1 : 0);
+    switch (code) {
+      case 0: RT_DWR(3, 4, 1, 1); break; case 1: RT_DWR(3, 4, 1, 2); break;
+      case 2: RT_DWR(3, 2, 2, 1); break; case 3: RT_DWR(3, 2, 2, 2); break;
+      case 4: RT_DWR(5, 4, 1, 1); break; case 5: RT_DWR(5, 4, 1, 2); break;
+      case 6: RT_DWR(5, 2, 2, 1); break; default: RT_DWR(5, 2, 2, 2); break;
+    }
+#undef RT_DWR
     return;
   }
   if (sh == 1 && sw == 1 && (K == 3 || K == 5) && g_dw_variant == 3 && Cp >= 16) {  // measured slower than the register strip (tools/), kept for A/B

@@ -238,3 +238,75 @@ def test_pipeline_cls_rotation(models, oracle_session):
             assert np.array_equal(g.tokens, ot)
     finally:
         s.close()
+
+
+def _planted_for(page_h, page_w, lines, seed):
+    """page + planted map at the det-input size the pipeline will derive for it."""
+    page, rects = workload.planted_page(page_h, page_w, lines, seed)
+    plan = R.resize_both_plan(page_h, page_w)
+    ah, aw = plan[-1] if plan else (page_h, page_w)
+    dh, dw = R.resize_either_dims(ah, aw)
+    return page, workload.planted_map(dh, dw, page_h, page_w, rects)
+
+
+def _teacher_forced(oracle_session, hip_session):
+    oracle_session.det_worker = hip_session.worker.det
+    oracle_session.cls_worker = hip_session.worker.cls
+    oracle_session.rec_worker = hip_session.worker.rec
+
+
+def _assert_page_equal(r, o):
+    assert len(r.det_result) == len(o.det_boxes)
+    if len(o.det_boxes):
+        gb = np.stack([d.boxes.as_array() for d in r.det_result])
+        assert np.array_equal(gb, o.det_boxes)
+    assert [c.label.label for c in r.cls_result] == list(o.cls_labels)
+    for g, ot in zip(r.rec_result, o.rec_tokens):
+        assert np.array_equal(g.tokens, ot)
+
+
+def test_pipeline_mixed_sizes_c4(hip_session, oracle_session):
+    """BASELINE config C4 flavour: mixed page sizes in one batch, including the 640 -> 736 upscaling
+    det resize (C1), a page above max_side_len (resize_both path) and non-square pages."""
+    specs = [(640, 640, 6, 41), (720, 1280, 5, 42), (2100, 1500, 7, 43), (416, 608, 3, 44)]
+    pages, maps = zip(*[_planted_for(h, w, L, s) for h, w, L, s in specs])
+    res = hip_session.run_batch(list(pages), det_map_override=list(maps))
+    _teacher_forced(oracle_session, hip_session)
+    for page, m, r in zip(pages, maps, res):
+        o = oracle_session.run(page, det_map_override=m)
+        assert len(o.det_boxes) > 0
+        _assert_page_equal(r, o)
+    # batch invariance: a page processed alone gives the same result as inside the batch
+    alone = hip_session.run_batch([pages[1]], det_map_override=[maps[1]])[0]
+    assert [g.text for g in alone.rec_result] == [g.text for g in res[1].rec_result]
+    assert np.array_equal(np.stack([d.boxes.as_array() for d in alone.det_result]),
+                          np.stack([d.boxes.as_array() for d in res[1].det_result]))
+
+
+def test_pipeline_empty_and_border_pages(hip_session, oracle_session):
+    blank = np.zeros((320, 320, 3), np.uint8)
+    m_blank = np.full((736, 736), 0.01, np.float32)
+    page, _ = workload.planted_page(320, 480, 3, 7)
+    dh, dw = R.resize_either_dims(320, 480)
+    # text regions touching the page border: crops sample outside the image (white fill)
+    m_border = workload.planted_map(dh, dw, 320, 480, [(0, 0, 200, 30), (300, 290, 480, 320), (100, 150, 380, 180)], shrink=0.0)
+    res = hip_session.run_batch([blank, page], det_map_override=[m_blank, m_border])
+    assert res[0].det_result == [] and res[0].cls_result == [] and res[0].rec_result == []
+    _teacher_forced(oracle_session, hip_session)
+    o = oracle_session.run(page, det_map_override=m_border)
+    assert len(o.det_boxes) == 3
+    _assert_page_equal(res[1], o)
+
+
+def test_reference_small_image_scenario(hip_session):
+    """session.rs:206-229 restated: 200x50 page, text blob in the bottom-right (the render rotated by
+    180 degrees); the first box's bottom-right corner lies within 10 px of (200, 50)."""
+    page = np.zeros((50, 200, 3), np.uint8)
+    page[28:48, 100:197] = 255
+    pred = np.full((736, 2944), 0.02, np.float32)
+    pred[int(0.55 * 736):int(0.97 * 736), int(0.5 * 2944):int(0.985 * 2944)] = 0.9
+    r = hip_session.run_batch([page], det_map_override=[pred])[0]
+    assert len(r.det_result) == 1
+    br = r.det_result[0].boxes.br()
+    assert np.hypot(br.x - 200, br.y - 50) < 10
+    assert r.cls_result[0].label.label in (0, 180)
