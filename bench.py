@@ -39,6 +39,7 @@ def parse():
     ap.add_argument("--lines", type=int, default=32, help="planted text lines per page")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--det-sub-batch", type=int, default=0)
+    ap.add_argument("--variants", type=str, default="", help="debug: gemm,dw,fuse kernel variants")
     ap.add_argument("--cpu-pages", type=int, default=1, help="pages of the same workload timed on the CPU oracle")
     ap.add_argument("--profile-all", action="store_true", help="print the per-family table to stderr")
     return ap.parse_args()
@@ -82,6 +83,8 @@ def main():
     cfg.rec_processor_config.character_source = retto_amd.RettoWorkerModelSource.Blob(dict_b)
     sess = retto_amd.RettoSession(cfg)
     lib, h = sess._hd.lib, sess._hd.h
+    if a.variants:
+        lib.rt_debug_set_variants(*[int(v) for v in a.variants.split(',')])
 
     # ---- synthetic pages + planted maps, staged to HBM once -------------------------------
     import ctypes as C

@@ -390,6 +390,11 @@ __device__ float box_score_fast(const float* pred, int H, int W, const int* box)
   int py_min = 0x7fffffff, py_max = -0x7fffffff - 1;
   for (int i = 0; i < 4; i++) { py_min = min(py_min, poly[i].y); py_max = max(py_max, poly[i].y); }
   py_min = max(0, min(py_min, bh - 1)); py_max = max(0, min(py_max, bh - 1));
+  // One wavefront per contour: every lane runs the (wave-uniform) geometry redundantly; here
+  // the 64 lanes fetch and mask-test 64 consecutive pixels of a row at once, and the masked
+  // values are then folded into `sum` one lane at a time in pixel order, which reproduces the
+  // reference's sequential f32 accumulation bit for bit.
+  const int lane = threadIdx.x & 63;
   float sum = 0.0f; unsigned long long count = 0;
   RowCover rc;
   for (int y = 0; y < bh; y++) {
@@ -398,10 +403,19 @@ __device__ float box_score_fast(const float* pred, int H, int W, const int* box)
     int lo = rc.lo[0], hi = rc.hi[0];
     for (int k = 1; k < rc.n; k++) { lo = min(lo, rc.lo[k]); hi = max(hi, rc.hi[k]); }
     const float* prow = pred + (size_t)(y + y_min) * W + x_min;
-    for (int x = lo; x <= hi; x++) {
+    for (int x0 = lo; x0 <= hi; x0 += 64) {
+      const int x = x0 + lane;
       bool in = false;
-      for (int k = 0; k < rc.n; k++) in = in || (x >= rc.lo[k] && x <= rc.hi[k]);
-      if (in) { sum = sum + prow[x]; count++; }
+      if (x <= hi)
+        for (int k = 0; k < rc.n; k++) in = in || (x >= rc.lo[k] && x <= rc.hi[k]);
+      const float v = in ? prow[x] : 0.0f;
+      unsigned long long m = __ballot(in);
+      count += (unsigned long long)__popcll(m);
+      while (m) {
+        const int l = __ffsll((long long)m) - 1;
+        sum = sum + __shfl(v, l);
+        m &= m - 1;
+      }
     }
   }
   return count > 0 ? sum / (float)count : 0.0f;
@@ -556,18 +570,18 @@ __device__ __forceinline__ float euclid_f32(float ax, float ay, float bx, float 
 }
 
 
+#define RT_CONTOUR_WAVES 128
 __global__ __launch_bounds__(64) void k_contour_boxes(const DbPage* __restrict__ pages, DbParams prm) {
   const DbPage pg = pages[blockIdx.y];
   const DbWs& ws = pg.ws;
   const int H = pg.H, W = pg.W;
   const float* pred = pg.pred;
-  int ci = blockIdx.x * 64 + threadIdx.x;
-  int ncont = min(ws.counters[0], ws.contour_cap);
-  if (ci >= ncont) return;
+  const int ncont = min(ws.counters[0], ws.contour_cap);
+  for (int ci = blockIdx.x; ci < ncont; ci += RT_CONTOUR_WAVES) {
   const Contour ct = ws.contours[ci];
   int2* hs = ws.hull + ct.hbase;
   int hn = hull_from_rows(ws.rowmin + ct.base, ws.rowmax + ct.base, ct.rows, ct.ymin, hs);
-  if (hn == 0) return;
+  if (hn == 0) continue;
   double r[8];
   min_area_rect_hull(hn, [&](int i) { return DP{(double)hs[i].x, (double)hs[i].y}; }, r);
   int box[8];
@@ -575,15 +589,15 @@ __global__ __launch_bounds__(64) void k_contour_boxes(const DbPage* __restrict__
   float s1 = euclid_f32((float)box[0], (float)box[1], (float)box[2], (float)box[3]);
   float s2 = euclid_f32((float)box[6], (float)box[7], (float)box[4], (float)box[5]);
   float sside = fminf(s1, s2);
-  if (sside < (float)prm.min_size) return;
+  if (sside < (float)prm.min_size) continue;
   float mean_score = box_score_fast(pred, H, W, box);
-  if (mean_score < prm.box_thresh) return;
+  if (mean_score < prm.box_thresh) continue;
   float ox[RT_MAX_OFFSET_PTS], oy[RT_MAX_OFFSET_PTS];
   short hidx[RT_MAX_OFFSET_PTS];
   int ovf = 0;
   int on = unclip_box(box, prm.unclip_ratio, ox, oy, &ovf);
-  if (ovf) { ws.counters[4] = 1; return; }
-  if (on == 0) return;
+  if (ovf) { ws.counters[4] = 1; continue; }
+  if (on == 0) continue;
   int h2 = hull_jarvis(ox, oy, on, hidx);
   double r2[8];
   min_area_rect_hull(h2, [&](int i) { return DP{(double)ox[hidx[i]], (double)oy[hidx[i]]}; }, r2);
@@ -591,16 +605,19 @@ __global__ __launch_bounds__(64) void k_contour_boxes(const DbPage* __restrict__
   for (int i = 0; i < 8; i++) b.pts[i] = (float)r2[i];
   float t1 = euclid_f32(b.pts[0], b.pts[1], b.pts[2], b.pts[3]);
   float t2 = euclid_f32(b.pts[6], b.pts[7], b.pts[4], b.pts[5]);
-  if (fminf(t1, t2) < (float)(prm.min_size + 2)) return;
+  if (fminf(t1, t2) < (float)(prm.min_size + 2)) continue;
   gm::scale_and_clip(b.pts, (double)W, (double)H, (double)pg.ori_w, (double)pg.ori_h);
   float pb_h = gm::side_len(&b.pts[0], &b.pts[6]);
   float pb_w = gm::side_len(&b.pts[0], &b.pts[2]);
-  if (pb_h <= 3.0f || pb_w <= 3.0f) return;
+  if (pb_h <= 3.0f || pb_w <= 3.0f) continue;
   b.score = mean_score;
   b.key = ct.type == 0 ? ct.root : ct.root - 1;
-  int slot = atomicAdd(&ws.counters[3], 1);
-  if (slot >= ws.cand_cap) { ws.counters[4] = 1; return; }
-  ws.cand[slot] = b;
+  if ((threadIdx.x & 63) == 0) {
+    int slot = atomicAdd(&ws.counters[3], 1);
+    if (slot >= ws.cand_cap) ws.counters[4] = 1;
+    else ws.cand[slot] = b;
+  }
+  }
 }
 
 // det_processor.rs:324-333.  Stable bottom-up merge sort (run width 1, 2, 4, ...; take
@@ -673,7 +690,8 @@ void db_postprocess_batch(hipStream_t st, int n, const DbPageIn* in, const DbPar
   hipLaunchKernelGGL(k_ccl_stats, grid, blk, 0, st, dp);
   hipLaunchKernelGGL(k_contour_alloc, grid, blk, 0, st, dp);
   hipLaunchKernelGGL(k_row_extents, grid, blk, 0, st, dp);
-  hipLaunchKernelGGL(k_contour_boxes, dim3((maxC + 63) / 64, n), dim3(64), 0, st, dp, p);
+  (void)maxC;
+  hipLaunchKernelGGL(k_contour_boxes, dim3(RT_CONTOUR_WAVES, n), dim3(64), 0, st, dp, p);
   hipLaunchKernelGGL(k_sort_boxes, dim3(n), dim3(256), 0, st, dp);
 }
 

@@ -225,7 +225,8 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm_wide(const float* __restr
       for (int nt = 0; nt < NT; nt++) b[g][nt] = *reinterpret_cast<const f32x4*>(wr + nt * 16 * LROW + g * 16 + 4 * q);
     }
 #pragma unroll
-    for (int g = 0; g < KC / 16; g++)
+    for (int g = 0; g < KC / 16; g++) {
+      if (g > 0 && kc * KC + g * 16 >= K) break;  // K tail (e.g. K = 240): the second 16-deep group of the last slab is all zero
 #pragma unroll
       for (int s = 0; s < 4; s++)
 #pragma unroll
@@ -233,6 +234,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm_wide(const float* __restr
 #pragma unroll
           for (int mt = 0; mt < MT; mt++)
             acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[g][nt][s], a[g][mt][s], acc[mt][nt], 0, 0, 0);
+    }
     if (DBG != 2) __syncthreads();
     if (DBG == 0 && kc + 1 < nkc) { stash(); __syncthreads(); }
     if (DBG == 1) __syncthreads();
@@ -530,6 +532,123 @@ void dwpw(hipStream_t st, int K, const float* x, const ImgGeom* geom, int n_img,
 }
 
 // ---------------------------------------------------------------------------
+// Persistent wide GEMM: same tile as k_gemm_wide, but a workgroup walks over several output
+// tiles and the register prefetch runs ACROSS tiles (the first K slab of the next tile is
+// fetched under the last MFMAs of the current one), so the load latency at the start of a
+// tile - a third of a tile's time at K = 240 - is paid once per workgroup instead of per tile.
+// Tiles are numbered row-block major with the column blocks of a row adjacent (shared A rows).
+// ---------------------------------------------------------------------------
+template <int MT, int NT, int WM, int WN>
+__global__ __launch_bounds__(64 * WM * WN) void k_gemm_persist(const float* __restrict__ A, int lda, long long M, int K,
+                                                                const float* __restrict__ Wp, int N, int Npad,
+                                                                float* __restrict__ C, int ldc, int coff, Epilogue epi) {
+  constexpr int NTHR = 64 * WM * WN, BM = 16 * MT * WM, BN = 16 * NT * WN;
+  constexpr int A_LD = (BM * 8 + NTHR - 1) / NTHR, W_LD = (BN * 8 + NTHR - 1) / NTHR;
+  __shared__ __attribute__((aligned(16))) float lds[(BM + BN) * LROW];
+  float* xs = lds;
+  float* ws = lds + BM * LROW;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, q = lane >> 4;
+  const int wm = wave / WN, wn = wave % WN;
+  const int ncol = (Npad + BN - 1) / BN;
+  const long long ntiles = ((M + BM - 1) / BM) * ncol;
+  const int nkc = (K + KC - 1) / KC;
+  const int nstore = (N + 3) & ~3;
+  f32x4 pa[A_LD], pw[W_LD];
+  auto fetch = [&](long long tile, int kc) {
+    const long long m0 = (tile / ncol) * BM;
+    const int n0 = (int)(tile % ncol) * BN, k0 = kc * KC;
+#pragma unroll
+    for (int i = 0; i < A_LD; i++) {
+      int idx = tid + NTHR * i, row = idx >> 3, c4 = idx & 7;
+      long long m = m0 + row;
+      pa[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (row < BM && m < M && k0 + c4 * 4 < K) pa[i] = *reinterpret_cast<const f32x4*>(A + m * lda + k0 + c4 * 4);
+    }
+#pragma unroll
+    for (int i = 0; i < W_LD; i++) {
+      int idx = tid + NTHR * i, row = idx >> 3, c4 = idx & 7;
+      pw[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (row < BN && n0 + row < Npad)
+        pw[i] = *reinterpret_cast<const f32x4*>(Wp + ((long long)kc * Npad + n0 + row) * KC + c4 * 4);
+    }
+  };
+  auto stash = [&]() {
+#pragma unroll
+    for (int i = 0; i < A_LD; i++) {
+      int idx = tid + NTHR * i, row = idx >> 3, c4 = idx & 7;
+      if (row < BM) *reinterpret_cast<f32x4*>(xs + row * LROW + c4 * 4) = pa[i];
+    }
+#pragma unroll
+    for (int i = 0; i < W_LD; i++) {
+      int idx = tid + NTHR * i, row = idx >> 3, c4 = idx & 7;
+      if (row < BN) *reinterpret_cast<f32x4*>(ws + row * LROW + c4 * 4) = pw[i];
+    }
+  };
+  long long tile = blockIdx.x;
+  if (tile >= ntiles) return;
+  fetch(tile, 0);
+  stash();
+  __syncthreads();
+  for (; tile < ntiles; tile += gridDim.x) {
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; i++)
+#pragma unroll
+      for (int j = 0; j < NT; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int kc = 0; kc < nkc; kc++) {
+      const bool more_k = kc + 1 < nkc;
+      const bool more = more_k || tile + gridDim.x < ntiles;
+      if (more_k) fetch(tile, kc + 1);
+      else if (more) fetch(tile + gridDim.x, 0);
+      const float* xr = xs + (wm * MT * 16 + r) * LROW;
+      const float* wr = ws + (wn * NT * 16 + r) * LROW;
+      f32x4 a[KC / 16][MT], b[KC / 16][NT];
+#pragma unroll
+      for (int g = 0; g < KC / 16; g++) {
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++) a[g][mt] = *reinterpret_cast<const f32x4*>(xr + mt * 16 * LROW + g * 16 + 4 * q);
+#pragma unroll
+        for (int nt = 0; nt < NT; nt++) b[g][nt] = *reinterpret_cast<const f32x4*>(wr + nt * 16 * LROW + g * 16 + 4 * q);
+      }
+#pragma unroll
+      for (int g = 0; g < KC / 16; g++)
+#pragma unroll
+        for (int s = 0; s < 4; s++)
+#pragma unroll
+          for (int nt = 0; nt < NT; nt++)
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++)
+              acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[g][nt][s], a[g][mt][s], acc[mt][nt], 0, 0, 0);
+      __syncthreads();
+      if (more) { stash(); __syncthreads(); }
+    }
+    const long long m0 = (tile / ncol) * BM;
+    const int n0 = (int)(tile % ncol) * BN;
+#pragma unroll
+    for (int nt = 0; nt < NT; nt++) {
+      int col = n0 + (wn * NT + nt) * 16 + q * 4;
+      if (col >= nstore) continue;
+      f32x4 bias = {0.f, 0.f, 0.f, 0.f};
+      if (epi.bias) bias = *reinterpret_cast<const f32x4*>(epi.bias + col);
+#pragma unroll
+      for (int mt = 0; mt < MT; mt++) {
+        long long m = m0 + (wm * MT + mt) * 16 + r;
+        if (m >= M) continue;
+        f32x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          float t = act_apply(acc[mt][nt][j] + bias[j], epi.act);
+          if (epi.has_lab) t = fmaf(t, epi.lab_a, epi.lab_c);
+          if (epi.residual) t += epi.residual[m * epi.ld_res + col + j];
+          o[j] = (col + j < N) ? t : 0.0f;
+        }
+        *reinterpret_cast<f32x4*>(C + m * ldc + coff + col) = o;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
 // LDS-DMA GEMM: both operands go HBM/L2 -> LDS with global_load_lds (no VGPR staging, no
 // ds_write pass), NBUF-deep ring of 32-deep K slabs so two slabs stay in flight behind the
 // MFMAs, one raw s_barrier per slab with a counted vmcnt.  LDS rows are unpadded 128 B
@@ -648,8 +767,19 @@ void gemm(hipStream_t st, const float* A, int lda, long long M, int K, const flo
   if (M <= 0) return;
   int v = g_gemm_variant;
   if (v == 0) {  // production dispatch (tools/bench_gemm.py): wide tiles once N and M are large
-    if (Npad16 % 240 == 0 && M >= 16384) v = 10;
+    if (Npad16 % 240 == 0 && M >= 131072) v = 15;      // 256 x 240 tile: halves the weight re-fetch per row
+    else if (Npad16 % 240 == 0 && M >= 16384) v = 10;
     else if (Npad16 >= 192 && M >= 8192) v = 8;
+  }
+  if (v == 13 || v == 14) {
+    if (v == 13) {
+      long long nt = ((M + 127) / 128) * ((Npad16 + 239) / 240);
+      hipLaunchKernelGGL((k_gemm_persist<2, 5, 4, 3>), dim3((unsigned)std::min<long long>(nt, 256)), dim3(768), 0, st, A, lda, M, K, Wp, N, Npad16, C, ldc, coff, epi);
+    } else {
+      long long nt = ((M + 127) / 128) * ((Npad16 + 127) / 128);
+      hipLaunchKernelGGL((k_gemm_persist<2, 4, 4, 2>), dim3((unsigned)std::min<long long>(nt, 512)), dim3(512), 0, st, A, lda, M, K, Wp, N, Npad16, C, ldc, coff, epi);
+    }
+    return;
   }
   if (v == 12) {
     dim3 grid((unsigned)((M + 127) / 128), (unsigned)((Npad16 + 255) / 256));
@@ -675,6 +805,11 @@ void gemm(hipStream_t st, const float* A, int lda, long long M, int K, const flo
   if (v == 8) {
     dim3 grid((unsigned)((M + 127) / 128), (unsigned)((Npad16 + 127) / 128));
     hipLaunchKernelGGL((k_gemm_wide<2, 4, 4, 2>), grid, dim3(512), 0, st, A, lda, M, K, Wp, N, Npad16, C, ldc, coff, epi);
+    return;
+  }
+  if (v == 15) {
+    dim3 grid((unsigned)((M + 255) / 256), (unsigned)((Npad16 + 239) / 240));
+    hipLaunchKernelGGL((k_gemm_wide<4, 5, 4, 3>), grid, dim3(768), 0, st, A, lda, M, K, Wp, N, Npad16, C, ldc, coff, epi);
     return;
   }
   if (v == 10) {
@@ -1067,16 +1202,16 @@ void dwconv(hipStream_t st, int K, int sh, int sw, const float* x, const ImgGeom
             float lab_c, float* y) {
   if (n_img <= 0) return;
   if ((K == 3 || K == 5) && sh >= 1 && sh <= 2 && sw >= 1 && sw <= 2 && (g_dw_variant == 0 || g_dw_variant == 4)) {
-    const int R = sh == 1 ? 4 : 2;  // input rows streamed: stride 1 -> R+K-1, stride 2 -> 2R+K-2
+    const int R = (sh == 1 && g_dw_variant != 4) ? 4 : 2;  // input rows streamed: stride 1 -> R+K-1, stride 2 -> 2R+K-2
     long long strips = (long long)((maxWo + 3) / 4) * ((maxHo + R - 1) / R);
     dim3 grid((unsigned)((strips + 31) / 32), n_img, (Cp + 31) / 32);
 #define RT_DWR(KK, RR, SH_, SW_) \
   hipLaunchKernelGGL((k_dwconv_rows<KK, RR, SH_, SW_>), grid, dim3(256), 0, st, x, gin, gout, Cp, Wd, bias, act, has_lab, lab_a, lab_c, y)
     const int code = (K == 5 ? 4 : 0) + (sh == 2 ? 2 : 0) + (sw == 2 ? 1 : 0);
     switch (code) {
-      case 0: RT_DWR(3, 4, 1, 1); break; case 1: RT_DWR(3, 4, 1, 2); break;
+      case 0: if (R == 4) RT_DWR(3, 4, 1, 1); else RT_DWR(3, 2, 1, 1); break; case 1: if (R == 4) RT_DWR(3, 4, 1, 2); else RT_DWR(3, 2, 1, 2); break;
       case 2: RT_DWR(3, 2, 2, 1); break; case 3: RT_DWR(3, 2, 2, 2); break;
-      case 4: RT_DWR(5, 4, 1, 1); break; case 5: RT_DWR(5, 4, 1, 2); break;
+      case 4: if (R == 4) RT_DWR(5, 4, 1, 1); else RT_DWR(5, 2, 1, 1); break; case 5: if (R == 4) RT_DWR(5, 4, 1, 2); else RT_DWR(5, 2, 1, 2); break;
       case 6: RT_DWR(5, 2, 2, 1); break; default: RT_DWR(5, 2, 2, 2); break;
     }
 #undef RT_DWR

@@ -362,8 +362,12 @@ std::string fnum(float v) {
 
 rt_results* rt_session::run_batch(const uint8_t* const* rgb, const int* hs, const int* ws, int n_pages, int mem,
                                   const float* const* det_map_override) {
+  static std::chrono::steady_clock::time_point last_exit = std::chrono::steady_clock::now();
+  if (g_trace) fprintf(stderr, "[rt host] %-28s %8.3f ms\n", "between calls", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - last_exit).count());
+  HostTick tick0;
   begin_call();
   dbws.reset();
+  tick0.lap("begin_call + arena reset");
   std::unique_ptr<rt_results> res(new rt_results());
   res->pages.resize((size_t)n_pages);
   if (n_pages == 0) return res.release();
@@ -653,6 +657,7 @@ rt_results* rt_session::run_batch(const uint8_t* const* rgb, const int* hs, cons
     }
   }
   tick.lap("results");
+  last_exit = std::chrono::steady_clock::now();
   return res.release();
 }
 
