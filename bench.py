@@ -40,6 +40,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--det-sub-batch", type=int, default=0)
     ap.add_argument("--variants", type=str, default="", help="debug: gemm,dw,fuse kernel variants")
+    ap.add_argument("--lanes", type=int, default=0, help="concurrent page streams inside rt_run_batch (0 = library default)")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for single-GPU smoke tests of the multi-rank path)")
+    ap.add_argument("--share-gpu", action="store_true", help="test only: every rank uses device 0")
     ap.add_argument("--cpu-pages", type=int, default=1, help="pages of the same workload timed on the CPU oracle")
     ap.add_argument("--profile-all", action="store_true", help="print the per-family table to stderr")
     return ap.parse_args()
@@ -57,11 +60,15 @@ def main():
     import torch
     import torch.distributed as dist
     dist_on = world > 1
+    tdev = "cuda" if a.backend == "nccl" else "cpu"
     if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-    device = local_rank if dist_on else 0
+        if a.backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(a.backend, rank=rank, world_size=world)
+    device = 0 if (a.share_gpu or not dist_on) else local_rank
 
     import retto_amd
     from retto_amd import synth, workload, workmodel
@@ -73,10 +80,11 @@ def main():
         blobs = [None] * 4
     if dist_on:
         from retto_amd.dist import broadcast_blobs
-        blobs = broadcast_blobs(blobs, 4, rank, device="cuda")  # RCCL over xGMI, once
+        blobs = broadcast_blobs(blobs, 4, rank, device=tdev)  # RCCL over xGMI, once
     det_b, cls_b, rec_b, dict_b = blobs
     cfg = retto_amd.RettoSessionConfig()
     cfg.det_sub_batch = a.det_sub_batch
+    cfg.lanes = a.lanes
     cfg.worker_config = retto_amd.RettoHipWorkerConfig(device=device, models=retto_amd.RettoWorkerModelProvider(
         det=retto_amd.RettoWorkerModelSource.Blob(det_b), rec=retto_amd.RettoWorkerModelSource.Blob(rec_b),
         cls=retto_amd.RettoWorkerModelSource.Blob(cls_b)))
@@ -106,10 +114,11 @@ def main():
         return r
 
     def barrier():
+        lib.rt_synchronize(h)
         if dist_on:
             dist.barrier()
-            torch.cuda.synchronize()
-        lib.rt_synchronize(h)
+            if tdev == "cuda":
+                torch.cuda.synchronize()
 
     # warmup (also sizes the arenas)
     n_lines = 0
@@ -120,7 +129,7 @@ def main():
         checksum = lib.rt_results_det_checksum(r)
         widths_probe = r
         lib.rt_results_free(r)
-    sess.profile_enable(True)
+    # ---- timed region: EXACTLY K steps at the production setting (concurrent lanes) -------
     barrier()
     t0 = time.perf_counter()
     for _ in range(a.steps):
@@ -129,13 +138,30 @@ def main():
     barrier()
     t1 = time.perf_counter()
     elapsed = t1 - t0
-    prof = sess.profile_get()
-    sess.profile_enable(False)
+    # ---- roofline pass (rank 0 only): the same K steps strictly serial on one stream with HIP
+    # events around every launch.  Concurrent lanes share the GPU and stretch each other's
+    # kernels, so a kernel's own duration can only be read from a serial pass.
+    prof, serial_ms = {}, None
+    if rank == 0:
+        lib.rt_set_lanes(h, 1)
+        for _ in range(2):  # lane 0's arenas re-size for the whole batch
+            r = step(); lib.rt_results_free(r)
+        sess.profile_enable(True)
+        lib.rt_synchronize(h)
+        ts = time.perf_counter()
+        for _ in range(a.steps):
+            r = step()
+            lib.rt_results_free(r)
+        lib.rt_synchronize(h)
+        serial_ms = 1000.0 * (time.perf_counter() - ts) / a.steps
+        prof = sess.profile_get()
+        sess.profile_enable(False)
+        lib.rt_set_lanes(h, 1 << 20)
     if dist_on:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=tdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        cnt = torch.tensor([n_lines], dtype=torch.int64, device="cuda")
+        cnt = torch.tensor([n_lines], dtype=torch.int64, device=tdev)
         dist.all_reduce(cnt)
         n_lines_total = int(cnt.item())
     else:
@@ -203,6 +229,7 @@ def main():
                 roofline = {"bound": "mfma", "achieved": round(tfs, 2), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
                             "frac": round(mfma_frac, 4), "traffic": None}
             roofline.update({"kernel": name, "avg_launch_ms": round(avg_ms, 4), "launches_per_step": launches_per_step,
+                             "measured": "HIP events on the session stream, serial pass (lanes=1) of the same %d steps, %.2f ms/step" % (a.steps, serial_ms),
                              "share_of_kernel_time": round(ms / total_ms, 3),
                              "algorithmic_bytes_per_launch": int(bytes_per_launch),
                              "algorithmic_flops_per_launch": int(flops_per_launch)})

@@ -99,6 +99,7 @@ typedef struct rt_config {
   /* backend knobs (no reference counterpart) */
   int32_t max_boxes_per_page; /* capacity of the per-page box list; 0 = default 4096 */
   int32_t det_sub_batch;      /* pages per det launch group; 0 = default */
+  int32_t lanes;              /* concurrent page streams inside rt_run_batch (1..4); 0 = default 3 */
 } rt_config;
 
 typedef struct rt_session rt_session;
@@ -179,6 +180,10 @@ RT_API int rt_memcpy_d2h(rt_session* s, void* dst, const void* src, size_t bytes
 RT_API int rt_synchronize(rt_session* s);
 /* Per-kernel-family device time of the last rt_run_batch / L1 call, measured with HIP
  * events on the session's own stream.  names/ms are library-owned arrays of *n entries. */
+/* Upper bound on the concurrent lanes rt_run_batch uses from now on (<= the number created by
+ * rt_config.lanes).  1 = strictly serial on the session's own stream (what the per-kernel
+ * profile wants: concurrent lanes share the GPU and stretch each other's kernels). */
+RT_API int rt_set_lanes(rt_session* s, int lanes);
 RT_API int rt_profile_enable(rt_session* s, int on);
 RT_API int rt_profile_get(rt_session* s, const char* const** names, const float** ms, const int** calls, int* n);
 

@@ -115,6 +115,7 @@ class RettoSessionConfig:  # session.rs:17-40
     rec_processor_config: RecProcessorConfig = field(default_factory=RecProcessorConfig)
     max_boxes_per_page: int = 0
     det_sub_batch: int = 0
+    lanes: int = 0
 
 
 # ---- result types (points.rs, processor/*.rs) ---------------------------------------------
@@ -223,7 +224,7 @@ class _Handle:
         c.rec_batch_num = rc.batch_num
         if tuple(cl.label) != (0, 180):
             raise InvalidArgument("cls label set other than [0, 180] is not supported")
-        c.max_boxes_per_page = cfg.max_boxes_per_page; c.det_sub_batch = cfg.det_sub_batch
+        c.max_boxes_per_page = cfg.max_boxes_per_page; c.det_sub_batch = cfg.det_sub_batch; c.lanes = cfg.lanes
         h = C.c_void_p()
         _check(lib.rt_create(C.byref(c), C.byref(h)), None)
         self.lib, self.h = lib, h

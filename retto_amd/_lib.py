@@ -33,7 +33,7 @@ class Config(C.Structure):
         ("det_min_mini_box_size", C.c_int32), ("det_dilation", C.c_int32),
         ("cls_image_shape", C.c_int32 * 3), ("cls_batch_num", C.c_int32), ("cls_thresh", C.c_float),
         ("rec_image_shape", C.c_int32 * 3), ("rec_batch_num", C.c_int32),
-        ("max_boxes_per_page", C.c_int32), ("det_sub_batch", C.c_int32),
+        ("max_boxes_per_page", C.c_int32), ("det_sub_batch", C.c_int32), ("lanes", C.c_int32),
     ]
 
 
@@ -48,7 +48,7 @@ EXPORTS = [
     "rt_results_det_scores", "rt_results_cls_labels", "rt_results_cls_scores", "rt_results_rec_scores",
     "rt_results_rec_tokens", "rt_results_rec_text", "rt_results_det_checksum", "rt_results_json",
     "rt_device_malloc", "rt_device_free", "rt_memcpy_h2d", "rt_memcpy_d2h", "rt_synchronize",
-    "rt_profile_enable", "rt_profile_get",
+    "rt_set_lanes", "rt_profile_enable", "rt_profile_get",
 ]
 
 _lib = None
@@ -97,6 +97,7 @@ def load():
     lib.rt_memcpy_d2h.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
     lib.rt_synchronize.argtypes = [C.c_void_p]
     lib.rt_profile_enable.argtypes = [C.c_void_p, C.c_int]
+    lib.rt_set_lanes.argtypes = [C.c_void_p, C.c_int]
     lib.rt_det.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
     lib.rt_cls.argtypes = lib.rt_det.argtypes
     lib.rt_rec.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, P(C.c_int)]

@@ -51,7 +51,7 @@ void rt_config_default(rt_config* c) {
   c->cls_batch_num = 6; c->cls_thresh = 0.9f;
   c->rec_image_shape[0] = 3; c->rec_image_shape[1] = 48; c->rec_image_shape[2] = 320;
   c->rec_batch_num = 6;
-  c->max_boxes_per_page = 0; c->det_sub_batch = 0;
+  c->max_boxes_per_page = 0; c->det_sub_batch = 0; c->lanes = 0;
 }
 
 int rt_create(const rt_config* cfg, rt_session** out) {
@@ -61,6 +61,7 @@ int rt_create(const rt_config* cfg, rt_session** out) {
   RT_REQUIRE(cfg->cls_image_shape[0] == 3 && cfg->rec_image_shape[0] == 3 && cfg->rec_image_shape[1] == 48 &&
                  cfg->cls_image_shape[1] == 48 && cfg->cls_image_shape[2] == 192,
              (rt_session*)nullptr, "unsupported cls/rec image_shape for the PP-OCRv4 mobile graphs");
+  RT_REQUIRE(cfg->lanes >= 0 && cfg->lanes <= 4, (rt_session*)nullptr, "lanes must be in [0, 4]");
   RT_REQUIRE(cfg->max_boxes_per_page >= 0 && cfg->max_boxes_per_page <= 4096, (rt_session*)nullptr,
              "max_boxes_per_page must be in [0, 4096]");
   return guarded(nullptr, [&] { *out = rt_session_create(cfg); });
@@ -69,6 +70,12 @@ void rt_destroy(rt_session* s) {
   if (!s) return;
   (void)hipSetDevice(s->device);
   if (s->st) { (void)hipStreamSynchronize(s->st); }
+  for (auto& h : s->helpers) {
+    if (h->st) (void)hipStreamSynchronize(h->st);
+    if (h->d_flags) (void)hipFree(h->d_flags);
+    if (h->st) (void)hipStreamDestroy(h->st);
+  }
+  s->helpers.clear();
   s->det.reset(); s->cls.reset(); s->rec.reset();
   if (s->d_flags) (void)hipFree(s->d_flags);
   if (s->st) (void)hipStreamDestroy(s->st);
@@ -202,12 +209,21 @@ int rt_synchronize(rt_session* s) {
   RT_REQUIRE(s, s, "rt_synchronize: null session");
   return guarded(s, [&] { RT_HIP_CHECK(hipSetDevice(s->device)); RT_HIP_CHECK(hipDeviceSynchronize()); });
 }
+int rt_set_lanes(rt_session* s, int lanes) {
+  RT_REQUIRE(s && lanes >= 1, s, "rt_set_lanes: bad argument");
+  s->active_lanes = lanes;
+  return RT_OK;
+}
 int rt_profile_enable(rt_session* s, int on) {
   RT_REQUIRE(s, s, "rt_profile_enable: null session");
-  return guarded(s, [&] { s->prof.clear(); s->prof.on = on != 0; });
+  return guarded(s, [&] {
+    s->prof.clear(); s->prof.on = on != 0;
+    for (auto& h : s->helpers) { h->prof.clear(); h->prof.on = on != 0; }
+  });
 }
 int rt_profile_get(rt_session* s, const char* const** names, const float** ms, const int** calls, int* n) {
   RT_REQUIRE(s && names && ms && calls && n, s, "rt_profile_get: null argument");
+  for (auto& h : s->helpers) s->prof.merge(h->prof);
   *names = s->prof.names.data(); *ms = s->prof.ms.data(); *calls = s->prof.calls.data(); *n = (int)s->prof.names.size();
   return RT_OK;
 }

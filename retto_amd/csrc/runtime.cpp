@@ -170,6 +170,14 @@ void Profiler::collect() {
   }
   recs_.clear();
 }
+void Profiler::merge(Profiler& o) {
+  o.collect();
+  for (size_t i = 0; i < o.name_store_.size(); i++) {
+    int id = id_of(o.name_store_[i].c_str());
+    ms[id] += o.ms[i]; calls[id] += o.calls[i];
+    o.ms[i] = 0.f; o.calls[i] = 0;
+  }
+}
 void Profiler::clear() {
   collect();
   for (auto& v : ms) v = 0.f;

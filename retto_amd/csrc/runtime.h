@@ -80,6 +80,7 @@ class Profiler {
   void end(hipStream_t st);
   void collect();  // after a stream sync: fold event pairs into the totals
   void clear();
+  void merge(Profiler& other);  // adds other's totals into this one and zeroes other's
   std::vector<const char*> names;
   std::vector<float> ms;
   std::vector<int> calls;

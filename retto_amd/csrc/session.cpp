@@ -7,6 +7,7 @@
 #include <cstring>
 #include <numeric>
 #include <sstream>
+#include <thread>
 
 #include <chrono>
 
@@ -81,6 +82,16 @@ rt_session* rt_session_create(const rt_config* cfg) {
                                     std::to_string(s->rec->classes()) + " classes");
   RT_HIP_CHECK(hipMalloc((void**)&s->d_flags, 64));
   RT_HIP_CHECK(hipMemset(s->d_flags, 0, 64));
+  const int lanes = cfg->lanes > 0 ? cfg->lanes : 3;  // measured on C3: 1 -> 640, 2 -> 681, 3 -> 700, 4 -> 652 images/s
+  for (int l = 1; l < lanes; l++) {
+    std::unique_ptr<rt_session> h(new rt_session());
+    h->cfg = s->cfg; h->device = s->device;
+    h->det = s->det; h->cls = s->cls; h->rec = s->rec; h->dict = s->dict;
+    RT_HIP_CHECK(hipStreamCreateWithFlags(&h->st, hipStreamNonBlocking));
+    RT_HIP_CHECK(hipMalloc((void**)&h->d_flags, 64));
+    RT_HIP_CHECK(hipMemset(h->d_flags, 0, 64));
+    s->helpers.push_back(std::move(h));
+  }
   return s.release();
 }
 
@@ -360,7 +371,7 @@ std::string fnum(float v) {
 }
 }  // namespace
 
-rt_results* rt_session::run_batch(const uint8_t* const* rgb, const int* hs, const int* ws, int n_pages, int mem,
+rt_results* rt_session::run_pages(const uint8_t* const* rgb, const int* hs, const int* ws, int n_pages, int mem,
                                   const float* const* det_map_override) {
   static std::chrono::steady_clock::time_point last_exit = std::chrono::steady_clock::now();
   if (g_trace) fprintf(stderr, "[rt host] %-28s %8.3f ms\n", "between calls", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - last_exit).count());
@@ -658,6 +669,42 @@ rt_results* rt_session::run_batch(const uint8_t* const* rgb, const int* hs, cons
   }
   tick.lap("results");
   last_exit = std::chrono::steady_clock::now();
+  return res.release();
+}
+
+// Splits the pages over the lanes (contiguous ranges, order preserved) and runs the lanes on
+// concurrent host threads; every lane is a full pipeline on its own stream, so one lane's
+// small kernels, launch gaps and host sync points overlap the other lanes' large kernels.
+rt_results* rt_session::run_batch(const uint8_t* const* rgb, const int* hs, const int* ws, int n_pages, int mem,
+                                  const float* const* det_map_override) {
+  const int nl = std::max(1, std::min<int>(std::min<int>((int)helpers.size() + 1, active_lanes), std::max(n_pages, 1)));
+  if (nl <= 1) return run_pages(rgb, hs, ws, n_pages, mem, det_map_override);
+  std::vector<rt_results*> parts((size_t)nl, nullptr);
+  std::vector<std::exception_ptr> errs((size_t)nl);
+  std::vector<int> first((size_t)nl + 1, 0);
+  for (int l = 0; l < nl; l++) first[l + 1] = first[l] + n_pages / nl + (l < n_pages % nl ? 1 : 0);
+  auto work = [&](int l) {
+    rt_session* s = l == 0 ? this : helpers[(size_t)l - 1].get();
+    try {
+      parts[l] = s->run_pages(rgb + first[l], hs + first[l], ws + first[l], first[l + 1] - first[l], mem,
+                              det_map_override ? det_map_override + first[l] : nullptr);
+    } catch (...) { errs[l] = std::current_exception(); }
+  };
+  std::vector<std::thread> th;
+  for (int l = 1; l < nl; l++) th.emplace_back(work, l);
+  work(0);
+  for (auto& t : th) t.join();
+  std::unique_ptr<rt_results> res(new rt_results());
+  std::exception_ptr err;
+  for (int l = 0; l < nl; l++) {
+    if (errs[l] && !err) err = errs[l];
+    if (parts[l]) {
+      for (auto& p : parts[l]->pages) res->pages.push_back(std::move(p));
+      res->det_checksum += parts[l]->det_checksum;
+      delete parts[l];
+    }
+  }
+  if (err) std::rethrow_exception(err);
   return res.release();
 }
 

@@ -35,9 +35,13 @@ struct rt_session {
   rt::Arena dbws;       // DB post-processing workspace (stream-ordered reuse across pages)
   rt::Pinned pinned;
   rt::Profiler prof;
-  std::unique_ptr<rt::DetNet> det;
-  std::unique_ptr<rt::ClsNet> cls;
-  std::unique_ptr<rt::RecNet> rec;
+  std::shared_ptr<rt::DetNet> det;   // weights are shared with the helper lanes
+  std::shared_ptr<rt::ClsNet> cls;
+  std::shared_ptr<rt::RecNet> rec;
+  // extra lanes: same networks and config, own stream / arenas; rt_run_batch splits the pages
+  // over the lanes and runs them on concurrent host threads
+  std::vector<std::unique_ptr<rt_session>> helpers;
+  int active_lanes = 1 << 30;  // rt_set_lanes: upper bound on the lanes rt_run_batch uses
   std::vector<std::string> dict;  // RecCharacter (rec_processor.rs:29-46)
   std::string last_error;
   int* d_flags = nullptr;         // [0] thumbnail/resize error flag
@@ -64,6 +68,8 @@ struct rt_session {
   // L2
   rt_results* run_batch(const uint8_t* const* rgb, const int* hs, const int* ws, int n_pages, int mem,
                         const float* const* det_map_override);
+  rt_results* run_pages(const uint8_t* const* rgb, const int* hs, const int* ws, int n_pages, int mem,
+                        const float* const* det_map_override);  // one lane
 };
 
 rt_session* rt_session_create(const rt_config* cfg);
