@@ -219,7 +219,7 @@ static float* run_lc(RunCtx& c, const LcBlock& b, const float* x, const Level& L
   if (b.se) run_se(c, y1, Lout, b.sew, HSIG_LCNET, 0);
   int Cpo = round_up(b.cout, 4);
   float* y2 = c.arena->alloc<float>((size_t)Lout.total * Cpo);
-  { ProfScope ps(c.prof, c.st, "gemm_pw");
+  { ProfScope ps(c.prof, c.st, nn::gemm_pw_label(Lout.total, b.pw.Npad));
     nn::gemm(c.st, y1, b.dw.Cp, Lout.total, b.pw.K, b.pw.w, b.pw.N, b.pw.Npad, y2, Cpo, 0,
              make_epi(b.pw, ACT_HSWISH, &b.pw_lab)); }
   return y2;

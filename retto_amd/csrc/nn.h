@@ -12,6 +12,7 @@ constexpr int KC = 32;  // K-chunk of the MFMA GEMM / conv kernels (weights are 
 // C[M, ldc] (+coff) = epi(A[M, lda] x W), W packed as [ceil(K/KC)][Npad16][KC].
 void gemm(hipStream_t st, const float* A, int lda, long long M, int K, const float* Wp, int N, int Npad16, float* C,
           int ldc, int coff, const Epilogue& epi);
+const char* gemm_pw_label(long long M, int Npad16);
 extern int g_dw_variant;    // same for dwconv
 extern int g_gemm_variant;  // kernel micro-benchmark hook (0 = production dispatch)
 

@@ -762,15 +762,30 @@ static const float* zero_page() {
 
 int g_gemm_variant = 0;  // 0 = production choice; others are forced by the kernel micro-benchmark
 
+// production dispatch (tools/bench_gemm.py): wide tiles once N and M are large; 0 = narrow k_gemm<NT>
+static int gemm_dispatch(long long M, int Npad16) {
+  if (Npad16 % 240 == 0 && M >= 131072) return 15;  // 256 x 240 tile: halves the weight re-fetch per row
+  if (Npad16 % 240 == 0 && M >= 16384) return 10;
+  if (Npad16 >= 192 && M >= 8192) return 8;
+  return 0;
+}
+// Profiler label of a pointwise-conv GEMM: family + the kernel symbol the dispatcher picks, so the
+// per-kernel numbers of bench.py can be compared with rocprofv3's kernel stats one to one.
+const char* gemm_pw_label(long long M, int Npad16) {
+  switch (g_gemm_variant ? -1 : gemm_dispatch(M, Npad16)) {
+    case 15: return "gemm_pw/k_gemm_wide<4,5,4,3>";
+    case 10: return "gemm_pw/k_gemm_wide<2,5,4,3>";
+    case 8: return "gemm_pw/k_gemm_wide<2,4,4,2>";
+    case 0: return "gemm_pw/k_gemm<NT>";
+    default: return "gemm_pw/variant";
+  }
+}
+
 void gemm(hipStream_t st, const float* A, int lda, long long M, int K, const float* Wp, int N, int Npad16, float* C,
           int ldc, int coff, const Epilogue& epi) {
   if (M <= 0) return;
   int v = g_gemm_variant;
-  if (v == 0) {  // production dispatch (tools/bench_gemm.py): wide tiles once N and M are large
-    if (Npad16 % 240 == 0 && M >= 131072) v = 15;      // 256 x 240 tile: halves the weight re-fetch per row
-    else if (Npad16 % 240 == 0 && M >= 16384) v = 10;
-    else if (Npad16 >= 192 && M >= 8192) v = 8;
-  }
+  if (v == 0) v = gemm_dispatch(M, Npad16);
   if (v == 13 || v == 14) {
     if (v == 13) {
       long long nt = ((M + 127) / 128) * ((Npad16 + 239) / 240);

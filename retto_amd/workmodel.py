@@ -18,6 +18,34 @@ def _down(v: int, s: int) -> int:
     return (v - 1) // s + 1
 
 
+def gemm_pw_label(M: int, N: int) -> str:
+    """Mirror of nn::gemm_pw_label (retto_amd/csrc/nn_kernels.hip): which kernel symbol the
+    dispatcher picks for a pointwise conv of M rows and N output channels."""
+    npad = (N + 15) // 16 * 16
+    if npad % 240 == 0 and M >= 131072:
+        return "gemm_pw/k_gemm_wide<4,5,4,3>"
+    if npad % 240 == 0 and M >= 16384:
+        return "gemm_pw/k_gemm_wide<2,5,4,3>"
+    if npad >= 192 and M >= 8192:
+        return "gemm_pw/k_gemm_wide<2,4,4,2>"
+    return "gemm_pw/k_gemm<NT>"
+
+
+DET_GROUP_PX = 32 * 960 * 960   # session.cpp: det launch-group budget (det-input pixels)
+REC_GROUP_PX = 24000000         # session.cpp: rec launch-group budget (48 x W pixels)
+
+
+def _groups(sizes, budget):
+    out, cur, acc = [], [], 0
+    for i, px in enumerate(sizes):
+        if cur and acc + px > budget:
+            out.append(cur); cur, acc = [], 0
+        cur.append(i); acc += px
+    if cur:
+        out.append(cur)
+    return out
+
+
 def det_work(pages: Iterable[Tuple[int, int]]) -> Dict[str, Dict[str, float]]:
     """pages: det-input (H, W) per page.  Returns family -> {bytes, flops}."""
     w = defaultdict(lambda: {"bytes": 0.0, "flops": 0.0})
@@ -25,7 +53,13 @@ def det_work(pages: Iterable[Tuple[int, int]]) -> Dict[str, Dict[str, float]]:
     def add(fam, b, f=0.0):
         w[fam]["bytes"] += b; w[fam]["flops"] += f
 
-    for (H, W) in pages:
+    pages = list(pages)
+    group_of = {}
+    for g in _groups([h * w_ for h, w_ in pages], DET_GROUP_PX):
+        for i in g:
+            group_of[i] = g
+    for pi, (H, W) in enumerate(pages):
+        grp = [pages[i] for i in group_of[pi]]
         add("det_normalize", H * W * 3 + H * W * 4 * F)
         h, ww = _down(H, 2), _down(W, 2)
         add("stem", H * W * 3 * F + h * ww * 16 * F, 2 * h * ww * 27 * 16)
@@ -36,7 +70,9 @@ def det_work(pages: Iterable[Tuple[int, int]]) -> Dict[str, Dict[str, float]]:
             if se:
                 add("se_pool_fc", ho * wo * cin * F)
                 add("scale_channels", 2 * ho * wo * cin * F)
-            add("gemm_pw", ho * wo * (cin + cout) * F + cin * cout * F, 2 * ho * wo * cin * cout)
+            scale = (ho * wo) / float(H * W)
+            m_group = int(round(sum(gh * gw for gh, gw in grp) * scale))
+            add(gemm_pw_label(m_group, cout), ho * wo * (cin + cout) * F + cin * cout * F, 2 * ho * wo * cin * cout)
             h, ww = ho, wo
             for j, (tn, tc, oc) in enumerate(synth.DET_TAPS):
                 if tn == name:
@@ -65,8 +101,14 @@ def rec_work(widths: Iterable[int], classes: int = synth.REC_CLASSES) -> Dict[st
     def add(fam, b, f=0.0):
         w[fam]["bytes"] += b; w[fam]["flops"] += f
 
-    for W in widths:
+    widths = list(widths)
+    group_of = {}
+    for g in _groups([48 * w_ for w_ in widths], REC_GROUP_PX):
+        for i in g:
+            group_of[i] = g
+    for wi, W in enumerate(widths):
         H = 48
+        grp_px = sum(48 * widths[i] for i in group_of[wi])
         h, ww = _down(H, 2), _down(W, 2)
         add("stem", H * W * 3 * F + h * ww * 16 * F, 2 * h * ww * 27 * 16)
         for name, k, cin, cout, sh, sw, se in synth.REC_BLOCKS:
@@ -74,7 +116,8 @@ def rec_work(widths: Iterable[int], classes: int = synth.REC_CLASSES) -> Dict[st
             add("dwconv%d" % k, (h * ww + ho * wo) * cin * F + k * k * cin * F, 2 * ho * wo * cin * k * k)
             if se:
                 add("se_pool_fc", ho * wo * cin * F); add("scale_channels", 2 * ho * wo * cin * F)
-            add("gemm_pw", ho * wo * (cin + cout) * F + cin * cout * F, 2 * ho * wo * cin * cout)
+            m_group = int(round(grp_px * (ho * wo) / float(H * W)))
+            add(gemm_pw_label(m_group, cout), ho * wo * (cin + cout) * F + cin * cout * F, 2 * ho * wo * cin * cout)
             h, ww = ho, wo
         T = (ww - 2) // 2 + 1
         add("avgpool", (h * ww + T) * 480 * F)
