@@ -100,3 +100,17 @@ def test_stage_json_shape(hip_session):
         assert set(c) == {"label"} and set(c["label"]) == {"label", "score"}
     for r in rec:
         assert set(r) == {"text", "score"}
+
+
+def test_cli_directory_run(tmp_path):
+    """retto-cli's loop (main.rs:72-93) over PNG files through the HIP session."""
+    import json
+    from PIL import Image
+    from retto_amd import cli, workload
+    for i in range(3):
+        page, _ = workload.planted_page(160, 320, 2, seed=i)
+        Image.fromarray(page).save(tmp_path / ("p%d.png" % i))
+    out = tmp_path / "out.jsonl"
+    assert cli.main(["--images", str(tmp_path), "--synthetic", "--batch", "2", "--json", str(out)]) == 0
+    lines = [json.loads(l) for l in open(out)]
+    assert len(lines) == 3 and all(set(l) == {"file", "det", "cls", "rec"} for l in lines)

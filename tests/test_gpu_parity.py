@@ -310,3 +310,34 @@ def test_reference_small_image_scenario(hip_session):
     br = r.det_result[0].boxes.br()
     assert np.hypot(br.x - 200, br.y - 50) < 10
     assert r.cls_result[0].label.label in (0, 180)
+
+
+def test_det_postprocess_noise_full_page(hip_session):
+    """Worst case for the contour machinery: a full 960x960 noise map (what the det net with
+    synthetic weights actually produces) -> tens of thousands of components and holes."""
+    rng = np.random.default_rng(99)
+    pred = rng.uniform(0, 1, (960, 960)).astype(np.float32)
+    gb, gs = hip_session.det_postprocess(pred, 960, 960)
+    rb, rs = R.det_postprocess(pred, 960, 960)
+    assert len(gb) == len(rb)
+    assert np.array_equal(gb, rb) and np.array_equal(gs.view(np.uint32), rs.view(np.uint32))
+
+
+def test_det_postprocess_sparse_noise(hip_session):
+    rng = np.random.default_rng(100)
+    pred = (rng.uniform(0, 1, (480, 640)) > 0.93).astype(np.float32) * 0.9 + 0.01   # many tiny blobs
+    pred[100:140, 50:400] = 0.8
+    gb, gs = hip_session.det_postprocess(pred, 480, 640)
+    rb, rs = R.det_postprocess(pred, 480, 640)
+    assert len(gb) == len(rb) >= 1
+    assert np.array_equal(gb, rb) and np.array_equal(gs.view(np.uint32), rs.view(np.uint32))
+
+
+def test_pipeline_raw_det_map(hip_session, oracle_session):
+    """No planted map: boxes come from the det network's own (noise-like) output; the oracle is
+    teacher-forced with the HIP map, so every discrete result must still agree."""
+    page = _rand_page(320, 416, 77)
+    r = hip_session.run_batch([page])[0]
+    _teacher_forced(oracle_session, hip_session)
+    o = oracle_session.run(page)
+    _assert_page_equal(r, o)

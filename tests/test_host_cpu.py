@@ -116,3 +116,11 @@ def test_decode_image_png():
     assert np.array_equal(retto_amd.decode_image(buf.getvalue()), a)
     with pytest.raises(retto_amd.ImageError):
         retto_amd.decode_image(b"not an image")
+
+
+def test_cli_parser_and_walk(tmp_path):
+    from retto_amd import cli
+    a = cli.build_parser().parse_args(["--images", str(tmp_path), "--batch", "4", "--synthetic"])
+    assert a.batch == 4 and a.synthetic and a.rec_keys_path == "ppocr_keys_v1.txt"
+    (tmp_path / "b").mkdir(); (tmp_path / "b" / "2.png").write_bytes(b"x"); (tmp_path / "a.png").write_bytes(b"y")
+    assert [os.path.basename(p) for p in cli.walk_files(str(tmp_path))] == ["a.png", "2.png"]
