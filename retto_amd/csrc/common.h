@@ -42,6 +42,10 @@ struct RtError : std::runtime_error {
   } while (0)
 
 static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+// Channel pitch of an NHWC activation: multiples of 4 (16-byte vectors); wide tensors are padded to
+// 32 channels so that every pixel starts on a 128-byte line (240 -> 256: the depthwise kernels'
+// 32-channel slabs and the GEMM A rows stop straddling lines).  Padding channels hold zeros.
+static inline int chan_pitch(int c) { return c >= 128 ? round_up(c, 32) : round_up(c, 4); }
 static inline long long round_up_ll(long long v, long long m) { return (v + m - 1) / m * m; }
 
 }  // namespace rt

@@ -114,7 +114,7 @@ static PackedDense pack_linear(WeightStore& ws, const Blob& b, const std::string
 static PackedDw pack_dw(WeightStore& ws, const Blob& b, const std::string& name, int C, int k) {
   const BlobTensor& w = b.get(name + ".w");
   expect_dims(w, {C, 1, k, k}, name + ".w");
-  PackedDw p; p.k = k; p.C = C; p.Cp = round_up(C, 4);
+  PackedDw p; p.k = k; p.C = C; p.Cp = chan_pitch(C);
   std::vector<float> host((size_t)k * k * p.Cp, 0.f), bias(p.Cp, 0.f);
   for (int c = 0; c < C; c++)
     for (int t = 0; t < k * k; t++) host[(size_t)t * p.Cp + c] = w.data[(size_t)c * k * k + t];
@@ -191,7 +191,7 @@ static Epilogue make_epi(const PackedDense& p, int act, const Lab* lab = nullptr
 }
 
 static void run_se(RunCtx& c, float* x, const Level& L, const SeW& se, float slope, int residual) {
-  int Cp = round_up(se.C, 4);
+  int Cp = chan_pitch(se.C);
   float* partial = c.arena->alloc<float>((size_t)L.n() * nn::pool_chunks(L.maxPix) * Cp);
   float* scale = c.arena->alloc<float>((size_t)L.n() * Cp);
   { ProfScope ps(c.prof, c.st, "se_pool_fc");
@@ -200,12 +200,16 @@ static void run_se(RunCtx& c, float* x, const Level& L, const SeW& se, float slo
     nn::scale_channels(c.st, x, L.d, L.n(), L.maxPix, Cp, scale); }
 }
 
+static std::string shape_str(long long a, long long b, long long c, long long d) {
+  return std::to_string(a) + "," + std::to_string(b) + "," + std::to_string(c) + "," + std::to_string(d);
+}
+
 static const float HSIG_LCNET = 0.1666667f;  // paddle nn.Hardsigmoid
 static const float HSIG_MBV3 = 0.2f;         // F.hardsigmoid(slope=0.2, offset=0.5)
 
 static float* run_lc(RunCtx& c, const LcBlock& b, const float* x, const Level& Lin, const Level& Lout) {
-  if (nn::g_fuse_dwpw && !b.se && b.sh == 1 && b.sw == 1 && b.dw.Cp % 4 == 0) {
-    int Cpo = round_up(b.cout, 4);
+  if (nn::g_fuse_dwpw && !b.se && b.sh == 1 && b.sw == 1 && b.dw.Cp == round_up(b.dw.C, 4)) {
+    int Cpo = chan_pitch(b.cout);
     float* y2 = c.arena->alloc<float>((size_t)Lout.total * Cpo);
     ProfScope ps(c.prof, c.st, b.dw.k == 3 ? "dwpw3" : "dwpw5");
     nn::dwpw(c.st, b.dw.k, x, Lout.d, Lout.n(), Lout.maxH, Lout.maxW, b.dw.Cp, b.dw.w, b.dw.b, b.dw_act, b.dw_lab.has,
@@ -213,13 +217,13 @@ static float* run_lc(RunCtx& c, const LcBlock& b, const float* x, const Level& L
     return y2;
   }
   float* y1 = c.arena->alloc<float>((size_t)Lout.total * b.dw.Cp);
-  { ProfScope ps(c.prof, c.st, b.dw.k == 3 ? "dwconv3" : "dwconv5");
-    nn::dwconv(c.st, b.dw.k, b.sh, b.sw, x, Lin.d, Lout.d, Lout.n(), Lout.maxH, Lout.maxW, b.dw.Cp, b.dw.w, b.dw.b,
+  { ProfScope ps(c.prof, c.st, b.dw.k == 3 ? "dwconv3" : "dwconv5", shape_str(Lin.total, Lout.total, b.dw.Cp, b.sh * 10 + b.sw));
+    nn::dwconv(c.st, b.dw.k, b.sh, b.sw, x, Lin.d, Lout.d, Lout.n(), Lout.maxH, Lout.maxW, b.dw.Cp, b.dw.C, b.dw.w, b.dw.b,
                b.dw_act, b.dw_lab.has, b.dw_lab.a, b.dw_lab.c, y1); }
   if (b.se) run_se(c, y1, Lout, b.sew, HSIG_LCNET, 0);
-  int Cpo = round_up(b.cout, 4);
+  int Cpo = chan_pitch(b.cout);
   float* y2 = c.arena->alloc<float>((size_t)Lout.total * Cpo);
-  { ProfScope ps(c.prof, c.st, nn::gemm_pw_label(Lout.total, b.pw.Npad));
+  { ProfScope ps(c.prof, c.st, nn::gemm_pw_label(Lout.total, b.pw.Npad), shape_str(Lout.total, b.pw.K, b.pw.N, 0));
     nn::gemm(c.st, y1, b.dw.Cp, Lout.total, b.pw.K, b.pw.w, b.pw.N, b.pw.Npad, y2, Cpo, 0,
              make_epi(b.pw, ACT_HSWISH, &b.pw_lab)); }
   return y2;
@@ -268,8 +272,8 @@ float* DetNet::run(RunCtx& c, const float* x, Level& L0) {
       if (tap_after_[j] == (int)i) {
         int Cpo = round_up(out_[j].N, 4);
         float* o = c.arena->alloc<float>((size_t)lv[li]->total * Cpo);
-        ProfScope ps(c.prof, c.st, "gemm_misc");
-        nn::gemm(c.st, t, round_up(b.cout, 4), lv[li]->total, out_[j].K, out_[j].w, out_[j].N, out_[j].Npad, o, Cpo, 0,
+        ProfScope ps(c.prof, c.st, "gemm_misc", shape_str(lv[li]->total, out_[j].K, out_[j].N, 0));
+        nn::gemm(c.st, t, chan_pitch(b.cout), lv[li]->total, out_[j].K, out_[j].w, out_[j].N, out_[j].Npad, o, Cpo, 0,
                  make_epi(out_[j], ACT_NONE));
         taps[j] = o; tap_lv[j] = lv[li];
       }
@@ -278,7 +282,7 @@ float* DetNet::run(RunCtx& c, const float* x, Level& L0) {
   float* in[4];
   for (int j = 3; j >= 0; j--) {
     in[j] = c.arena->alloc<float>((size_t)tap_lv[j]->total * 96);
-    { ProfScope ps(c.prof, c.st, "gemm_misc");
+    { ProfScope ps(c.prof, c.st, "gemm_misc", shape_str(tap_lv[j]->total, ins_[j].K, 96, 0));
       nn::gemm(c.st, taps[j], round_up(out_[j].N, 4), tap_lv[j]->total, ins_[j].K, ins_[j].w, 96, ins_[j].Npad, in[j], 96,
                0, make_epi(ins_[j], ACT_NONE)); }
     run_se(c, in[j], *tap_lv[j], ins_se_[j], HSIG_MBV3, 1);
@@ -290,7 +294,7 @@ float* DetNet::run(RunCtx& c, const float* x, Level& L0) {
   float* p[4];
   for (int j = 3; j >= 0; j--) {
     p[j] = c.arena->alloc<float>((size_t)tap_lv[j]->total * 24);
-    { ProfScope ps(c.prof, c.st, "conv3x3");
+    { ProfScope ps(c.prof, c.st, "conv3x3", shape_str(tap_lv[j]->total, 9 * 96, 24, 0));
       nn::conv_sp(c.st, 3, 3, in[j], 96, tap_lv[j]->d, tap_lv[j]->n(), tap_lv[j]->maxH, tap_lv[j]->maxW, 96, inp_[j].w, 24,
                   inp_[j].Npad, p[j], 24, make_epi(inp_[j], ACT_NONE)); }
     run_se(c, p[j], *tap_lv[j], inp_se_[j], HSIG_MBV3, 1);
@@ -299,7 +303,7 @@ float* DetNet::run(RunCtx& c, const float* x, Level& L0) {
   { ProfScope ps(c.prof, c.st, "fpn_concat");
     nn::fpn_concat(c.st, p[3], p[2], p[1], p[0], L32.d, L16.d, L8.d, L4.d, L4.n(), L4.maxPix, 24, fuse); }
   float* h1 = c.arena->alloc<float>((size_t)L4.total * 24);
-  { ProfScope ps(c.prof, c.st, "conv3x3");
+  { ProfScope ps(c.prof, c.st, "conv3x3", shape_str(L4.total, 9 * 96, 24, 1));
     nn::conv_sp(c.st, 3, 3, fuse, 96, L4.d, L4.n(), L4.maxH, L4.maxW, 96, head_conv1_.w, 24, head_conv1_.Npad, h1, 24,
                 make_epi(head_conv1_, ACT_RELU)); }
   float* map = c.arena->alloc<float>((size_t)L0.total);
@@ -405,7 +409,7 @@ float* RecNet::run(RunCtx& c, const float* x, Level& L0, Level& Lt) {
     nn::gemm(c.st, z4, 60, rows, conv1x1_.K, conv1x1_.w, D, conv1x1_.Npad, z5, D, 0, make_epi(conv1x1_, ACT_SWISH)); }
   const int ld = logits_ld();
   float* logits = c.arena->alloc<float>((size_t)rows * ld);
-  { ProfScope ps(c.prof, c.st, "gemm_ctc_fc");
+  { ProfScope ps(c.prof, c.st, "gemm_ctc_fc", shape_str(rows, fc_.K, classes_, 0));
     nn::gemm(c.st, z5, D, rows, fc_.K, fc_.w, classes_, fc_.Npad, logits, ld, 0, make_epi(fc_, ACT_NONE)); }
   return logits;
 }
@@ -463,7 +467,7 @@ float* ClsNet::run(RunCtx& c, const float* x, Level& L0) {
                make_epi(b.expand, b.act)); }
     float* d = c.arena->alloc<float>((size_t)Lout.total * mid);
     { ProfScope ps(c.prof, c.st, b.dw.k == 3 ? "dwconv3" : "dwconv5");
-      nn::dwconv(c.st, b.dw.k, b.sh, b.sw, e, Lin.d, Lout.d, Lout.n(), Lout.maxH, Lout.maxW, mid, b.dw.w, b.dw.b, b.act, 0,
+      nn::dwconv(c.st, b.dw.k, b.sh, b.sw, e, Lin.d, Lout.d, Lout.n(), Lout.maxH, Lout.maxW, mid, b.dw.C, b.dw.w, b.dw.b, b.act, 0,
                  1.f, 0.f, d); }
     if (b.se) run_se(c, d, Lout, b.sew, HSIG_MBV3, 0);
     int co = b.linear.N;

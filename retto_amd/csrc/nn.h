@@ -23,8 +23,8 @@ void conv_sp(hipStream_t st, int KH, int KW, const float* x, int ldx, const ImgG
 
 // Depthwise KxK (K in {3,5}), stride (sh,sw), pad K/2.  Wd packed [K*K][Cp].
 void dwconv(hipStream_t st, int K, int sh, int sw, const float* x, const ImgGeom* gin, const ImgGeom* gout, int n_img,
-            int maxHo, int maxWo, int Cp, const float* Wd, const float* bias, int act, int has_lab, float lab_a,
-            float lab_c, float* y);
+            int maxHo, int maxWo, int Cp, int C, const float* Wd, const float* bias, int act, int has_lab,
+            float lab_a, float lab_c, float* y);  // Cp = channel pitch (chan_pitch), C = real channels
 
 // Fused stride-1 depthwise KxK (+bias, act, LAB) -> 1x1 conv (+epilogue); see k_dwpw.
 void dwpw(hipStream_t st, int K, const float* x, const ImgGeom* geom, int n_img, int maxH, int maxW, int Cp,

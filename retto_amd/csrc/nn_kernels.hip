@@ -766,7 +766,7 @@ int g_gemm_variant = 0;  // 0 = production choice; others are forced by the kern
 static int gemm_dispatch(long long M, int Npad16) {
   if (Npad16 % 240 == 0 && M >= 131072) return 15;  // 256 x 240 tile: halves the weight re-fetch per row
   if (Npad16 % 240 == 0 && M >= 16384) return 10;
-  if (Npad16 >= 192 && M >= 8192) return 8;
+  if (Npad16 >= 128 && M >= 8192) return 8;  // 128 x 128 register-prefetch tile (N = 128: 71 vs 61 TFLOP/s narrow)
   return 0;
 }
 // Profiler label of a pointwise-conv GEMM: family + the kernel symbol the dispatcher picks, so the
@@ -1133,9 +1133,12 @@ __global__ __launch_bounds__(256) void k_dwconv_lds(const float* __restrict__ x,
 // 32-channel slab in LDS (3.2 KB).  Strips are numbered column-major so that the vertically
 // adjacent strips (which share K-SH halo rows) sit in the same workgroup and meet in L1/L2
 // instead of re-reading HBM.  Accumulation order per output: bias, then taps in (dy, dx) order.
+// 128 VGPRs (4 waves/SIMD): +15 % over 3 waves at C = 480.  Measured and rejected: lane groups
+// spanning whole pixels with all the weights in LDS (1.2-1.5x slower), one-row-ahead register
+// prefetch (hipcc hoists every load: spills).
 template <int K, int R, int SH, int SW>
-__global__ __launch_bounds__(256) void k_dwconv_rows(const float* __restrict__ x, const ImgGeom* __restrict__ gin,
-                                                     const ImgGeom* __restrict__ gout, int Cp,
+__global__ __launch_bounds__(256, 4) void k_dwconv_rows(const float* __restrict__ x, const ImgGeom* __restrict__ gin,
+                                                     const ImgGeom* __restrict__ gout, int Cp, int C,
                                                      const float* __restrict__ Wd, const float* __restrict__ bias, int act,
                                                      int has_lab, float lab_a, float lab_c, float* __restrict__ y) {
   constexpr int NV = 3 * SW + K;       // input columns feeding 4 output pixels
@@ -1202,7 +1205,7 @@ __global__ __launch_bounds__(256) void k_dwconv_rows(const float* __restrict__ x
       for (int e = 0; e < 4; e++) {
         float t = act_apply(acc[r][j][e], act);
         if (has_lab) t = fmaf(t, lab_a, lab_c);
-        o[e] = t;
+        o[e] = (ch + e < C) ? t : 0.f;  // pitch padding (chan_pitch) holds zeros whatever the input padding held
       }
       *reinterpret_cast<f32x4*>(y + (go.off + (long long)oy * go.W + ox0 + j) * Cp + ch) = o;
     }
@@ -1213,7 +1216,7 @@ int g_dw_variant = 0;  // 0 = production; 1 = generic; 2 = register strip; 3 = L
 int g_fuse_dwpw = 0;  // experimental: correct, but producer-latency bound; off by default
 
 void dwconv(hipStream_t st, int K, int sh, int sw, const float* x, const ImgGeom* gin, const ImgGeom* gout, int n_img,
-            int maxHo, int maxWo, int Cp, const float* Wd, const float* bias, int act, int has_lab, float lab_a,
+            int maxHo, int maxWo, int Cp, int C, const float* Wd, const float* bias, int act, int has_lab, float lab_a,
             float lab_c, float* y) {
   if (n_img <= 0) return;
   if ((K == 3 || K == 5) && sh >= 1 && sh <= 2 && sw >= 1 && sw <= 2 && (g_dw_variant == 0 || g_dw_variant == 4)) {
@@ -1221,7 +1224,7 @@ void dwconv(hipStream_t st, int K, int sh, int sw, const float* x, const ImgGeom
     long long strips = (long long)((maxWo + 3) / 4) * ((maxHo + R - 1) / R);
     dim3 grid((unsigned)((strips + 31) / 32), n_img, (Cp + 31) / 32);
 #define RT_DWR(KK, RR, SH_, SW_) \
-  hipLaunchKernelGGL((k_dwconv_rows<KK, RR, SH_, SW_>), grid, dim3(256), 0, st, x, gin, gout, Cp, Wd, bias, act, has_lab, lab_a, lab_c, y)
+  hipLaunchKernelGGL((k_dwconv_rows<KK, RR, SH_, SW_>), grid, dim3(256), 0, st, x, gin, gout, Cp, C, Wd, bias, act, has_lab, lab_a, lab_c, y)
     const int code = (K == 5 ? 4 : 0) + (sh == 2 ? 2 : 0) + (sw == 2 ? 1 : 0);
     switch (code) {
       case 0: if (R == 4) RT_DWR(3, 4, 1, 1); else RT_DWR(3, 2, 1, 1); break; case 1: if (R == 4) RT_DWR(3, 4, 1, 2); else RT_DWR(3, 2, 1, 2); break;
@@ -1232,6 +1235,7 @@ void dwconv(hipStream_t st, int K, int sh, int sw, const float* x, const ImgGeom
 #undef RT_DWR
     return;
   }
+  if (Cp - C >= 4) throw RtError(8, "dwconv: only the row-streaming kernel supports padded channel pitches");
   if (sh == 1 && sw == 1 && (K == 3 || K == 5) && g_dw_variant == 3 && Cp >= 16) {  // measured slower than the register strip (tools/), kept for A/B
     const bool c8 = Cp >= 32;
     const int TH = c8 ? 4 : 8, CB = c8 ? 32 : 16;

@@ -2,6 +2,7 @@
 // arena for activations, a pinned staging buffer for descriptor tables, an RTWB blob
 // reader, and a per-kernel-family HIP-event profiler.
 #pragma once
+#include <cstdlib>
 #include <map>
 #include <string>
 #include <vector>
@@ -76,6 +77,7 @@ class Profiler {
  public:
   ~Profiler();
   bool on = false;
+  bool detail = getenv("RT_PROFILE_DETAIL") != nullptr;  // per-layer labels "family@shape" (tools/layer_profile.py)
   void begin(hipStream_t st, const char* name);
   void end(hipStream_t st);
   void collect();  // after a stream sync: fold event pairs into the totals
@@ -98,6 +100,9 @@ class Profiler {
 struct ProfScope {
   Profiler* p; hipStream_t st;
   ProfScope(Profiler* p_, hipStream_t s, const char* name) : p(p_), st(s) { if (p && p->on) p->begin(st, name); }
+  ProfScope(Profiler* p_, hipStream_t s, const char* name, const std::string& shape) : p(p_), st(s) {
+    if (p && p->on) p->begin(st, p->detail ? (std::string(name) + "@" + shape).c_str() : name);
+  }
   ~ProfScope() { if (p && p->on) p->end(st); }
 };
 

@@ -1,0 +1,59 @@
+"""Per-layer timing table of the C3 workload (GPU only): run with RT_PROFILE_DETAIL=1 so the
+HIP-event profiler labels every LCNet block kernel "family@shape"; prints time per launch with
+the algorithmic bytes and FLOPs of that launch.
+
+    RT_PROFILE_DETAIL=1 python tools/layer_profile.py [pages] [steps]
+"""
+import ctypes as C, os, sys
+os.environ.setdefault("RT_PROFILE_DETAIL", "1")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import retto_amd
+from retto_amd import workload
+
+pages_n = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+steps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+cfg = retto_amd.synthetic_session_config(0)
+cfg.lanes = 1
+s = retto_amd.RettoSession(cfg)
+lib, h = s._hd.lib, s._hd.h
+if os.environ.get("VARIANTS"):
+    lib.rt_debug_set_variants(*[int(v) for v in os.environ["VARIANTS"].split(",")])
+d_pages, d_maps = [], []
+for i in range(pages_n):
+    page, rects = workload.planted_page(960, 960, 32, seed=i)
+    m = workload.planted_map(960, 960, 960, 960, rects)
+    for arr, lst in ((page, d_pages), (m, d_maps)):
+        p = C.c_void_p()
+        assert lib.rt_device_malloc(h, arr.nbytes, C.byref(p)) == 0
+        assert lib.rt_memcpy_h2d(h, p, arr.ctypes.data, arr.nbytes) == 0
+        lst.append(p.value)
+hs = [960] * pages_n
+for _ in range(2):
+    lib.rt_results_free(s.run_batch_raw(d_pages, hs, hs, retto_amd.RT_MEM_DEVICE, d_maps))
+s.profile_enable(True)
+for _ in range(steps):
+    lib.rt_results_free(s.run_batch_raw(d_pages, hs, hs, retto_amd.RT_MEM_DEVICE, d_maps))
+rows = []
+for name, (ms, calls) in s.profile_get().items():
+    if calls == 0:
+        continue
+    fam, _, shape = name.partition("@")
+    per = ms / calls
+    by = fl = 0.0
+    if shape:
+        a, b, c, d = (int(v) for v in shape.split(","))
+        if fam.startswith("dwconv"):
+            k = int(fam[-1]); by = (a + b) * c * 4.0; fl = 2.0 * b * c * k * k
+        else:
+            by = a * (b + c) * 4.0 if not fam.startswith("conv3x3") else a * (96 + 24) * 4.0
+            fl = 2.0 * a * b * c
+    rows.append((ms / steps, fam, shape, calls // steps, per, by / per / 1e6 if by else 0, fl / per / 1e6 if fl else 0))
+rows.sort(reverse=True)
+tot = sum(r[0] for r in rows)
+print("total profiled %.2f ms/step" % tot)
+print("%8s %-34s %-28s %5s %9s %8s %8s" % ("ms/step", "family", "shape", "n/stp", "ms/launch", "TB/s", "TFLOP/s"))
+only = os.environ.get("ONLY")
+for r in rows:
+    if only and only not in r[1]:
+        continue
+    print("%8.3f %-34s %-28s %5d %9.3f %8.2f %8.1f" % (r[0], r[1], r[2], r[3], r[4], r[5] / 1e3, r[6] / 1e3))
