@@ -26,6 +26,12 @@ struct Epilogue {
   float lab_a, lab_c;
   const float* residual;  // optional, same row indexing as the output
   int ld_res;
+  // Squeeze-excite scale folded into the A operand (wide GEMM tiles only): row m of image i is
+  // multiplied by a_scale[i * ld_scale + k] while its K-slab is staged.  a_tab holds, per row tile,
+  // {image of the tile's first row, first row of the next image}; a tile spans at most 2 images.
+  const float* a_scale = nullptr;
+  int ld_scale = 0;
+  const int* a_tab = nullptr;
 };
 
 struct RtError : std::runtime_error {

@@ -1,5 +1,7 @@
 #include "nets.h"
 
+#include <algorithm>
+#include <cstdlib>
 #include <cstring>
 
 namespace rt {
@@ -217,15 +219,47 @@ static float* run_lc(RunCtx& c, const LcBlock& b, const float* x, const Level& L
     return y2;
   }
   float* y1 = c.arena->alloc<float>((size_t)Lout.total * b.dw.Cp);
+  // Squeeze-excite without extra passes over y1: the depthwise kernel leaves per-block channel sums,
+  // the FC turns them into scales, and the pointwise GEMM multiplies them in while staging its A
+  // rows (a row tile spans at most two images when every image has >= tile rows).
+  const int tile_rows = b.se ? nn::gemm_tile_rows(Lout.total, b.pw.Npad) : 0;
+  long long min_pix = Lout.maxPix;
+  for (const ImgGeom& g : Lout.h) min_pix = std::min<long long>(min_pix, (long long)g.H * g.W);
+  const bool fuse_se = b.se && tile_rows > 0 && min_pix >= tile_rows && b.pw.K <= 512 && (b.dw.k == 3 || b.dw.k == 5) &&
+                       !getenv("RT_NO_SE_FUSION");
+  float* pool = nullptr; int chunks = 0, strip_R = 0;
+  if (fuse_se) {
+    nn::dwconv_pool_layout(b.sh, Lout.maxH, Lout.maxW, &chunks, &strip_R);
+    pool = c.arena->alloc<float>((size_t)Lout.n() * chunks * b.dw.Cp);
+  }
   { ProfScope ps(c.prof, c.st, b.dw.k == 3 ? "dwconv3" : "dwconv5", shape_str(Lin.total, Lout.total, b.dw.Cp, b.sh * 10 + b.sw));
     nn::dwconv(c.st, b.dw.k, b.sh, b.sw, x, Lin.d, Lout.d, Lout.n(), Lout.maxH, Lout.maxW, b.dw.Cp, b.dw.C, b.dw.w, b.dw.b,
-               b.dw_act, b.dw_lab.has, b.dw_lab.a, b.dw_lab.c, y1); }
-  if (b.se) run_se(c, y1, Lout, b.sew, HSIG_LCNET, 0);
+               b.dw_act, b.dw_lab.has, b.dw_lab.a, b.dw_lab.c, y1, pool); }
+  Epilogue epi = make_epi(b.pw, ACT_HSWISH, &b.pw_lab);
+  if (fuse_se) {
+    float* scale = c.arena->alloc<float>((size_t)Lout.n() * b.dw.Cp);
+    { ProfScope ps(c.prof, c.st, "se_pool_fc");
+      nn::se_fc_from_dw(c.st, pool, Lout.d, Lout.n(), chunks, strip_R, b.sew.C, b.dw.Cp, b.sew.w1, b.sew.b1, b.sew.w2,
+                        b.sew.b2, b.sew.Cr, HSIG_LCNET, 0, scale); }
+    const long long tiles = (Lout.total + tile_rows - 1) / tile_rows;
+    int* htab = c.pinned->alloc<int>((size_t)tiles * 2);
+    int* dtab = c.arena->alloc<int>((size_t)tiles * 2);
+    size_t img = 0;
+    for (long long t = 0; t < tiles; t++) {
+      const long long m0 = t * tile_rows;
+      while (img + 1 < Lout.h.size() && Lout.h[img + 1].off <= m0) img++;
+      htab[2 * t] = (int)img;
+      htab[2 * t + 1] = img + 1 < Lout.h.size() ? (int)Lout.h[img + 1].off : 0x7fffffff;  // no next image: never crossed
+    }
+    RT_HIP_CHECK(hipMemcpyAsync(dtab, htab, (size_t)tiles * 2 * sizeof(int), hipMemcpyHostToDevice, c.st));
+    epi.a_scale = scale; epi.ld_scale = b.dw.Cp; epi.a_tab = dtab;
+  } else if (b.se) {
+    run_se(c, y1, Lout, b.sew, HSIG_LCNET, 0);
+  }
   int Cpo = chan_pitch(b.cout);
   float* y2 = c.arena->alloc<float>((size_t)Lout.total * Cpo);
-  { ProfScope ps(c.prof, c.st, nn::gemm_pw_label(Lout.total, b.pw.Npad), shape_str(Lout.total, b.pw.K, b.pw.N, 0));
-    nn::gemm(c.st, y1, b.dw.Cp, Lout.total, b.pw.K, b.pw.w, b.pw.N, b.pw.Npad, y2, Cpo, 0,
-             make_epi(b.pw, ACT_HSWISH, &b.pw_lab)); }
+  { ProfScope ps(c.prof, c.st, nn::gemm_pw_label(Lout.total, b.pw.Npad, fuse_se), shape_str(Lout.total, b.pw.K, b.pw.N, 0));
+    nn::gemm(c.st, y1, b.dw.Cp, Lout.total, b.pw.K, b.pw.w, b.pw.N, b.pw.Npad, y2, Cpo, 0, epi); }
   return y2;
 }
 

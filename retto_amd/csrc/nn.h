@@ -12,7 +12,7 @@ constexpr int KC = 32;  // K-chunk of the MFMA GEMM / conv kernels (weights are 
 // C[M, ldc] (+coff) = epi(A[M, lda] x W), W packed as [ceil(K/KC)][Npad16][KC].
 void gemm(hipStream_t st, const float* A, int lda, long long M, int K, const float* Wp, int N, int Npad16, float* C,
           int ldc, int coff, const Epilogue& epi);
-const char* gemm_pw_label(long long M, int Npad16);
+const char* gemm_pw_label(long long M, int Npad16, bool a_scale = false);
 extern int g_dw_variant;    // same for dwconv
 extern int g_gemm_variant;  // kernel micro-benchmark hook (0 = production dispatch)
 
@@ -24,7 +24,17 @@ void conv_sp(hipStream_t st, int KH, int KW, const float* x, int ldx, const ImgG
 // Depthwise KxK (K in {3,5}), stride (sh,sw), pad K/2.  Wd packed [K*K][Cp].
 void dwconv(hipStream_t st, int K, int sh, int sw, const float* x, const ImgGeom* gin, const ImgGeom* gout, int n_img,
             int maxHo, int maxWo, int Cp, int C, const float* Wd, const float* bias, int act, int has_lab,
-            float lab_a, float lab_c, float* y);  // Cp = channel pitch (chan_pitch), C = real channels
+            float lab_a, float lab_c, float* y, float* pool = nullptr);  // Cp = channel pitch (chan_pitch), C = real channels
+// Fused squeeze-excite pooling: with `pool` (n_img * chunks * Cp floats, dwconv_pool_layout) the depthwise
+// kernel also writes per-block channel sums of its output; se_fc_from_dw turns them into the scales.
+void dwconv_pool_layout(int sh, int maxHo, int maxWo, int* chunks, int* strip_R);
+void se_fc_from_dw(hipStream_t st, const float* partial, const ImgGeom* geom, int n_img, int chunks, int strip_R, int C,
+                   int Cp, const float* w1, const float* b1, const float* w2, const float* b2, int Cr, float slope,
+                   int residual, float* scale);
+// Row-tile height of the wide GEMM the dispatcher picks for (M, Npad16), 0 when it picks the narrow
+// kernel: Epilogue::a_scale (squeeze-excite scale folded into the A staging) needs a wide tile and
+// every image at least that many rows.
+int gemm_tile_rows(long long M, int Npad16);
 
 // Fused stride-1 depthwise KxK (+bias, act, LAB) -> 1x1 conv (+epilogue); see k_dwpw.
 void dwpw(hipStream_t st, int K, const float* x, const ImgGeom* geom, int n_img, int maxH, int maxW, int Cp,

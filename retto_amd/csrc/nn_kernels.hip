@@ -144,15 +144,17 @@ __global__ __launch_bounds__(256) void k_gemm(const float* __restrict__ A, int l
 // each activation row once (the narrow kernel re-reads A once per 128 columns), WM x WN waves,
 // and the next K-slab is prefetched into registers while the MFMAs of the current one run.
 // ---------------------------------------------------------------------------
-template <int MT, int NT, int WM, int WN, int RASTER = 0, int DBG = 0>
+template <int MT, int NT, int WM, int WN, int RASTER = 0, int DBG = 0, int ASC = 0>
 __global__ __launch_bounds__(64 * WM * WN) void k_gemm_wide(const float* __restrict__ A, int lda, long long M, int K,
                                                              const float* __restrict__ Wp, int N, int Npad,
                                                              float* __restrict__ C, int ldc, int coff, Epilogue epi) {
   constexpr int NTHR = 64 * WM * WN, BM = 16 * MT * WM, BN = 16 * NT * WN;
   constexpr int A_LD = (BM * 8 + NTHR - 1) / NTHR, W_LD = (BN * 8 + NTHR - 1) / NTHR;
-  __shared__ __attribute__((aligned(16))) float lds[(BM + BN) * LROW];
+  constexpr int SC_MAXK = 512;  // ASC: the squeeze-excite scales of the (at most 2) images under this row tile
+  __shared__ __attribute__((aligned(16))) float lds[(BM + BN) * LROW + (ASC ? 2 * SC_MAXK : 0)];
   float* xs = lds;
   float* ws = lds + BM * LROW;
+  float* sc = lds + (BM + BN) * LROW;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, q = lane >> 4;
   const int wm = wave / WN, wn = wave % WN;
   long long mb = blockIdx.x;
@@ -193,11 +195,32 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm_wide(const float* __restr
         pw[i] = *reinterpret_cast<const f32x4*>(Wp + ((long long)kc * Npad + n0 + row) * KC + c4 * 4);
     }
   };
-  auto stash = [&]() {
+  int sc_bnd = 0;  // tile-relative row where the second image starts (>= BM: none)
+  if (ASC) {
+    const int img = epi.a_tab[2 * mb];
+    const long long sc_boundary = epi.a_tab[2 * mb + 1];
+    sc_bnd = (int)min((long long)BM, sc_boundary - m0);
+    for (int i = tid; i < 2 * (K >> 2); i += NTHR) {
+      const int which = i >= (K >> 2), k4 = i - which * (K >> 2);
+      // (the second image only exists when the boundary falls inside the tile)
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (!which || sc_boundary < m0 + BM) v = *reinterpret_cast<const f32x4*>(epi.a_scale + (long long)(img + which) * epi.ld_scale + k4 * 4);
+      *reinterpret_cast<f32x4*>(sc + which * SC_MAXK + k4 * 4) = v;
+    }
+    __syncthreads();
+  }
+  auto stash = [&](int kc) {
 #pragma unroll
     for (int i = 0; i < A_LD; i++) {
       int idx = tid + NTHR * i, row = idx >> 3, c4 = idx & 7;
-      if (row < BM) *reinterpret_cast<f32x4*>(xs + row * LROW + c4 * 4) = pa[i];
+      if (row < BM) {
+        f32x4 v = pa[i];
+        if (ASC) {
+          const int k = kc * KC + c4 * 4;
+          if (k < K) v *= *reinterpret_cast<const f32x4*>(sc + (row >= sc_bnd ? SC_MAXK : 0) + k);
+        }
+        *reinterpret_cast<f32x4*>(xs + row * LROW + c4 * 4) = v;
+      }
     }
 #pragma unroll
     for (int i = 0; i < W_LD; i++) {
@@ -206,7 +229,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm_wide(const float* __restr
     }
   };
   fetch(0);
-  stash();
+  stash(0);
   __syncthreads();
   for (int kc = 0; kc < nkc; kc++) {
     if (DBG == 0 && kc + 1 < nkc) fetch(kc + 1);
@@ -236,7 +259,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm_wide(const float* __restr
             acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[g][nt][s], a[g][mt][s], acc[mt][nt], 0, 0, 0);
     }
     if (DBG != 2) __syncthreads();
-    if (DBG == 0 && kc + 1 < nkc) { stash(); __syncthreads(); }
+    if (DBG == 0 && kc + 1 < nkc) { stash(kc + 1); __syncthreads(); }
     if (DBG == 1) __syncthreads();
   }
   const int nstore = (N + 3) & ~3;
@@ -771,7 +794,8 @@ static int gemm_dispatch(long long M, int Npad16) {
 }
 // Profiler label of a pointwise-conv GEMM: family + the kernel symbol the dispatcher picks, so the
 // per-kernel numbers of bench.py can be compared with rocprofv3's kernel stats one to one.
-const char* gemm_pw_label(long long M, int Npad16) {
+const char* gemm_pw_label(long long M, int Npad16, bool a_scale) {
+  if (a_scale && !g_gemm_variant) return gemm_dispatch(M, Npad16) == 8 ? "gemm_pw/k_gemm_wide<2,4,4,2>+se" : "gemm_pw/k_gemm_wide<2,5,4,3>+se";
   switch (g_gemm_variant ? -1 : gemm_dispatch(M, Npad16)) {
     case 15: return "gemm_pw/k_gemm_wide<4,5,4,3>";
     case 10: return "gemm_pw/k_gemm_wide<2,5,4,3>";
@@ -781,11 +805,32 @@ const char* gemm_pw_label(long long M, int Npad16) {
   }
 }
 
+int gemm_tile_rows(long long M, int Npad16) {
+  switch (g_gemm_variant ? -1 : gemm_dispatch(M, Npad16)) {
+    case 15: case 10: case 8: return 128;  // (a_scale runs the 256 x 240 shapes on the 128 x 240 tile)
+    default: return 0;
+  }
+}
+
 void gemm(hipStream_t st, const float* A, int lda, long long M, int K, const float* Wp, int N, int Npad16, float* C,
           int ldc, int coff, const Epilogue& epi) {
   if (M <= 0) return;
   int v = g_gemm_variant;
   if (v == 0) v = gemm_dispatch(M, Npad16);
+  if (epi.a_scale) {  // squeeze-excite scale folded into the A staging: wide tiles only (gemm_tile_rows)
+    if (K > 512 || !epi.a_tab) throw RtError(8, "gemm: a_scale needs K <= 512 and a row-tile table");
+    if (v == 15) v = 10;  // the 256-row tile has no registers to spare for the scaling (spills): 128 x 240 measured faster
+    if (v == 10) {
+      dim3 grid((unsigned)((M + 127) / 128), (unsigned)((Npad16 + 239) / 240));
+      hipLaunchKernelGGL((k_gemm_wide<2, 5, 4, 3, 0, 0, 1>), grid, dim3(768), 0, st, A, lda, M, K, Wp, N, Npad16, C, ldc, coff, epi);
+    } else if (v == 8) {
+      dim3 grid((unsigned)((M + 127) / 128), (unsigned)((Npad16 + 127) / 128));
+      hipLaunchKernelGGL((k_gemm_wide<2, 4, 4, 2, 0, 0, 1>), grid, dim3(512), 0, st, A, lda, M, K, Wp, N, Npad16, C, ldc, coff, epi);
+    } else {
+      throw RtError(8, "gemm: a_scale is only implemented for the wide tiles");
+    }
+    return;
+  }
   if (v == 13 || v == 14) {
     if (v == 13) {
       long long nt = ((M + 127) / 128) * ((Npad16 + 239) / 240);
@@ -1136,11 +1181,12 @@ __global__ __launch_bounds__(256) void k_dwconv_lds(const float* __restrict__ x,
 // 128 VGPRs (4 waves/SIMD): +15 % over 3 waves at C = 480.  Measured and rejected: lane groups
 // spanning whole pixels with all the weights in LDS (1.2-1.5x slower), one-row-ahead register
 // prefetch (hipcc hoists every load: spills).
-template <int K, int R, int SH, int SW>
+template <int K, int R, int SH, int SW, int POOL>
 __global__ __launch_bounds__(256, 4) void k_dwconv_rows(const float* __restrict__ x, const ImgGeom* __restrict__ gin,
                                                      const ImgGeom* __restrict__ gout, int Cp, int C,
                                                      const float* __restrict__ Wd, const float* __restrict__ bias, int act,
-                                                     int has_lab, float lab_a, float lab_c, float* __restrict__ y) {
+                                                     int has_lab, float lab_a, float lab_c, float* __restrict__ y,
+                                                     float* __restrict__ pool) {
   constexpr int NV = 3 * SW + K;       // input columns feeding 4 output pixels
   constexpr int NI = (R - 1) * SH + K; // input rows feeding R output rows
   __shared__ __attribute__((aligned(16))) float wl[K * K * 32];
@@ -1158,7 +1204,9 @@ __global__ __launch_bounds__(256, 4) void k_dwconv_rows(const float* __restrict_
   __syncthreads();
   const int c4 = tid & 7, ch = cbase + c4 * 4;
   const long long strip = (long long)blockIdx.x * 32 + (tid >> 3);
-  if (ch >= Cp || strip >= (long long)strips_x * strips_y) return;
+  const bool active = ch < Cp && strip < (long long)strips_x * strips_y;
+  f32x4 psum;  // squeeze-excite pooling: this thread's share of the channel sums (summed only in the store loop)
+  if (active) {
   const int oy0 = (int)(strip % strips_y) * R, ox0 = (int)(strip / strips_y) * 4;  // column-major
   const f32x4 b = *reinterpret_cast<const f32x4*>(bias + ch);
   f32x4 acc[R][4];
@@ -1193,6 +1241,7 @@ __global__ __launch_bounds__(256, 4) void k_dwconv_rows(const float* __restrict_
       }
     }
   }
+  f32x4 ps = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int r = 0; r < R; r++) {
     const int oy = oy0 + r;
@@ -1208,6 +1257,26 @@ __global__ __launch_bounds__(256, 4) void k_dwconv_rows(const float* __restrict_
         o[e] = (ch + e < C) ? t : 0.f;  // pitch padding (chan_pitch) holds zeros whatever the input padding held
       }
       *reinterpret_cast<f32x4*>(y + (go.off + (long long)oy * go.W + ox0 + j) * Cp + ch) = o;
+      if (POOL) ps += o;
+    }
+  }
+  psum = ps;
+  } else {
+    psum = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  if (POOL) {  // fixed-order reduction: 8 strips of a wave by shuffles, 4 waves through LDS -> pool[image][block][channel]
+    __shared__ __attribute__((aligned(16))) float red[4 * 8 * 4];
+#pragma unroll
+    for (int d = 8; d < 64; d <<= 1)
+#pragma unroll
+      for (int e = 0; e < 4; e++) psum[e] += __shfl_xor(psum[e], d);
+    if ((tid & 63) < 8) *reinterpret_cast<f32x4*>(red + ((tid >> 6) * 8 + (tid & 7)) * 4) = psum;
+    __syncthreads();
+    if (tid < 8 && cbase + tid * 4 < Cp) {
+      f32x4 t = *reinterpret_cast<const f32x4*>(red + tid * 4);
+#pragma unroll
+      for (int w = 1; w < 4; w++) t += *reinterpret_cast<const f32x4*>(red + (w * 8 + tid) * 4);
+      *reinterpret_cast<f32x4*>(pool + ((long long)blockIdx.y * gridDim.x + blockIdx.x) * Cp + cbase + tid * 4) = t;
     }
   }
 }
@@ -1217,14 +1286,17 @@ int g_fuse_dwpw = 0;  // experimental: correct, but producer-latency bound (see 
 
 void dwconv(hipStream_t st, int K, int sh, int sw, const float* x, const ImgGeom* gin, const ImgGeom* gout, int n_img,
             int maxHo, int maxWo, int Cp, int C, const float* Wd, const float* bias, int act, int has_lab, float lab_a,
-            float lab_c, float* y) {
+            float lab_c, float* y, float* pool) {
   if (n_img <= 0) return;
   if ((K == 3 || K == 5) && sh >= 1 && sh <= 2 && sw >= 1 && sw <= 2 && (g_dw_variant == 0 || g_dw_variant == 4)) {
     const int R = (sh == 1 && g_dw_variant != 4) ? 4 : 2;  // input rows streamed: stride 1 -> R+K-1, stride 2 -> 2R+K-2
     long long strips = (long long)((maxWo + 3) / 4) * ((maxHo + R - 1) / R);
     dim3 grid((unsigned)((strips + 31) / 32), n_img, (Cp + 31) / 32);
-#define RT_DWR(KK, RR, SH_, SW_) \
-  hipLaunchKernelGGL((k_dwconv_rows<KK, RR, SH_, SW_>), grid, dim3(256), 0, st, x, gin, gout, Cp, C, Wd, bias, act, has_lab, lab_a, lab_c, y)
+#define RT_DWR(KK, RR, SH_, SW_)                                                                                              \
+  do {                                                                                                                       \
+    if (pool) hipLaunchKernelGGL((k_dwconv_rows<KK, RR, SH_, SW_, 1>), grid, dim3(256), 0, st, x, gin, gout, Cp, C, Wd, bias, act, has_lab, lab_a, lab_c, y, pool); \
+    else hipLaunchKernelGGL((k_dwconv_rows<KK, RR, SH_, SW_, 0>), grid, dim3(256), 0, st, x, gin, gout, Cp, C, Wd, bias, act, has_lab, lab_a, lab_c, y, pool); \
+  } while (0)
     const int code = (K == 5 ? 4 : 0) + (sh == 2 ? 2 : 0) + (sw == 2 ? 1 : 0);
     switch (code) {
       case 0: if (R == 4) RT_DWR(3, 4, 1, 1); else RT_DWR(3, 2, 1, 1); break; case 1: if (R == 4) RT_DWR(3, 4, 1, 2); else RT_DWR(3, 2, 1, 2); break;
@@ -1235,7 +1307,7 @@ void dwconv(hipStream_t st, int K, int sh, int sw, const float* x, const ImgGeom
 #undef RT_DWR
     return;
   }
-  if (Cp - C >= 4) throw RtError(8, "dwconv: only the row-streaming kernel supports padded channel pitches");
+  if (Cp - C >= 4 || pool) throw RtError(8, "dwconv: only the row-streaming kernel supports padded channel pitches / fused pooling");
   if (sh == 1 && sw == 1 && (K == 3 || K == 5) && g_dw_variant == 3 && Cp >= 16) {  // measured slower than the register strip (tools/), kept for A/B
     const bool c8 = Cp >= 32;
     const int TH = c8 ? 4 : 8, CB = c8 ? 32 : 16;
@@ -1378,13 +1450,16 @@ __global__ __launch_bounds__(256) void k_se_fc(const float* __restrict__ partial
                                                int chunks_alloc, int C, int Cp, const float* __restrict__ w1,
                                                const float* __restrict__ b1, const float* __restrict__ w2,
                                                const float* __restrict__ b2, int Cr, float slope, int residual,
-                                               float* __restrict__ scale) {
+                                               float* __restrict__ scale, int strip_R) {
   extern __shared__ float sm[];  // mean[Cp] + hid[Cr]
   float* mean = sm;
   float* hid = sm + Cp;
   const ImgGeom g = geom[blockIdx.x];
   const long long npix = (long long)g.H * g.W;
-  const int chunks = (int)((npix + POOL_PIX - 1) / POOL_PIX);
+  // partial sums come from k_pool_partial (POOL_PIX pixels each) or, strip_R > 0, from the blocks of the
+  // depthwise kernel that produced the tensor (32 strips of strip_R x 4 pixels each)
+  const int chunks = strip_R > 0 ? (((g.W + 3) >> 2) * ((g.H + strip_R - 1) / strip_R) + 31) / 32
+                                 : (int)((npix + POOL_PIX - 1) / POOL_PIX);
   const float inv = 1.0f / (float)npix;
   for (int c = threadIdx.x; c < Cp; c += 256) {
     float s = 0.f;
@@ -1421,7 +1496,19 @@ void se_scale(hipStream_t st, const float* x, const ImgGeom* geom, int n_img, lo
   int chunks = pool_chunks(max_pix);
   hipLaunchKernelGGL(k_pool_partial, dim3(chunks, n_img), dim3(256), 0, st, x, geom, Cp, chunks, partial);
   hipLaunchKernelGGL(k_se_fc, dim3(n_img), dim3(256), (Cp + Cr + 4) * sizeof(float), st, partial, geom, chunks, C, Cp,
-                     w1, b1, w2, b2, Cr, slope, residual, scale);
+                     w1, b1, w2, b2, Cr, slope, residual, scale, 0);
+}
+void dwconv_pool_layout(int sh, int maxHo, int maxWo, int* chunks, int* strip_R) {
+  const int R = (sh == 1 && g_dw_variant != 4) ? 4 : 2;
+  *strip_R = R;
+  *chunks = (int)(((long long)((maxWo + 3) / 4) * ((maxHo + R - 1) / R) + 31) / 32);
+}
+void se_fc_from_dw(hipStream_t st, const float* partial, const ImgGeom* geom, int n_img, int chunks, int strip_R, int C,
+                   int Cp, const float* w1, const float* b1, const float* w2, const float* b2, int Cr, float slope,
+                   int residual, float* scale) {
+  if (n_img <= 0) return;
+  hipLaunchKernelGGL(k_se_fc, dim3(n_img), dim3(256), (Cp + Cr + 4) * sizeof(float), st, partial, geom, chunks, C, Cp,
+                     w1, b1, w2, b2, Cr, slope, residual, scale, strip_R);
 }
 void global_mean(hipStream_t st, const float* x, const ImgGeom* geom, int n_img, long long max_pix, int Cp,
                  float* partial, float* out) {
@@ -1430,7 +1517,7 @@ void global_mean(hipStream_t st, const float* x, const ImgGeom* geom, int n_img,
   hipLaunchKernelGGL(k_pool_partial, dim3(chunks, n_img), dim3(256), 0, st, x, geom, Cp, chunks, partial);
   hipLaunchKernelGGL(k_se_fc, dim3(n_img), dim3(256), (Cp + 4) * sizeof(float), st, partial, geom, chunks, Cp, Cp,
                      (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, 0,
-                     0.f, 0, out);
+                     0.f, 0, out, 0);
 }
 
 __global__ __launch_bounds__(256) void k_scale_channels(float* __restrict__ x, const ImgGeom* __restrict__ geom, int Cp,

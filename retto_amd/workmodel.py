@@ -18,10 +18,14 @@ def _down(v: int, s: int) -> int:
     return (v - 1) // s + 1
 
 
-def gemm_pw_label(M: int, N: int) -> str:
+def gemm_pw_label(M: int, N: int, se: bool = False) -> str:
     """Mirror of nn::gemm_pw_label (retto_amd/csrc/nn_kernels.hip): which kernel symbol the
-    dispatcher picks for a pointwise conv of M rows and N output channels."""
+    dispatcher picks for a pointwise conv of M rows and N output channels.  `se`: the block has a
+    squeeze-excite whose scale is folded into the GEMM's A staging (wide tiles, every image
+    >= 128 rows at that level -- true for the bench workloads)."""
     npad = (N + 15) // 16 * 16
+    if se and M >= 8192 and npad >= 128:
+        return "gemm_pw/k_gemm_wide<2,5,4,3>+se" if npad % 240 == 0 and M >= 16384 else "gemm_pw/k_gemm_wide<2,4,4,2>+se"
     if npad % 240 == 0 and M >= 131072:
         return "gemm_pw/k_gemm_wide<4,5,4,3>"
     if npad % 240 == 0 and M >= 16384:
@@ -67,12 +71,9 @@ def det_work(pages: Iterable[Tuple[int, int]]) -> Dict[str, Dict[str, float]]:
         for name, k, cin, cout, sh, sw, se in synth.DET_BLOCKS:
             ho, wo = _down(h, sh), _down(ww, sw)
             add("dwconv%d" % k, (h * ww + ho * wo) * cin * F + k * k * cin * F, 2 * ho * wo * cin * k * k)
-            if se:
-                add("se_pool_fc", ho * wo * cin * F)
-                add("scale_channels", 2 * ho * wo * cin * F)
             scale = (ho * wo) / float(H * W)
             m_group = int(round(sum(gh * gw for gh, gw in grp) * scale))
-            add(gemm_pw_label(m_group, cout), ho * wo * (cin + cout) * F + cin * cout * F, 2 * ho * wo * cin * cout)
+            add(gemm_pw_label(m_group, cout, se), ho * wo * (cin + cout) * F + cin * cout * F, 2 * ho * wo * cin * cout)
             h, ww = ho, wo
             for j, (tn, tc, oc) in enumerate(synth.DET_TAPS):
                 if tn == name:
@@ -114,10 +115,8 @@ def rec_work(widths: Iterable[int], classes: int = synth.REC_CLASSES) -> Dict[st
         for name, k, cin, cout, sh, sw, se in synth.REC_BLOCKS:
             ho, wo = _down(h, sh), _down(ww, sw)
             add("dwconv%d" % k, (h * ww + ho * wo) * cin * F + k * k * cin * F, 2 * ho * wo * cin * k * k)
-            if se:
-                add("se_pool_fc", ho * wo * cin * F); add("scale_channels", 2 * ho * wo * cin * F)
             m_group = int(round(grp_px * (ho * wo) / float(H * W)))
-            add(gemm_pw_label(m_group, cout), ho * wo * (cin + cout) * F + cin * cout * F, 2 * ho * wo * cin * cout)
+            add(gemm_pw_label(m_group, cout, se), ho * wo * (cin + cout) * F + cin * cout * F, 2 * ho * wo * cin * cout)
             h, ww = ho, wo
         T = (ww - 2) // 2 + 1
         add("avgpool", (h * ww + T) * 480 * F)
