@@ -32,6 +32,12 @@ struct Epilogue {
   const float* a_scale = nullptr;
   int ld_scale = 0;
   const int* a_tab = nullptr;
+  // CTC head: instead of storing the logits tile, the wide GEMM leaves per (row, column tile) the
+  // maximum, its column and sum(exp(logit - max)); nn::argmax_merge folds the tiles of a row.
+  float* am_max = nullptr;
+  int* am_idx = nullptr;
+  float* am_sum = nullptr;
+  int am_tiles = 0;
 };
 
 struct RtError : std::runtime_error {

@@ -379,7 +379,7 @@ int RecNet::tokens_for_width(int w) {
   return wc >= 2 ? (wc - 2) / 2 + 1 : 0;
 }
 
-float* RecNet::run(RunCtx& c, const float* x, Level& L0, Level& Lt) {
+float* RecNet::run(RunCtx& c, const float* x, Level& L0, Level& Lt, int* idx_out, float* prob_out) {
   for (auto& g : L0.h) if (g.H != 48 || g.W < 8) throw RtError(3, "rec input must be 48 high and at least 8 wide");
   Level La = down_level(L0, 2, 2);
   std::vector<Level> lv; lv.reserve(16);
@@ -441,6 +441,19 @@ float* RecNet::run(RunCtx& c, const float* x, Level& L0, Level& Lt) {
   float* z5 = c.arena->alloc<float>((size_t)rows * D);
   { ProfScope ps(c.prof, c.st, "gemm_neck");
     nn::gemm(c.st, z4, 60, rows, conv1x1_.K, conv1x1_.w, D, conv1x1_.Npad, z5, D, 0, make_epi(conv1x1_, ACT_SWISH)); }
+  if (idx_out) {
+    const int tiles = nn::gemm_argmax_tiles(fc_.Npad);
+    Epilogue e = make_epi(fc_, ACT_NONE);
+    e.am_max = c.arena->alloc<float>((size_t)rows * tiles);
+    e.am_sum = c.arena->alloc<float>((size_t)rows * tiles);
+    e.am_idx = c.arena->alloc<int>((size_t)rows * tiles);
+    e.am_tiles = tiles;
+    { ProfScope ps(c.prof, c.st, "gemm_ctc_fc", shape_str(rows, fc_.K, classes_, 1));
+      nn::gemm(c.st, z5, D, rows, fc_.K, fc_.w, classes_, fc_.Npad, nullptr, 0, 0, e); }
+    { ProfScope ps(c.prof, c.st, "ctc_argmax");
+      nn::argmax_merge(c.st, e.am_max, e.am_idx, e.am_sum, tiles, rows, idx_out, prob_out); }
+    return nullptr;
+  }
   const int ld = logits_ld();
   float* logits = c.arena->alloc<float>((size_t)rows * ld);
   { ProfScope ps(c.prof, c.st, "gemm_ctc_fc", shape_str(rows, fc_.K, classes_, 0));

@@ -84,7 +84,9 @@ class RecNet {
   int logits_ld() const { return round_up(classes_, 4); }
   // x: f32 NHWC pitch-4 (R,G,B,0), level L0 = lines of height 48. Returns logits
   // [rows, logits_ld()] with rows = sum of T_i; Lt (out) is the token level (H=1, W=T_i).
-  float* run(RunCtx& c, const float* x, Level& L0, Level& Lt);
+  // Returns the logits [Lt.total, logits_ld()], or -- with idx_out / prob_out (Lt.total each) -- runs the fused
+  // CTC head (argmax + softmax probability of the argmax per time step, no logits in HBM) and returns nullptr.
+  float* run(RunCtx& c, const float* x, Level& L0, Level& Lt, int* idx_out = nullptr, float* prob_out = nullptr);
   static int tokens_for_width(int w);
  private:
   WeightStore ws_;

@@ -35,6 +35,12 @@ void se_fc_from_dw(hipStream_t st, const float* partial, const ImgGeom* geom, in
 // kernel: Epilogue::a_scale (squeeze-excite scale folded into the A staging) needs a wide tile and
 // every image at least that many rows.
 int gemm_tile_rows(long long M, int Npad16);
+// Fused CTC head: gemm() with Epilogue::am_* set (am_tiles = gemm_argmax_tiles(Npad16), buffers of
+// M * am_tiles elements) leaves softmax statistics per column tile; argmax_merge gives, per row, the
+// argmax over the N logits and softmax(logits)[argmax] -- the [M, 6625] logits never reach HBM.
+int gemm_argmax_tiles(int Npad16);
+void argmax_merge(hipStream_t st, const float* pm, const int* pi, const float* ps, int tiles, long long rows, int* idx,
+                  float* prob);
 
 // Fused stride-1 depthwise KxK (+bias, act, LAB) -> 1x1 conv (+epilogue); see k_dwpw.
 void dwpw(hipStream_t st, int K, const float* x, const ImgGeom* geom, int n_img, int maxH, int maxW, int Cp,

@@ -144,7 +144,7 @@ __global__ __launch_bounds__(256) void k_gemm(const float* __restrict__ A, int l
 // each activation row once (the narrow kernel re-reads A once per 128 columns), WM x WN waves,
 // and the next K-slab is prefetched into registers while the MFMAs of the current one run.
 // ---------------------------------------------------------------------------
-template <int MT, int NT, int WM, int WN, int RASTER = 0, int DBG = 0, int ASC = 0>
+template <int MT, int NT, int WM, int WN, int RASTER = 0, int DBG = 0, int ASC = 0, int EPIM = 0>
 __global__ __launch_bounds__(64 * WM * WN) void k_gemm_wide(const float* __restrict__ A, int lda, long long M, int K,
                                                              const float* __restrict__ Wp, int N, int Npad,
                                                              float* __restrict__ C, int ldc, int coff, Epilogue epi) {
@@ -261,6 +261,63 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm_wide(const float* __restr
     if (DBG != 2) __syncthreads();
     if (DBG == 0 && kc + 1 < nkc) { stash(kc + 1); __syncthreads(); }
     if (DBG == 1) __syncthreads();
+  }
+  if (EPIM) {
+    // Softmax statistics of this column tile, per row: (max, first column of the max, sum exp(v - max)).
+    // In-lane over the lane's 4*NT columns (ascending), then the 4 lane quarters (ascending columns),
+    // then the WN waves through LDS -- fixed order, lowest column wins ties like the reference's argmax.
+    float* rm = lds;
+    float* rs = lds + BM * WN;
+    int* ri = reinterpret_cast<int*>(lds + 2 * BM * WN);
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++) {
+      float m = -INFINITY, sum = 0.f;
+      int mi = 0x7fffffff;
+#pragma unroll
+      for (int nt = 0; nt < NT; nt++) {
+        if (nt >= nt_valid) continue;
+        const int col = n0 + (wn * NT + nt) * 16 + q * 4;
+        f32x4 bias = {0.f, 0.f, 0.f, 0.f};
+        if (epi.bias) bias = *reinterpret_cast<const f32x4*>(epi.bias + col);
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          if (col + j >= N) continue;
+          const float v = acc[mt][nt][j] + bias[j];
+          if (v > m) { sum = sum * __expf(m - v) + 1.0f; m = v; mi = col + j; }
+          else sum += __expf(v - m);
+        }
+      }
+#pragma unroll
+      for (int d = 16; d < 64; d <<= 1) {
+        const float om = __shfl_xor(m, d), os = __shfl_xor(sum, d);
+        const int oi = __shfl_xor(mi, d);
+        const float nm = fmaxf(m, om);
+        sum = sum * (m == nm ? 1.0f : __expf(m - nm)) + os * (om == nm ? 1.0f : __expf(om - nm));
+        if (om > m || (om == m && oi < mi)) mi = oi;
+        m = nm;
+      }
+      if (q == 0) {
+        const int row = (wm * MT + mt) * 16 + r;
+        rm[row * WN + wn] = m; rs[row * WN + wn] = sum; ri[row * WN + wn] = mi;
+      }
+    }
+    __syncthreads();
+    for (int row = tid; row < BM; row += NTHR) {
+      if (m0 + row >= M) break;
+      float m = rm[row * WN], sum = rs[row * WN];
+      int mi = ri[row * WN];
+      for (int w = 1; w < WN; w++) {
+        const float om = rm[row * WN + w], os = rs[row * WN + w];
+        const int oi = ri[row * WN + w];
+        const float nm = fmaxf(m, om);
+        sum = sum * (m == nm ? 1.0f : __expf(m - nm)) + os * (om == nm ? 1.0f : __expf(om - nm));
+        if (om > m || (om == m && oi < mi)) mi = oi;
+        m = nm;
+      }
+      const long long o = (m0 + row) * epi.am_tiles + nb;
+      epi.am_max[o] = m; epi.am_sum[o] = sum; epi.am_idx[o] = mi;
+    }
+    return;
   }
   const int nstore = (N + 3) & ~3;
 #pragma unroll
@@ -805,6 +862,31 @@ const char* gemm_pw_label(long long M, int Npad16, bool a_scale) {
   }
 }
 
+int gemm_argmax_tiles(int Npad16) { return (Npad16 + 127) / 128; }
+
+// one thread per row: fold the column tiles in ascending order -> argmax (first maximum) and softmax(max) = 1 / sum
+__global__ __launch_bounds__(256) void k_argmax_merge(const float* __restrict__ pm, const int* __restrict__ pi,
+                                                      const float* __restrict__ ps, int tiles, long long rows,
+                                                      int* __restrict__ idx, float* __restrict__ prob) {
+  const long long row = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (row >= rows) return;
+  float m = -INFINITY;
+  int mi = 0x7fffffff;
+  for (int t = 0; t < tiles; t++) {
+    const float v = pm[row * tiles + t];
+    if (v > m) { m = v; mi = pi[row * tiles + t]; }
+  }
+  float sum = 0.f;
+  for (int t = 0; t < tiles; t++) sum += ps[row * tiles + t] * expf(pm[row * tiles + t] - m);
+  idx[row] = mi;
+  prob[row] = 1.0f / sum;
+}
+void argmax_merge(hipStream_t st, const float* pm, const int* pi, const float* ps, int tiles, long long rows, int* idx,
+                  float* prob) {
+  if (rows <= 0) return;
+  hipLaunchKernelGGL(k_argmax_merge, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, pm, pi, ps, tiles, rows, idx, prob);
+}
+
 int gemm_tile_rows(long long M, int Npad16) {
   switch (g_gemm_variant ? -1 : gemm_dispatch(M, Npad16)) {
     case 15: case 10: case 8: return 128;  // (a_scale runs the 256 x 240 shapes on the 128 x 240 tile)
@@ -817,6 +899,12 @@ void gemm(hipStream_t st, const float* A, int lda, long long M, int K, const flo
   if (M <= 0) return;
   int v = g_gemm_variant;
   if (v == 0) v = gemm_dispatch(M, Npad16);
+  if (epi.am_max) {  // CTC head: softmax statistics per 128-column tile instead of the logits (argmax_merge folds them)
+    if (epi.am_tiles != (Npad16 + 127) / 128) throw RtError(8, "gemm: am_tiles must be gemm_argmax_tiles(Npad16)");
+    dim3 grid((unsigned)((M + 127) / 128), (unsigned)((Npad16 + 127) / 128));
+    hipLaunchKernelGGL((k_gemm_wide<2, 4, 4, 2, 0, 0, 0, 1>), grid, dim3(512), 0, st, A, lda, M, K, Wp, N, Npad16, C, ldc, coff, epi);
+    return;
+  }
   if (epi.a_scale) {  // squeeze-excite scale folded into the A staging: wide tiles only (gemm_tile_rows)
     if (K > 512 || !epi.a_tab) throw RtError(8, "gemm: a_scale needs K <= 512 and a row-tile table");
     if (v == 15) v = 10;  // the 256-row tile has no registers to spare for the scaling (spills): 128 x 240 measured faster

@@ -625,10 +625,9 @@ rt_results* rt_session::run_pages(const uint8_t* const* rgb, const int* hs, cons
         pp::resize_norm(st, dl, ln, rh, maxW, pool, 0, x, d_flags); }
       Level L0 = make_level(hw), Lt;
       RunCtx c = ctx(&scratch);
-      float* logits = rec->run(c, x, L0, Lt);
+      // (the token count per line only depends on the widths, so the offsets are known before the net runs)
+      rec->run(c, x, L0, Lt, d_idx + tok_off[l0], d_prob + tok_off[l0]);  // fused CTC head: logits never reach HBM
       if (Lt.total != tok_off[l1] - tok_off[l0]) throw RtError(RT_ERR_SHAPE, "token count mismatch");
-      { ProfScope ps(&prof, st, "ctc_argmax");
-        nn::argmax_prob_rows(st, logits, rec->logits_ld(), Lt.total, rec->classes(), d_idx + tok_off[l0], d_prob + tok_off[l0]); }
       { ProfScope ps(&prof, st, "ctc_decode");
         pp::ctc_decode(st, d_idx + tok_off[l0], d_prob + tok_off[l0], Lt.d, ln, d_tok + tok_off[l0], d_ntok + l0, d_rscore + l0); }
       l0 = l1;

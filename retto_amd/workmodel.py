@@ -126,8 +126,9 @@ def rec_work(widths: Iterable[int], classes: int = synth.REC_CLASSES) -> Dict[st
             add("gemm_neck", cnt * (T * (cin + cout) * F + cin * cout * F), cnt * 2 * T * cin * cout)
         add("attention", 2 * T * (360 + 120) * F, 2 * 2 * 2 * T * T * 120)
         add("layernorm", 5 * 3 * T * 120 * F)
-        add("gemm_ctc_fc", T * (120 + classes) * F + 120 * classes * F, 2 * T * 120 * classes)
-        add("ctc_argmax", T * classes * F)
+        tiles = ((classes + 15) // 16 * 16 + 127) // 128  # fused CTC head: softmax statistics per 128-column tile, no logits
+        add("gemm_ctc_fc", T * 120 * F + 120 * classes * F + T * tiles * 12, 2 * T * 120 * classes)
+        add("ctc_argmax", T * tiles * 12 + T * 8)
     return dict(w)
 
 
