@@ -144,17 +144,17 @@ __global__ __launch_bounds__(256) void k_gemm(const float* __restrict__ A, int l
 // each activation row once (the narrow kernel re-reads A once per 128 columns), WM x WN waves,
 // and the next K-slab is prefetched into registers while the MFMAs of the current one run.
 // ---------------------------------------------------------------------------
-template <int MT, int NT, int WM, int WN, int RASTER = 0, int DBG = 0, int ASC = 0, int EPIM = 0>
+template <int MT, int NT, int WM, int WN, int RASTER = 0, int DBG = 0, int ASC = 0, int EPIM = 0, int DBUF = 0>
 __global__ __launch_bounds__(64 * WM * WN) void k_gemm_wide(const float* __restrict__ A, int lda, long long M, int K,
                                                              const float* __restrict__ Wp, int N, int Npad,
                                                              float* __restrict__ C, int ldc, int coff, Epilogue epi) {
   constexpr int NTHR = 64 * WM * WN, BM = 16 * MT * WM, BN = 16 * NT * WN;
   constexpr int A_LD = (BM * 8 + NTHR - 1) / NTHR, W_LD = (BN * 8 + NTHR - 1) / NTHR;
   constexpr int SC_MAXK = 512;  // ASC: the squeeze-excite scales of the (at most 2) images under this row tile
-  __shared__ __attribute__((aligned(16))) float lds[(BM + BN) * LROW + (ASC ? 2 * SC_MAXK : 0)];
-  float* xs = lds;
-  float* ws = lds + BM * LROW;
-  float* sc = lds + (BM + BN) * LROW;
+  // DBUF: two LDS stages -- slab kc+1 is written while other waves still multiply slab kc, one barrier per slab
+  constexpr int STAGE = (BM + BN) * LROW;
+  __shared__ __attribute__((aligned(16))) float lds[(DBUF ? 2 : 1) * STAGE + (ASC ? 2 * SC_MAXK : 0)];
+  float* sc = lds + (DBUF ? 2 : 1) * STAGE;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, q = lane >> 4;
   const int wm = wave / WN, wn = wave % WN;
   long long mb = blockIdx.x;
@@ -210,6 +210,8 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm_wide(const float* __restr
     __syncthreads();
   }
   auto stash = [&](int kc) {
+    float* xs = lds + (DBUF ? (kc & 1) * STAGE : 0);
+    float* ws = xs + BM * LROW;
 #pragma unroll
     for (int i = 0; i < A_LD; i++) {
       int idx = tid + NTHR * i, row = idx >> 3, c4 = idx & 7;
@@ -233,6 +235,8 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm_wide(const float* __restr
   __syncthreads();
   for (int kc = 0; kc < nkc; kc++) {
     if (DBG == 0 && kc + 1 < nkc) fetch(kc + 1);
+    const float* xs = lds + (DBUF ? (kc & 1) * STAGE : 0);
+    const float* ws = xs + BM * LROW;
     const float* xr = xs + (wm * MT * 16 + r) * LROW;
     const float* wr = ws + (wn * NT * 16 + r) * LROW;
     // Fragments of both 16-deep groups are requested up front; the MFMA block of group 0 only
@@ -258,9 +262,14 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm_wide(const float* __restr
           for (int mt = 0; mt < MT; mt++)
             acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[g][nt][s], a[g][mt][s], acc[mt][nt], 0, 0, 0);
     }
-    if (DBG != 2) __syncthreads();
-    if (DBG == 0 && kc + 1 < nkc) { stash(kc + 1); __syncthreads(); }
-    if (DBG == 1) __syncthreads();
+    if (DBUF) {
+      if (kc + 1 < nkc) stash(kc + 1);
+      __syncthreads();
+    } else {
+      if (DBG != 2) __syncthreads();
+      if (DBG == 0 && kc + 1 < nkc) { stash(kc + 1); __syncthreads(); }
+      if (DBG == 1) __syncthreads();
+    }
   }
   if (EPIM) {
     // Softmax statistics of this column tile, per row: (max, first column of the max, sum exp(v - max)).
@@ -955,6 +964,12 @@ void gemm(hipStream_t st, const float* A, int lda, long long M, int K, const flo
     hipLaunchKernelGGL((k_gemm_wide<2, 4, 4, 2>), grid, dim3(512), 0, st, A, lda, M, K, Wp, N, Npad16, C, ldc, coff, epi);
     return;
   }
+  if (v == 16 || v == 17) {
+    dim3 grid((unsigned)((M + (v == 16 ? 255 : 127)) / (v == 16 ? 256 : 128)), (unsigned)((Npad16 + 239) / 240));
+    if (v == 16) hipLaunchKernelGGL((k_gemm_wide<4, 5, 4, 3, 0, 0, 0, 0, 1>), grid, dim3(768), 0, st, A, lda, M, K, Wp, N, Npad16, C, ldc, coff, epi);
+    else hipLaunchKernelGGL((k_gemm_wide<2, 5, 4, 3, 0, 0, 0, 0, 1>), grid, dim3(768), 0, st, A, lda, M, K, Wp, N, Npad16, C, ldc, coff, epi);
+    return;
+  }
   if (v == 15) {
     dim3 grid((unsigned)((M + 255) / 256), (unsigned)((Npad16 + 239) / 240));
     hipLaunchKernelGGL((k_gemm_wide<4, 5, 4, 3>), grid, dim3(768), 0, st, A, lda, M, K, Wp, N, Npad16, C, ldc, coff, epi);
@@ -1280,7 +1295,9 @@ __global__ __launch_bounds__(256, 4) void k_dwconv_rows(const float* __restrict_
   __shared__ __attribute__((aligned(16))) float wl[K * K * 32];
   const ImgGeom gi = gin[blockIdx.y], go = gout[blockIdx.y];
   const int strips_x = (go.W + 3) >> 2, strips_y = (go.H + R - 1) / R;
-  if ((long long)blockIdx.x * 32 >= (long long)strips_x * strips_y) return;
+  // (Measured and rejected: channel slab as the fastest block coordinate -- 1.4x slower at C = 256.)
+  const int bx = blockIdx.x, nbx = gridDim.x;
+  if ((long long)bx * 32 >= (long long)strips_x * strips_y) return;
   const int cbase = blockIdx.z * 32;
   const int tid = threadIdx.x;
   if (tid < K * K * 8) {
@@ -1291,7 +1308,7 @@ __global__ __launch_bounds__(256, 4) void k_dwconv_rows(const float* __restrict_
   }
   __syncthreads();
   const int c4 = tid & 7, ch = cbase + c4 * 4;
-  const long long strip = (long long)blockIdx.x * 32 + (tid >> 3);
+  const long long strip = (long long)bx * 32 + (tid >> 3);
   const bool active = ch < Cp && strip < (long long)strips_x * strips_y;
   f32x4 psum;  // squeeze-excite pooling: this thread's share of the channel sums (summed only in the store loop)
   if (active) {
@@ -1364,12 +1381,19 @@ __global__ __launch_bounds__(256, 4) void k_dwconv_rows(const float* __restrict_
       f32x4 t = *reinterpret_cast<const f32x4*>(red + tid * 4);
 #pragma unroll
       for (int w = 1; w < 4; w++) t += *reinterpret_cast<const f32x4*>(red + (w * 8 + tid) * 4);
-      *reinterpret_cast<f32x4*>(pool + ((long long)blockIdx.y * gridDim.x + blockIdx.x) * Cp + cbase + tid * 4) = t;
+      *reinterpret_cast<f32x4*>(pool + ((long long)blockIdx.y * nbx + bx) * Cp + cbase + tid * 4) = t;
     }
   }
 }
 
-int g_dw_variant = 0;  // 0 = production; 1 = generic; 2 = register strip; 3 = LDS tile; 4 = row streaming
+int g_dw_variant = 0;
+// Output rows per thread of k_dwconv_rows: 4 (stride 1) or 2 (stride 2); 3 for the 3- and 6-row maps of the
+// recognition net's last stages, where 4-row (2-row) strips would leave a quarter of the lanes' rows empty.
+static int dw_strip_rows(int sh, int maxHo) {
+  if (g_dw_variant == 4) return 2;
+  if (maxHo == 6 || (maxHo == 3 && sh == 1)) return 3;  // (stride 2 onto 3 rows: 2-row strips measured faster)
+  return sh == 1 ? 4 : 2;
+}  // 0 = production; 1 = generic; 2 = register strip; 3 = LDS tile; 4 = row streaming
 int g_fuse_dwpw = 0;  // experimental: correct, but producer-latency bound; off by default
 
 void dwconv(hipStream_t st, int K, int sh, int sw, const float* x, const ImgGeom* gin, const ImgGeom* gout, int n_img,
@@ -1377,7 +1401,7 @@ void dwconv(hipStream_t st, int K, int sh, int sw, const float* x, const ImgGeom
             float lab_c, float* y, float* pool) {
   if (n_img <= 0) return;
   if ((K == 3 || K == 5) && sh >= 1 && sh <= 2 && sw >= 1 && sw <= 2 && (g_dw_variant == 0 || g_dw_variant == 4)) {
-    const int R = (sh == 1 && g_dw_variant != 4) ? 4 : 2;  // input rows streamed: stride 1 -> R+K-1, stride 2 -> 2R+K-2
+    const int R = dw_strip_rows(sh, maxHo);  // input rows streamed: stride 1 -> R+K-1, stride 2 -> 2R+K-2
     long long strips = (long long)((maxWo + 3) / 4) * ((maxHo + R - 1) / R);
     dim3 grid((unsigned)((strips + 31) / 32), n_img, (Cp + 31) / 32);
 #define RT_DWR(KK, RR, SH_, SW_)                                                                                              \
@@ -1386,12 +1410,15 @@ void dwconv(hipStream_t st, int K, int sh, int sw, const float* x, const ImgGeom
     else hipLaunchKernelGGL((k_dwconv_rows<KK, RR, SH_, SW_, 0>), grid, dim3(256), 0, st, x, gin, gout, Cp, C, Wd, bias, act, has_lab, lab_a, lab_c, y, pool); \
   } while (0)
     const int code = (K == 5 ? 4 : 0) + (sh == 2 ? 2 : 0) + (sw == 2 ? 1 : 0);
+#define RT_DWR_R(KK, SH_, SW_, RBIG) \
+  do { if (R == 3) RT_DWR(KK, 3, SH_, SW_); else if (R == RBIG) RT_DWR(KK, RBIG, SH_, SW_); else RT_DWR(KK, 2, SH_, SW_); } while (0)
     switch (code) {
-      case 0: if (R == 4) RT_DWR(3, 4, 1, 1); else RT_DWR(3, 2, 1, 1); break; case 1: if (R == 4) RT_DWR(3, 4, 1, 2); else RT_DWR(3, 2, 1, 2); break;
-      case 2: RT_DWR(3, 2, 2, 1); break; case 3: RT_DWR(3, 2, 2, 2); break;
-      case 4: if (R == 4) RT_DWR(5, 4, 1, 1); else RT_DWR(5, 2, 1, 1); break; case 5: if (R == 4) RT_DWR(5, 4, 1, 2); else RT_DWR(5, 2, 1, 2); break;
-      case 6: RT_DWR(5, 2, 2, 1); break; default: RT_DWR(5, 2, 2, 2); break;
+      case 0: RT_DWR_R(3, 1, 1, 4); break; case 1: RT_DWR_R(3, 1, 2, 4); break;
+      case 2: RT_DWR_R(3, 2, 1, 2); break; case 3: RT_DWR_R(3, 2, 2, 2); break;
+      case 4: RT_DWR_R(5, 1, 1, 4); break; case 5: RT_DWR_R(5, 1, 2, 4); break;
+      case 6: RT_DWR_R(5, 2, 1, 2); break; default: RT_DWR_R(5, 2, 2, 2); break;
     }
+#undef RT_DWR_R
 #undef RT_DWR
     return;
   }
@@ -1587,7 +1614,7 @@ void se_scale(hipStream_t st, const float* x, const ImgGeom* geom, int n_img, lo
                      w1, b1, w2, b2, Cr, slope, residual, scale, 0);
 }
 void dwconv_pool_layout(int sh, int maxHo, int maxWo, int* chunks, int* strip_R) {
-  const int R = (sh == 1 && g_dw_variant != 4) ? 4 : 2;
+  const int R = dw_strip_rows(sh, maxHo);
   *strip_R = R;
   *chunks = (int)(((long long)((maxWo + 3) / 4) * ((maxHo + R - 1) / R) + 31) / 32);
 }
