@@ -140,6 +140,88 @@ __global__ __launch_bounds__(256) void k_gemm(const float* __restrict__ A, int l
 }
 
 // ---------------------------------------------------------------------------
+// Streaming GEMM for the thin layers (K <= 16*KG <= 128, N <= 16*NT <= 128), which are HBM bound:
+// the whole weight matrix sits in LDS for the life of the block and every wave walks over 32-row
+// tiles on its own -- the activation fragments go from global memory straight into the MFMA
+// operand registers (lane (r, q) loads A[m0 + r][16g + 4q .. +3], the same (q, s) -> k map the LDS
+// path uses), the next tile's fragments are in flight while the current one is multiplied, and
+// there is no barrier after the weights are staged.  Same k order per accumulator as k_gemm:
+// bit-identical results.
+// ---------------------------------------------------------------------------
+template <int NT, int KG>
+__global__ __launch_bounds__(256) void k_gemm_stream(const float* __restrict__ A, int lda, long long M, int K,
+                                                     const float* __restrict__ Wp, int N, int Npad,
+                                                     float* __restrict__ C, int ldc, int coff, Epilogue epi) {
+  constexpr int NKC = (KG + 1) / 2;
+  __shared__ __attribute__((aligned(16))) float ws[NKC * 16 * NT * LROW];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, q = lane >> 4;
+  for (int idx = tid; idx < NKC * 16 * NT * 8; idx += 256) {
+    const int c4 = idx & 7, row = (idx >> 3) % (16 * NT), kc = (idx >> 3) / (16 * NT);
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (row < Npad) v = *reinterpret_cast<const f32x4*>(Wp + ((long long)kc * Npad + row) * KC + c4 * 4);
+    *reinterpret_cast<f32x4*>(ws + (kc * 16 * NT + row) * LROW + c4 * 4) = v;
+  }
+  __syncthreads();
+  const int nt_valid = min(NT, Npad / 16);
+  const long long n_tiles = (M + 31) >> 5, stride = (long long)gridDim.x * 4;
+  const int nstore = (N + 3) & ~3;
+  constexpr int PD = 1;  // tiles of A fragments in flight per wave (2 and 4 measured slower: 0.57 -> 0.68 ms at K = 32)
+  f32x4 an[PD][2][KG];
+  auto fetch = [&](long long tile, f32x4 (&dst)[2][KG]) {
+#pragma unroll
+    for (int mt = 0; mt < 2; mt++) {
+      const long long m = tile * 32 + mt * 16 + r;
+      const float* row = A + (m < M ? m : 0) * lda + 4 * q;
+#pragma unroll
+      for (int g = 0; g < KG; g++) {
+        dst[mt][g] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (m < M && g * 16 + 4 * q < K) dst[mt][g] = *reinterpret_cast<const f32x4*>(row + g * 16);
+      }
+    }
+  };
+  const long long tile0 = (long long)blockIdx.x * 4 + wave;
+#pragma unroll
+  for (int u = 0; u < PD; u++)
+    if (tile0 + u * stride < n_tiles) fetch(tile0 + u * stride, an[u]);
+  for (long long base = tile0; base < n_tiles; base += stride * PD) {
+#pragma unroll
+    for (int u = 0; u < PD; u++) {
+      const long long tile = base + u * stride;
+      if (tile >= n_tiles) break;
+      f32x4 a[2][KG];
+#pragma unroll
+      for (int mt = 0; mt < 2; mt++)
+#pragma unroll
+        for (int g = 0; g < KG; g++) a[mt][g] = an[u][mt][g];
+      if (tile + stride * PD < n_tiles) fetch(tile + stride * PD, an[u]);
+      f32x4 acc[2][NT];
+#pragma unroll
+      for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < NT; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int g = 0; g < KG; g++) {
+#pragma unroll
+        for (int nt = 0; nt < NT; nt++) {
+          if (nt < nt_valid) {
+            const f32x4 b = *reinterpret_cast<const f32x4*>(ws + ((g >> 1) * 16 * NT + nt * 16 + r) * LROW + (g & 1) * 16 + 4 * q);
+#pragma unroll
+            for (int s2 = 0; s2 < 4; s2++) {
+              acc[0][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[s2], a[0][g][s2], acc[0][nt], 0, 0, 0);
+              acc[1][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[s2], a[1][g][s2], acc[1][nt], 0, 0, 0);
+            }
+          }
+        }
+      }
+      const long long ma = tile * 32 + r, mb = ma + 16;
+      epilogue_store<NT>(acc, nt_valid, epi, 0, N, nstore, C + ma * ldc + coff, C + mb * ldc + coff, ma < M, mb < M,
+                         epi.residual ? epi.residual + ma * epi.ld_res : nullptr,
+                         epi.residual ? epi.residual + mb * epi.ld_res : nullptr, q);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
 // Wide GEMM for N > 128: block tile (16*MT*WM) rows x (16*NT*WN) cols so that a pass reads
 // each activation row once (the narrow kernel re-reads A once per 128 columns), WM x WN waves,
 // and the next K-slab is prefetched into registers while the MFMAs of the current one run.
@@ -856,7 +938,7 @@ static int gemm_dispatch(long long M, int Npad16) {
   if (Npad16 % 240 == 0 && M >= 131072) return 15;  // 256 x 240 tile: halves the weight re-fetch per row
   if (Npad16 % 240 == 0 && M >= 16384) return 10;
   if (Npad16 >= 128 && M >= 8192) return 8;  // 128 x 128 register-prefetch tile (N = 128: 71 vs 61 TFLOP/s narrow)
-  return 0;
+  return 0;  // thin: gemm() picks the streaming kernel when K <= 64 as well, else the narrow LDS kernel
 }
 // Profiler label of a pointwise-conv GEMM: family + the kernel symbol the dispatcher picks, so the
 // per-kernel numbers of bench.py can be compared with rocprofv3's kernel stats one to one.
@@ -866,7 +948,7 @@ const char* gemm_pw_label(long long M, int Npad16, bool a_scale) {
     case 15: return "gemm_pw/k_gemm_wide<4,5,4,3>";
     case 10: return "gemm_pw/k_gemm_wide<2,5,4,3>";
     case 8: return "gemm_pw/k_gemm_wide<2,4,4,2>";
-    case 0: return "gemm_pw/k_gemm<NT>";
+    case 0: return "gemm_pw/thin";  // k_gemm_stream (K, N <= 64) or k_gemm<NT>
     default: return "gemm_pw/variant";
   }
 }
@@ -962,6 +1044,18 @@ void gemm(hipStream_t st, const float* A, int lda, long long M, int K, const flo
   if (v == 8) {
     dim3 grid((unsigned)((M + 127) / 128), (unsigned)((Npad16 + 127) / 128));
     hipLaunchKernelGGL((k_gemm_wide<2, 4, 4, 2>), grid, dim3(512), 0, st, A, lda, M, K, Wp, N, Npad16, C, ldc, coff, epi);
+    return;
+  }
+  if ((v == 20 && Npad16 <= 128 && K <= 128) || (v == 0 && !g_gemm_variant && Npad16 <= 64 && K <= 64 && M >= 65536)) {  // streaming kernel for the thin layers
+    const int ntl = Npad16 / 16, kg = (K + 15) / 16;
+    const long long tiles = (M + 31) / 32;
+    const unsigned blocks = (unsigned)std::min<long long>((tiles + 3) / 4, 256 * 8);
+#define RT_GS(NTV, KGV) hipLaunchKernelGGL((k_gemm_stream<NTV, KGV>), dim3(blocks), dim3(256), 0, st, A, lda, M, K, Wp, N, Npad16, C, ldc, coff, epi)
+#define RT_GS_K(NTV) do { if (kg <= 1) RT_GS(NTV, 1); else if (kg <= 2) RT_GS(NTV, 2); else if (kg <= 4) RT_GS(NTV, 4); else if (kg <= 6) RT_GS(NTV, 6); else RT_GS(NTV, 8); } while (0)
+    if (ntl <= 1) RT_GS_K(1); else if (ntl <= 2) RT_GS_K(2); else if (ntl <= 3) RT_GS_K(3); else if (ntl <= 4) RT_GS_K(4);
+    else if (ntl <= 6) RT_GS_K(6); else RT_GS_K(8);
+#undef RT_GS_K
+#undef RT_GS
     return;
   }
   if (v == 16 || v == 17) {

@@ -32,7 +32,7 @@ def gemm_pw_label(M: int, N: int, se: bool = False) -> str:
         return "gemm_pw/k_gemm_wide<2,5,4,3>"
     if npad >= 128 and M >= 8192:
         return "gemm_pw/k_gemm_wide<2,4,4,2>"
-    return "gemm_pw/k_gemm<NT>"
+    return "gemm_pw/thin"
 
 
 DET_GROUP_PX = 32 * 960 * 960   # session.cpp: det launch-group budget (det-input pixels)
