@@ -228,6 +228,18 @@ def main():
             else:
                 roofline = {"bound": "mfma", "achieved": round(tfs, 2), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
                             "frac": round(mfma_frac, 4), "traffic": None}
+            # HBM bytes per launch from the committed PMC passes of this same command (profiles/pmc_traffic.json,
+            # tools/pmc_summary.py: separate FETCH_SIZE / WRITE_SIZE passes, gfx950 corrections); only valid for
+            # the default workload the passes were taken on
+            pmc_symbol = {"gemm_pw/k_gemm_wide<4,5,4,3>": "k_gemm_wide<4, 5, 4, 3, 0, 0, 0, 0, 0>",
+                          "gemm_pw/k_gemm_wide<2,5,4,3>+se": "k_gemm_wide<2, 5, 4, 3, 0, 0, 1, 0, 0>",
+                          "gemm_pw/k_gemm_wide<2,4,4,2>": "k_gemm_wide<2, 4, 4, 2, 0, 0, 0, 0, 0>"}.get(name)
+            pmc_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_traffic.json")
+            if pmc_symbol and (a.pages, a.size, a.lines) == (32, 960, 32) and os.path.exists(pmc_path):
+                k = json.load(open(pmc_path))["kernels"].get(pmc_symbol)
+                if k:
+                    roofline["traffic"] = k["fetch_bytes_per_launch"] + k["write_bytes_per_launch"]
+                    roofline["traffic_source"] = "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload, FETCH_SIZE x2)"
             roofline.update({"kernel": name, "avg_launch_ms": round(avg_ms, 4), "launches_per_step": launches_per_step,
                              "measured": "HIP events on the session stream, serial pass (lanes=1) of the same %d steps, %.2f ms/step" % (a.steps, serial_ms),
                              "share_of_kernel_time": round(ms / total_ms, 3),

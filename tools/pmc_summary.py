@@ -1,0 +1,49 @@
+"""Folds two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE -- they do not fit one pass on gfx950) into
+per-kernel HBM bytes per launch.
+
+    rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_fetch -o f -- python3 bench.py --steps 2 --warmup 2 --no-cpu-baseline --lanes 1
+    rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_write -o w -- python3 bench.py --steps 2 --warmup 2 --no-cpu-baseline --lanes 1
+    python tools/pmc_summary.py gpurun_out/pmc_fetch/f_counter_collection.csv gpurun_out/pmc_write/w_counter_collection.csv profiles/pmc_traffic.json
+
+Units / corrections (MI355X_MICROARCH.md, HBM section): both counters are in KiB; on gfx950 FETCH_SIZE
+reports half of the bytes of 16-byte-per-lane coalesced reads (128-byte requests tallied at 64 bytes), so
+it is doubled; WRITE_SIZE is exact for 16-byte-per-lane stores.  Every load/store in these kernels is a
+16-byte vector access.
+"""
+import collections
+import csv
+import json
+import re
+import sys
+
+
+def agg(path):
+    d = collections.defaultdict(lambda: [0, 0.0])
+    for r in csv.DictReader(open(path)):
+        d[r["Kernel_Name"]][0] += 1
+        d[r["Kernel_Name"]][1] += float(r["Counter_Value"])
+    return d
+
+
+def short(name):
+    m = re.match(r"(?:void )?(?:rt::\w+::)?([\w]+(?:<[^>]*>)?)", name)
+    return m.group(1) if m else name
+
+
+def main():
+    f, w, out = agg(sys.argv[1]), agg(sys.argv[2]), sys.argv[3]
+    res = {}
+    for k, (n, fv) in f.items():
+        wn, wv = w.get(k, [0, 0.0])
+        res[short(k)] = {"launches": n, "fetch_bytes_per_launch": int(fv / n * 1024 * 2),
+                         "write_bytes_per_launch": int(wv / max(wn, 1) * 1024)}
+    top = dict(sorted(res.items(), key=lambda kv: -(kv[1]["fetch_bytes_per_launch"] + kv[1]["write_bytes_per_launch"]) * kv[1]["launches"])[:40])
+    json.dump({"command": "bench.py --steps 2 --warmup 2 --no-cpu-baseline --lanes 1 (C3 workload), separate --pmc FETCH_SIZE / --pmc WRITE_SIZE passes",
+               "corrections": "KiB -> bytes; FETCH_SIZE x2 (gfx950 128-byte requests tallied at 64 bytes); WRITE_SIZE as is",
+               "kernels": top}, open(out, "w"), indent=1)
+    for k, v in list(top.items())[:12]:
+        print("%-44s n=%4d fetch %.3f GB write %.3f GB" % (k[:44], v["launches"], v["fetch_bytes_per_launch"] / 1e9, v["write_bytes_per_launch"] / 1e9))
+
+
+if __name__ == "__main__":
+    main()
