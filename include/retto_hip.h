@@ -187,6 +187,19 @@ RT_API int rt_set_lanes(rt_session* s, int lanes);
 RT_API int rt_profile_enable(rt_session* s, int on);
 RT_API int rt_profile_get(rt_session* s, const char* const** names, const float** ms, const int** calls, int* n);
 
+/* ---- model files -----------------------------------------------------
+ * Replaces the model loading of retto-core/src/worker/ort_worker.rs:120-135 (the .onnx bytes
+ * resolved by worker.rs:30-56 go to ONNX Runtime there).  rt_config's det / cls / rec sources
+ * may hold either an RTWB blob or the PP-OCRv4 .onnx file itself: non-RTWB bytes are imported
+ * by rt_create through the same code as rt_onnx_to_rtwb.  which: 0 det, 1 cls, 2 rec.
+ * Host-only (no GPU needed).  *out is library-owned until rt_buffer_free; on failure err
+ * (optional, err_cap bytes) receives the message and the RT_ERR_* code is returned. */
+RT_API int rt_onnx_to_rtwb(int which, const void* onnx, size_t len, void** out, size_t* out_len, char* err, size_t err_cap);
+RT_API void rt_buffer_free(void* p);
+/* The tensor list (RTWB names and shapes, forward order, -1 = read from the file) the importer
+ * fills for model `which`, one "name d0 d1 ..." line per tensor; returns the length needed. */
+RT_API size_t rt_model_manifest(int which, char* buf, size_t cap);
+
 #ifdef __cplusplus
 }
 #endif

@@ -436,6 +436,31 @@ class RettoSession:
         self._hd.close()
 
 
+MODEL_DET, MODEL_CLS, MODEL_REC = 0, 1, 2
+
+
+def onnx_to_rtwb(which: int, onnx_bytes: bytes) -> bytes:
+    """PP-OCRv4 .onnx file -> RTWB blob (rt_onnx_to_rtwb; replaces ort_worker.rs:120-135's model loading).
+    RettoSession accepts the .onnx bytes / path directly as well."""
+    lib = _lib.load()
+    out = C.c_void_p(); n = C.c_size_t(); err = C.create_string_buffer(1024)
+    rc = lib.rt_onnx_to_rtwb(which, onnx_bytes, len(onnx_bytes), C.byref(out), C.byref(n), err, len(err))
+    if rc != 0:
+        raise _ERRS.get(rc, RettoError)(err.value.decode("utf-8", "replace"))
+    try:
+        return C.string_at(out, n.value)
+    finally:
+        lib.rt_buffer_free(out)
+
+
+def model_manifest(which: int) -> str:
+    lib = _lib.load()
+    n = lib.rt_model_manifest(which, None, 0)
+    buf = C.create_string_buffer(n)
+    lib.rt_model_manifest(which, buf, n)
+    return buf.value.decode()
+
+
 def synthetic_session_config(seed: int = 0, device: int = 0, **kw) -> RettoSessionConfig:
     """Session config over seeded synthetic PP-OCRv4-shaped weights (see retto_amd.synth)."""
     from . import synth

@@ -5,6 +5,7 @@
 
 #include "geom_math.h"
 #include "session.h"
+#include "onnx_import.h"
 
 using namespace rt;
 
@@ -226,6 +227,38 @@ int rt_profile_get(rt_session* s, const char* const** names, const float** ms, c
   for (auto& h : s->helpers) s->prof.merge(h->prof);
   *names = s->prof.names.data(); *ms = s->prof.ms.data(); *calls = s->prof.calls.data(); *n = (int)s->prof.names.size();
   return RT_OK;
+}
+
+int rt_onnx_to_rtwb(int which, const void* onnx, size_t len, void** out, size_t* out_len, char* err, size_t err_cap) {
+  if (err && err_cap) err[0] = 0;
+  if (!onnx || !len || !out || !out_len) { if (err && err_cap) snprintf(err, err_cap, "rt_onnx_to_rtwb: null argument"); return RT_ERR_INVALID; }
+  try {
+    std::vector<uint8_t> b = rt::onnx_to_rtwb(which, (const uint8_t*)onnx, len);
+    void* p = malloc(b.size());
+    if (!p) throw RtError(RT_ERR_BACKEND, "out of memory");
+    memcpy(p, b.data(), b.size());
+    *out = p; *out_len = b.size();
+    return RT_OK;
+  } catch (const RtError& e) {
+    if (err && err_cap) snprintf(err, err_cap, "%s", e.what());
+    return e.code;
+  } catch (const std::exception& e) {
+    if (err && err_cap) snprintf(err, err_cap, "%s", e.what());
+    return RT_ERR_BACKEND;
+  }
+}
+void rt_buffer_free(void* p) { free(p); }
+size_t rt_model_manifest(int which, char* buf, size_t cap) {
+  std::string s;
+  try {
+    for (const rt::ManifestEntry& m : rt::model_manifest(which)) {
+      s += m.name;
+      for (int d : m.dims) s += " " + std::to_string(d);
+      s += "\n";
+    }
+  } catch (const std::exception&) { return 0; }
+  if (buf && cap) { size_t n = std::min(cap - 1, s.size()); memcpy(buf, s.data(), n); buf[n] = 0; }
+  return s.size() + 1;
 }
 
 RT_API void rt_debug_set_variants(int gemm_variant, int dw_variant, int fuse_dwpw) { nn::g_gemm_variant = gemm_variant; nn::g_dw_variant = dw_variant; nn::g_fuse_dwpw = fuse_dwpw; }

@@ -1,4 +1,5 @@
 #include "nets.h"
+#include "onnx_import.h"
 
 #include <algorithm>
 #include <cstdlib>
@@ -542,6 +543,93 @@ float* ClsNet::run(RunCtx& c, const float* x, Level& L0) {
   { ProfScope ps(c.prof, c.st, "softmax");
     nn::softmax_rows(c.st, logits, 4, Lp.n(), 2, probs); }
   return probs;
+}
+
+// ---------------------------------------------------------------------------
+// Model manifest: the RTWB tensor list of each network (onnx_import.h), in the order the
+// parameters appear in the forward graph of the PaddleOCR modules (same-shaped layers are told
+// apart by that order only: the RSEFPN runs its levels top-down, ins3..ins0 then inp3..inp0).
+// Must stay in sync with the constructors above and with retto_amd/synth.py (tests check both).
+// ---------------------------------------------------------------------------
+static void mf_conv(std::vector<ManifestEntry>& m, const std::string& n, int cout, int cin_g, int kh, int kw, bool bias = true) {
+  m.push_back({n + ".w", {cout, cin_g, kh, kw}});
+  if (bias) m.push_back({n + ".b", {cout}});
+}
+static void mf_lab(std::vector<ManifestEntry>& m, const std::string& n) { m.push_back({n + ".a", {1}}); m.push_back({n + ".c", {1}}); }
+static void mf_se(std::vector<ManifestEntry>& m, const std::string& n, int c) {
+  mf_conv(m, n + ".fc1", c / 4, c, 1, 1);
+  mf_conv(m, n + ".fc2", c, c / 4, 1, 1);
+}
+static void mf_linear(std::vector<ManifestEntry>& m, const std::string& n, int cin, int cout) {
+  m.push_back({n + ".w", {cin, cout}}); m.push_back({n + ".b", {cout}});
+}
+static void mf_ln(std::vector<ManifestEntry>& m, const std::string& n, int c) { m.push_back({n + ".g", {c}}); m.push_back({n + ".beta", {c}}); }
+template <size_t N>
+static void mf_lcnet(std::vector<ManifestEntry>& m, const std::string& prefix, const LcSpec (&spec)[N], bool det) {
+  mf_conv(m, prefix + ".stem", 16, 3, 3, 3);
+  for (const LcSpec& s : spec) {
+    const std::string p = prefix + "." + s.name;
+    mf_conv(m, p + ".dw", s.cin, 1, s.k, s.k);
+    if (!det || !(s.sh == 2 && s.sw == 2)) mf_lab(m, p + ".dw");  // LearnableRepLayer: act (and its LAB) unless stride == 2
+    if (s.se) mf_se(m, p + ".se", s.cin);
+    mf_conv(m, p + ".pw", s.cout, s.cin, 1, 1);
+    mf_lab(m, p + ".pw");
+  }
+}
+
+std::vector<ManifestEntry> model_manifest(int which) {
+  std::vector<ManifestEntry> m;
+  if (which == MODEL_DET) {
+    mf_lcnet(m, "det", DET_SPEC, true);
+    const int tap_c[4] = {48, 96, 192, 384}, out_c[4] = {12, 18, 42, 360};
+    for (int j = 0; j < 4; j++) mf_conv(m, "det.out" + std::to_string(j), out_c[j], tap_c[j], 1, 1);
+    for (int j = 3; j >= 0; j--) {
+      mf_conv(m, "det.fpn.ins" + std::to_string(j), 96, out_c[j], 1, 1, false);
+      mf_se(m, "det.fpn.ins" + std::to_string(j) + ".se", 96);
+    }
+    for (int j = 3; j >= 0; j--) {
+      mf_conv(m, "det.fpn.inp" + std::to_string(j), 24, 96, 3, 3, false);
+      mf_se(m, "det.fpn.inp" + std::to_string(j) + ".se", 24);
+    }
+    mf_conv(m, "det.head.conv1", 24, 96, 3, 3);
+    m.push_back({"det.head.deconv1.w", {24, 24, 2, 2}}); m.push_back({"det.head.deconv1.b", {24}});
+    m.push_back({"det.head.deconv2.w", {24, 1, 2, 2}}); m.push_back({"det.head.deconv2.b", {1}});
+  } else if (which == MODEL_REC) {
+    mf_lcnet(m, "rec", REC_SPEC, false);
+    const int C = 480, D = 120;
+    mf_conv(m, "rec.neck.conv1", C / 8, C, 1, 3);
+    mf_conv(m, "rec.neck.conv2", D, C / 8, 1, 1);
+    for (int i = 0; i < 2; i++) {
+      const std::string p = "rec.neck.blk" + std::to_string(i);
+      mf_linear(m, p + ".qkv", D, 3 * D);
+      mf_linear(m, p + ".proj", D, D);
+      mf_ln(m, p + ".norm1", D);
+      mf_linear(m, p + ".fc1", D, 2 * D);
+      mf_linear(m, p + ".fc2", 2 * D, D);
+      mf_ln(m, p + ".norm2", D);
+    }
+    mf_ln(m, "rec.neck.norm", D);
+    mf_conv(m, "rec.neck.conv3", C, D, 1, 1);
+    mf_conv(m, "rec.neck.conv4", C / 8, 2 * C, 1, 3);
+    mf_conv(m, "rec.neck.conv1x1", D, C / 8, 1, 1);
+    m.push_back({"rec.head.fc.w", {D, -1}}); m.push_back({"rec.head.fc.b", {-1}});
+  } else if (which == MODEL_CLS) {
+    mf_conv(m, "cls.stem", 8, 3, 3, 3);
+    int cin = 8, i = 0;
+    for (const ClsSpec& s : CLS_SPEC) {
+      const std::string p = "cls.b" + std::to_string(i++);
+      mf_conv(m, p + ".expand", s.mid, cin, 1, 1);
+      mf_conv(m, p + ".dw", s.mid, 1, s.k, s.k);
+      if (s.se) mf_se(m, p + ".se", s.mid);
+      mf_conv(m, p + ".linear", s.cout, s.mid, 1, 1);
+      cin = s.cout;
+    }
+    mf_conv(m, "cls.conv2", 200, cin, 1, 1);
+    mf_linear(m, "cls.head.fc", 200, 2);
+  } else {
+    throw RtError(8, "model_manifest: unknown model kind");
+  }
+  return m;
 }
 
 }  // namespace rt

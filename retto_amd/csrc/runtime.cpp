@@ -1,4 +1,5 @@
 #include "runtime.h"
+#include "onnx_import.h"
 
 #include <sys/stat.h>
 
@@ -26,9 +27,10 @@ std::vector<uint8_t> read_source_bytes(const char* path, const void* data, size_
   return out;
 }
 
-Blob Blob::from_source(const char* path, const void* data, size_t len, const char* what) {
+Blob Blob::from_source(const char* path, const void* data, size_t len, const char* what, int model_kind) {
   Blob b;
   b.bytes_ = read_source_bytes(path, data, len, what);
+  if (model_kind >= 0 && !looks_like_rtwb(b.bytes_)) b.bytes_ = onnx_to_rtwb(model_kind, b.bytes_.data(), b.bytes_.size());
   b.parse();
   return b;
 }

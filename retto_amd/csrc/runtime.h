@@ -20,7 +20,8 @@ struct BlobTensor {
 class Blob {
  public:
   // worker.rs:30-56: Path must exist / Blob must be non-empty, else ModelNotFound
-  static Blob from_source(const char* path, const void* data, size_t len, const char* what);
+  // model_kind >= 0 (onnx_import.h ModelKind): bytes that are not RTWB are taken as an .onnx file and imported
+  static Blob from_source(const char* path, const void* data, size_t len, const char* what, int model_kind = -1);
   const BlobTensor& get(const std::string& name) const;
   bool has(const std::string& name) const { return t_.count(name) != 0; }
   const std::vector<uint8_t>& bytes() const { return bytes_; }

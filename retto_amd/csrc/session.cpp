@@ -1,4 +1,5 @@
 #include "session.h"
+#include "onnx_import.h"
 
 #include <algorithm>
 #include <cmath>
@@ -43,9 +44,9 @@ rt_session* rt_session_create(const rt_config* cfg) {
   s->cfg = *cfg;
   s->device = cfg->device_id;
   // model sources are consumed here; do not keep caller pointers
-  Blob bd = Blob::from_source(cfg->det.path, cfg->det.data, cfg->det.len, "det");
-  Blob bc = Blob::from_source(cfg->cls.path, cfg->cls.data, cfg->cls.len, "cls");
-  Blob br = Blob::from_source(cfg->rec.path, cfg->rec.data, cfg->rec.len, "rec");
+  Blob bd = Blob::from_source(cfg->det.path, cfg->det.data, cfg->det.len, "det", MODEL_DET);
+  Blob bc = Blob::from_source(cfg->cls.path, cfg->cls.data, cfg->cls.len, "cls", MODEL_CLS);
+  Blob br = Blob::from_source(cfg->rec.path, cfg->rec.data, cfg->rec.len, "rec", MODEL_REC);
   std::vector<uint8_t> dict = read_source_bytes(cfg->dict.path, cfg->dict.data, cfg->dict.len, "dict");
   s->cfg.det = s->cfg.cls = s->cfg.rec = s->cfg.dict = rt_model_source{nullptr, nullptr, 0};
   RT_HIP_CHECK(hipStreamCreateWithFlags(&s->st, hipStreamNonBlocking));

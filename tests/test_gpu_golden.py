@@ -114,3 +114,36 @@ def test_cli_directory_run(tmp_path):
     assert cli.main(["--images", str(tmp_path), "--synthetic", "--batch", "2", "--json", str(out)]) == 0
     lines = [json.loads(l) for l in open(out)]
     assert len(lines) == 3 and all(set(l) == {"file", "det", "cls", "rec"} for l in lines)
+
+
+def test_session_from_onnx_sources(tmp_path):
+    """rt_create takes the .onnx files themselves (Path or Blob sources, worker.rs:18-27): the importer output
+    drives the same kernels as the RTWB blob it was un-folded from."""
+    import sys
+    sys.path.insert(0, os.path.dirname(__file__))
+    import retto_amd
+    from retto_amd import synth, workload
+    from onnx_writer import build_model_onnx
+    blobs = synth.synth_models(0)
+    tens = [synth.det_tensors(), synth.cls_tensors(), synth.rec_tensors()]
+    # same seeds as synth_models: the blobs and the tensor dicts describe the same weights
+    assert all(np.array_equal(synth.unpack_blob(b)[k], t[k]) for b, t in zip(blobs[:3], tens) for k in list(t)[:3])
+    kinds = [retto_amd.MODEL_DET, retto_amd.MODEL_CLS, retto_amd.MODEL_REC]
+    onnx = [build_model_onnx(retto_amd.model_manifest(k), t, seed=9, style=i % 2) for i, (k, t) in enumerate(zip(kinds, tens))]
+    (tmp_path / "det.onnx").write_bytes(onnx[0])
+    S = retto_amd.RettoWorkerModelSource
+    cfg = retto_amd.synthetic_session_config(0)
+    cfg.worker_config.models = retto_amd.RettoWorkerModelProvider(det=S.Path(str(tmp_path / "det.onnx")), rec=S.Blob(onnx[2]), cls=S.Blob(onnx[1]))
+    a = retto_amd.RettoSession(cfg)
+    b = retto_amd.RettoSession(retto_amd.synthetic_session_config(0))
+    try:
+        page, rects = workload.planted_page(160, 320, 3, seed=4)
+        x = b.det_preprocess(page)
+        wa, wb = retto_amd.RettoHipWorker(cfg, a._hd), retto_amd.RettoHipWorker(cfg, b._hd)
+        assert np.abs(wa.det(x) - wb.det(x)).max() < 1e-4
+        m = workload.planted_map(x.shape[2], x.shape[3], 160, 320, rects)
+        ra, rb = a.run_batch([page], det_map_override=[m])[0], b.run_batch([page], det_map_override=[m])[0]
+        assert [t.text for t in ra.rec_result] == [t.text for t in rb.rec_result]
+        assert [c.label.label for c in ra.cls_result] == [c.label.label for c in rb.cls_result]
+    finally:
+        a.close(); b.close()
