@@ -23,6 +23,33 @@ __device__ __forceinline__ float act_apply(float v, int act) {
   return act == ACT_SWISH ? v * s : s;
 }
 
+// The epilogues resolve (activation, LAB) ONCE per kernel instead of per element: with the runtime
+// `act` inside the element loops hipcc emits a branch ladder per output value (the 256 x 240 GEMM tile
+// spent ~16 us of its ~80 us there).  act_dispatch calls f with compile-time tags for the combinations
+// the networks use and with (-1, -1) = "decide per element" for anything else.  Same expressions, same
+// rounding as act_apply.
+template <int V> struct IntTag { static constexpr int value = V; };
+template <int ACT, int LAB>
+__device__ __forceinline__ float epi_val(float v, int act, int has_lab, float lab_a, float lab_c) {
+  float t;
+  if (ACT == ACT_HSWISH) t = v * fminf(fmaxf(v + 3.0f, 0.0f), 6.0f) * 0.16666667f;
+  else if (ACT == ACT_RELU) t = fmaxf(v, 0.0f);
+  else if (ACT == ACT_NONE) t = v;
+  else if (ACT == ACT_SWISH) t = v * __builtin_amdgcn_rcpf(1.0f + __expf(-v));
+  else t = act_apply(v, act);
+  if (LAB == 1 || (LAB < 0 && has_lab)) t = fmaf(t, lab_a, lab_c);
+  return t;
+}
+template <class F>
+__device__ __forceinline__ void act_dispatch(int act, int has_lab, F&& f) {
+  if (act == ACT_HSWISH && has_lab) f(IntTag<ACT_HSWISH>{}, IntTag<1>{});
+  else if (act == ACT_HSWISH) f(IntTag<ACT_HSWISH>{}, IntTag<0>{});
+  else if (act == ACT_NONE && !has_lab) f(IntTag<ACT_NONE>{}, IntTag<0>{});
+  else if (act == ACT_RELU && !has_lab) f(IntTag<ACT_RELU>{}, IntTag<0>{});
+  else if (act == ACT_SWISH && !has_lab) f(IntTag<ACT_SWISH>{}, IntTag<0>{});
+  else f(IntTag<-1>{}, IntTag<-1>{});
+}
+
 // ---------------------------------------------------------------------------
 // MFMA micro-kernel shared by gemm and conv_sp.
 // LDS rows are KC(32)+4 floats.  Weights are the MFMA "A" operand (M dim = cout),
@@ -60,31 +87,33 @@ template <int NT>
 __device__ __forceinline__ void epilogue_store(f32x4 (&acc)[2][NT], int nt_valid, const Epilogue& epi, int n0, int N,
                                                int nstore, float* __restrict__ yrow0, float* __restrict__ yrow1,
                                                bool v0, bool v1, const float* res0, const float* res1, int q) {
+  act_dispatch(epi.act, epi.has_lab, [&](auto at, auto lt) {
+    constexpr int A = decltype(at)::value, L = decltype(lt)::value;
 #pragma unroll
-  for (int nt = 0; nt < NT; nt++) {
-    if (nt >= nt_valid) continue;
-    int col = n0 + nt * 16 + q * 4;
-    if (col >= nstore) continue;
-    f32x4 bias = {0.f, 0.f, 0.f, 0.f};
-    if (epi.bias) bias = *reinterpret_cast<const f32x4*>(epi.bias + col);
+    for (int nt = 0; nt < NT; nt++) {
+      if (nt >= nt_valid) continue;
+      int col = n0 + nt * 16 + q * 4;
+      if (col >= nstore) continue;
+      f32x4 bias = {0.f, 0.f, 0.f, 0.f};
+      if (epi.bias) bias = *reinterpret_cast<const f32x4*>(epi.bias + col);
 #pragma unroll
-    for (int mt = 0; mt < 2; mt++) {
-      bool valid = mt == 0 ? v0 : v1;
-      if (!valid) continue;
-      float* yr = mt == 0 ? yrow0 : yrow1;
-      const float* rr = mt == 0 ? res0 : res1;
-      f32x4 v = acc[mt][nt];
-      f32x4 o;
+      for (int mt = 0; mt < 2; mt++) {
+        bool valid = mt == 0 ? v0 : v1;
+        if (!valid) continue;
+        float* yr = mt == 0 ? yrow0 : yrow1;
+        const float* rr = mt == 0 ? res0 : res1;
+        f32x4 v = acc[mt][nt];
+        f32x4 o;
 #pragma unroll
-      for (int j = 0; j < 4; j++) {
-        float t = act_apply(v[j] + bias[j], epi.act);
-        if (epi.has_lab) t = fmaf(t, epi.lab_a, epi.lab_c);
-        if (rr) t += rr[col + j];
-        o[j] = (col + j < N) ? t : 0.0f;
+        for (int j = 0; j < 4; j++) {
+          float t = epi_val<A, L>(v[j] + bias[j], epi.act, epi.has_lab, epi.lab_a, epi.lab_c);
+          if (rr) t += rr[col + j];
+          o[j] = (col + j < N) ? t : 0.0f;
+        }
+        *reinterpret_cast<f32x4*>(yr + col) = o;
       }
-      *reinterpret_cast<f32x4*>(yr + col) = o;
     }
-  }
+  });
 }
 
 // ---------------------------------------------------------------------------
@@ -411,28 +440,30 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm_wide(const float* __restr
     return;
   }
   const int nstore = (N + 3) & ~3;
+  act_dispatch(epi.act, epi.has_lab, [&](auto at, auto lt) {
+    constexpr int A = decltype(at)::value, L = decltype(lt)::value;
 #pragma unroll
-  for (int nt = 0; nt < NT; nt++) {
-    if (nt >= nt_valid) continue;
-    int col = n0 + (wn * NT + nt) * 16 + q * 4;
-    if (col >= nstore) continue;
-    f32x4 bias = {0.f, 0.f, 0.f, 0.f};
-    if (epi.bias) bias = *reinterpret_cast<const f32x4*>(epi.bias + col);
+    for (int nt = 0; nt < NT; nt++) {
+      if (nt >= nt_valid) continue;
+      int col = n0 + (wn * NT + nt) * 16 + q * 4;
+      if (col >= nstore) continue;
+      f32x4 bias = {0.f, 0.f, 0.f, 0.f};
+      if (epi.bias) bias = *reinterpret_cast<const f32x4*>(epi.bias + col);
 #pragma unroll
-    for (int mt = 0; mt < MT; mt++) {
-      long long m = m0 + (wm * MT + mt) * 16 + r;
-      if (m >= M) continue;
-      f32x4 o;
+      for (int mt = 0; mt < MT; mt++) {
+        long long m = m0 + (wm * MT + mt) * 16 + r;
+        if (m >= M) continue;
+        f32x4 o;
 #pragma unroll
-      for (int j = 0; j < 4; j++) {
-        float t = act_apply(acc[mt][nt][j] + bias[j], epi.act);
-        if (epi.has_lab) t = fmaf(t, epi.lab_a, epi.lab_c);
-        if (epi.residual) t += epi.residual[m * epi.ld_res + col + j];
-        o[j] = (col + j < N) ? t : 0.0f;
+        for (int j = 0; j < 4; j++) {
+          float t = epi_val<A, L>(acc[mt][nt][j] + bias[j], epi.act, epi.has_lab, epi.lab_a, epi.lab_c);
+          if (epi.residual) t += epi.residual[m * epi.ld_res + col + j];
+          o[j] = (col + j < N) ? t : 0.0f;
+        }
+        *reinterpret_cast<f32x4*>(C + m * ldc + coff + col) = o;
       }
-      *reinterpret_cast<f32x4*>(C + m * ldc + coff + col) = o;
     }
-  }
+  });
 }
 
 // ---------------------------------------------------------------------------
@@ -1441,24 +1472,26 @@ __global__ __launch_bounds__(256, 4) void k_dwconv_rows(const float* __restrict_
     }
   }
   f32x4 ps = {0.f, 0.f, 0.f, 0.f};
+  act_dispatch(act, has_lab, [&](auto at, auto lt) {
+    constexpr int A = decltype(at)::value, L = decltype(lt)::value;
 #pragma unroll
-  for (int r = 0; r < R; r++) {
-    const int oy = oy0 + r;
-    if (oy >= go.H) break;
+    for (int r = 0; r < R; r++) {
+      const int oy = oy0 + r;
+      if (oy >= go.H) break;
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
-      if (ox0 + j >= go.W) break;
-      f32x4 o;
+      for (int j = 0; j < 4; j++) {
+        if (ox0 + j >= go.W) break;
+        f32x4 o;
 #pragma unroll
-      for (int e = 0; e < 4; e++) {
-        float t = act_apply(acc[r][j][e], act);
-        if (has_lab) t = fmaf(t, lab_a, lab_c);
-        o[e] = (ch + e < C) ? t : 0.f;  // pitch padding (chan_pitch) holds zeros whatever the input padding held
+        for (int e = 0; e < 4; e++) {
+          const float t = epi_val<A, L>(acc[r][j][e], act, has_lab, lab_a, lab_c);
+          o[e] = (ch + e < C) ? t : 0.f;  // pitch padding (chan_pitch) holds zeros whatever the input padding held
+        }
+        *reinterpret_cast<f32x4*>(y + (go.off + (long long)oy * go.W + ox0 + j) * Cp + ch) = o;
+        if (POOL) ps += o;
       }
-      *reinterpret_cast<f32x4*>(y + (go.off + (long long)oy * go.W + ox0 + j) * Cp + ch) = o;
-      if (POOL) ps += o;
     }
-  }
+  });
   psum = ps;
   } else {
     psum = f32x4{0.f, 0.f, 0.f, 0.f};
