@@ -193,14 +193,19 @@ static Epilogue make_epi(const PackedDense& p, int act, const Lab* lab = nullptr
   return e;
 }
 
-static void run_se(RunCtx& c, float* x, const Level& L, const SeW& se, float slope, int residual) {
+// Squeeze-excite scales of x ([image][Cp]); with apply the tensor is rescaled in place, otherwise the
+// caller folds the returned factors into the kernel that consumes x.
+static float* run_se(RunCtx& c, float* x, const Level& L, const SeW& se, float slope, int residual, bool apply = true) {
   int Cp = chan_pitch(se.C);
   float* partial = c.arena->alloc<float>((size_t)L.n() * nn::pool_chunks(L.maxPix) * Cp);
   float* scale = c.arena->alloc<float>((size_t)L.n() * Cp);
   { ProfScope ps(c.prof, c.st, "se_pool_fc");
     nn::se_scale(c.st, x, L.d, L.n(), L.maxPix, se.C, Cp, se.w1, se.b1, se.w2, se.b2, se.Cr, slope, residual, partial, scale); }
-  { ProfScope ps(c.prof, c.st, "scale_channels");
-    nn::scale_channels(c.st, x, L.d, L.n(), L.maxPix, Cp, scale); }
+  if (apply) {
+    ProfScope ps(c.prof, c.st, "scale_channels");
+    nn::scale_channels(c.st, x, L.d, L.n(), L.maxPix, Cp, scale);
+  }
+  return scale;
 }
 
 static std::string shape_str(long long a, long long b, long long c, long long d) {
@@ -313,30 +318,35 @@ float* DetNet::run(RunCtx& c, const float* x, Level& L0) {
         taps[j] = o; tap_lv[j] = lv[li];
       }
   }
-  // RSEFPN
+  // RSEFPN.  The squeeze-excite factors of the lateral (ins) and output (inp) convs are not applied in a pass
+  // of their own: ins[j]'s go into the top-down add that consumes it (out = ins[j] * s + up(ins[j+1]); the
+  // coarsest level, which has no add, is rescaled in place), inp[j]'s into the concat gather.
   float* in[4];
+  float* in_scale[4];
   for (int j = 3; j >= 0; j--) {
     in[j] = c.arena->alloc<float>((size_t)tap_lv[j]->total * 96);
     { ProfScope ps(c.prof, c.st, "gemm_misc", shape_str(tap_lv[j]->total, ins_[j].K, 96, 0));
       nn::gemm(c.st, taps[j], round_up(out_[j].N, 4), tap_lv[j]->total, ins_[j].K, ins_[j].w, 96, ins_[j].Npad, in[j], 96,
                0, make_epi(ins_[j], ACT_NONE)); }
-    run_se(c, in[j], *tap_lv[j], ins_se_[j], HSIG_MBV3, 1);
+    in_scale[j] = run_se(c, in[j], *tap_lv[j], ins_se_[j], HSIG_MBV3, 1, j == 3);
   }
   for (int j = 2; j >= 0; j--) {
     ProfScope ps(c.prof, c.st, "upsample_add");
-    nn::upsample_add(c.st, in[j], in[j + 1], tap_lv[j]->d, tap_lv[j + 1]->d, tap_lv[j]->n(), tap_lv[j]->maxPix, 96, in[j]);
+    nn::upsample_add(c.st, in[j], in[j + 1], tap_lv[j]->d, tap_lv[j + 1]->d, tap_lv[j]->n(), tap_lv[j]->maxPix, 96, in[j],
+                     in_scale[j]);
   }
   float* p[4];
+  const float* p_scale[4];
   for (int j = 3; j >= 0; j--) {
     p[j] = c.arena->alloc<float>((size_t)tap_lv[j]->total * 24);
     { ProfScope ps(c.prof, c.st, "conv3x3", shape_str(tap_lv[j]->total, 9 * 96, 24, 0));
       nn::conv_sp(c.st, 3, 3, in[j], 96, tap_lv[j]->d, tap_lv[j]->n(), tap_lv[j]->maxH, tap_lv[j]->maxW, 96, inp_[j].w, 24,
                   inp_[j].Npad, p[j], 24, make_epi(inp_[j], ACT_NONE)); }
-    run_se(c, p[j], *tap_lv[j], inp_se_[j], HSIG_MBV3, 1);
+    p_scale[3 - j] = run_se(c, p[j], *tap_lv[j], inp_se_[j], HSIG_MBV3, 1, false);  // order p5, p4, p3, p2
   }
   float* fuse = c.arena->alloc<float>((size_t)L4.total * 96);
   { ProfScope ps(c.prof, c.st, "fpn_concat");
-    nn::fpn_concat(c.st, p[3], p[2], p[1], p[0], L32.d, L16.d, L8.d, L4.d, L4.n(), L4.maxPix, 24, fuse); }
+    nn::fpn_concat(c.st, p[3], p[2], p[1], p[0], L32.d, L16.d, L8.d, L4.d, L4.n(), L4.maxPix, 24, fuse, p_scale); }
   float* h1 = c.arena->alloc<float>((size_t)L4.total * 24);
   { ProfScope ps(c.prof, c.st, "conv3x3", shape_str(L4.total, 9 * 96, 24, 1));
     nn::conv_sp(c.st, 3, 3, fuse, 96, L4.d, L4.n(), L4.maxH, L4.maxW, 96, head_conv1_.w, 24, head_conv1_.Npad, h1, 24,

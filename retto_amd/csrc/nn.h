@@ -68,13 +68,13 @@ void scale_channels(hipStream_t st, float* x, const ImgGeom* geom, int n_img, lo
 void global_mean(hipStream_t st, const float* x, const ImgGeom* geom, int n_img, long long max_pix, int Cp,
                  float* partial, float* out);
 
-// out = a + nearest_up2(b)   (in place on a allowed)
+// out = a * scale_a[image] + nearest_up2(b)   (in place on a allowed; scale_a [image][Cp] optional)
 void upsample_add(hipStream_t st, const float* a, const float* b, const ImgGeom* ga, const ImgGeom* gb, int n_img,
-                  long long max_pix, int Cp, float* out);
+                  long long max_pix, int Cp, float* out, const float* scale_a = nullptr);
 // fuse = concat(up8(p5), up4(p4), up2(p3), p2) along channels; every input has pitch Cq, output pitch 4*Cq
 void fpn_concat(hipStream_t st, const float* p5, const float* p4, const float* p3, const float* p2, const ImgGeom* g5,
                 const ImgGeom* g4, const ImgGeom* g3, const ImgGeom* g2, int n_img, long long max_pix, int Cq,
-                float* out);
+                float* out, const float* const* scales = nullptr);  // scales[4]: per-level [img][Cq] factors (p5..p2) or null
 // DB head tail: convT2x2s2(24->24)+relu, convT2x2s2(24->1), sigmoid. in [.,.,24] at 1/4 res,
 // out f32 map at full res (geometry gout, one float per pixel).
 void db_head_tail(hipStream_t st, const float* x, const ImgGeom* gin, const ImgGeom* gout, int n_img, long long max_pix,

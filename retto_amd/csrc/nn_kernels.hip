@@ -41,13 +41,15 @@ __device__ __forceinline__ float epi_val(float v, int act, int has_lab, float la
   return t;
 }
 template <class F>
-__device__ __forceinline__ void act_dispatch(int act, int has_lab, F&& f) {
-  if (act == ACT_HSWISH && has_lab) f(IntTag<ACT_HSWISH>{}, IntTag<1>{});
-  else if (act == ACT_HSWISH) f(IntTag<ACT_HSWISH>{}, IntTag<0>{});
-  else if (act == ACT_NONE && !has_lab) f(IntTag<ACT_NONE>{}, IntTag<0>{});
-  else if (act == ACT_RELU && !has_lab) f(IntTag<ACT_RELU>{}, IntTag<0>{});
-  else if (act == ACT_SWISH && !has_lab) f(IntTag<ACT_SWISH>{}, IntTag<0>{});
-  else f(IntTag<-1>{}, IntTag<-1>{});
+__device__ __forceinline__ void act_dispatch(int act, int has_lab, bool has_res, F&& f) {
+  // f(activation tag, LAB tag, residual tag); (-1, -1, 1) = everything decided per element
+  if (has_res) f(IntTag<-1>{}, IntTag<-1>{}, IntTag<1>{});
+  else if (act == ACT_HSWISH && has_lab) f(IntTag<ACT_HSWISH>{}, IntTag<1>{}, IntTag<0>{});
+  else if (act == ACT_HSWISH) f(IntTag<ACT_HSWISH>{}, IntTag<0>{}, IntTag<0>{});
+  else if (act == ACT_NONE && !has_lab) f(IntTag<ACT_NONE>{}, IntTag<0>{}, IntTag<0>{});
+  else if (act == ACT_RELU && !has_lab) f(IntTag<ACT_RELU>{}, IntTag<0>{}, IntTag<0>{});
+  else if (act == ACT_SWISH && !has_lab) f(IntTag<ACT_SWISH>{}, IntTag<0>{}, IntTag<0>{});
+  else f(IntTag<-1>{}, IntTag<-1>{}, IntTag<0>{});
 }
 
 // ---------------------------------------------------------------------------
@@ -87,8 +89,8 @@ template <int NT>
 __device__ __forceinline__ void epilogue_store(f32x4 (&acc)[2][NT], int nt_valid, const Epilogue& epi, int n0, int N,
                                                int nstore, float* __restrict__ yrow0, float* __restrict__ yrow1,
                                                bool v0, bool v1, const float* res0, const float* res1, int q) {
-  act_dispatch(epi.act, epi.has_lab, [&](auto at, auto lt) {
-    constexpr int A = decltype(at)::value, L = decltype(lt)::value;
+  act_dispatch(epi.act, epi.has_lab, res0 != nullptr, [&](auto at, auto lt, auto rt_) {
+    constexpr int A = decltype(at)::value, L = decltype(lt)::value, RES = decltype(rt_)::value;
 #pragma unroll
     for (int nt = 0; nt < NT; nt++) {
       if (nt >= nt_valid) continue;
@@ -107,7 +109,7 @@ __device__ __forceinline__ void epilogue_store(f32x4 (&acc)[2][NT], int nt_valid
 #pragma unroll
         for (int j = 0; j < 4; j++) {
           float t = epi_val<A, L>(v[j] + bias[j], epi.act, epi.has_lab, epi.lab_a, epi.lab_c);
-          if (rr) t += rr[col + j];
+          if (RES) t += rr[col + j];
           o[j] = (col + j < N) ? t : 0.0f;
         }
         *reinterpret_cast<f32x4*>(yr + col) = o;
@@ -440,8 +442,8 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm_wide(const float* __restr
     return;
   }
   const int nstore = (N + 3) & ~3;
-  act_dispatch(epi.act, epi.has_lab, [&](auto at, auto lt) {
-    constexpr int A = decltype(at)::value, L = decltype(lt)::value;
+  act_dispatch(epi.act, epi.has_lab, epi.residual != nullptr, [&](auto at, auto lt, auto rt_) {
+    constexpr int A = decltype(at)::value, L = decltype(lt)::value, RES = decltype(rt_)::value;
 #pragma unroll
     for (int nt = 0; nt < NT; nt++) {
       if (nt >= nt_valid) continue;
@@ -457,7 +459,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm_wide(const float* __restr
 #pragma unroll
         for (int j = 0; j < 4; j++) {
           float t = epi_val<A, L>(acc[mt][nt][j] + bias[j], epi.act, epi.has_lab, epi.lab_a, epi.lab_c);
-          if (epi.residual) t += epi.residual[m * epi.ld_res + col + j];
+          if (RES) t += epi.residual[m * epi.ld_res + col + j];
           o[j] = (col + j < N) ? t : 0.0f;
         }
         *reinterpret_cast<f32x4*>(C + m * ldc + coff + col) = o;
@@ -1472,7 +1474,7 @@ __global__ __launch_bounds__(256, 4) void k_dwconv_rows(const float* __restrict_
     }
   }
   f32x4 ps = {0.f, 0.f, 0.f, 0.f};
-  act_dispatch(act, has_lab, [&](auto at, auto lt) {
+  act_dispatch(act, has_lab, false, [&](auto at, auto lt, auto) {
     constexpr int A = decltype(at)::value, L = decltype(lt)::value;
 #pragma unroll
     for (int r = 0; r < R; r++) {
@@ -1786,9 +1788,11 @@ void scale_channels(hipStream_t st, float* x, const ImgGeom* geom, int n_img, lo
 // ---------------------------------------------------------------------------
 // FPN glue
 // ---------------------------------------------------------------------------
+// out = a * sa + nearest-2x(b); sa (optional, [image][Cp]) is the squeeze-excite scale of `a`, folded in here
+// instead of a separate read+write pass over `a`.
 __global__ __launch_bounds__(256) void k_upsample_add(const float* __restrict__ a, const float* __restrict__ b,
                                                       const ImgGeom* __restrict__ ga, const ImgGeom* __restrict__ gb,
-                                                      int Cp, float* __restrict__ out) {
+                                                      int Cp, float* __restrict__ out, const float* __restrict__ sa) {
   const ImgGeom A = ga[blockIdx.y], B = gb[blockIdx.y];
   const int C4 = Cp >> 2;
   long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -1798,22 +1802,25 @@ __global__ __launch_bounds__(256) void k_upsample_add(const float* __restrict__ 
   int y = (int)(p / A.W), x = (int)(p % A.W);
   int by = min(y >> 1, B.H - 1), bx = min(x >> 1, B.W - 1);
   f32x4 va = *reinterpret_cast<const f32x4*>(a + (A.off + p) * Cp + c4 * 4);
+  if (sa) va *= *reinterpret_cast<const f32x4*>(sa + (long long)blockIdx.y * Cp + c4 * 4);
   f32x4 vb = *reinterpret_cast<const f32x4*>(b + (B.off + (long long)by * B.W + bx) * Cp + c4 * 4);
   *reinterpret_cast<f32x4*>(out + (A.off + p) * Cp + c4 * 4) = va + vb;
 }
 void upsample_add(hipStream_t st, const float* a, const float* b, const ImgGeom* ga, const ImgGeom* gb, int n_img,
-                  long long max_pix, int Cp, float* out) {
+                  long long max_pix, int Cp, float* out, const float* scale_a) {
   if (n_img <= 0) return;
   long long total = max_pix * (Cp / 4);
   hipLaunchKernelGGL(k_upsample_add, dim3((unsigned)((total + 255) / 256), n_img), dim3(256), 0, st, a, b, ga, gb, Cp,
-                     out);
+                     out, scale_a);
 }
 
 __global__ __launch_bounds__(256) void k_fpn_concat(const float* __restrict__ p5, const float* __restrict__ p4,
                                                     const float* __restrict__ p3, const float* __restrict__ p2,
                                                     const ImgGeom* __restrict__ g5, const ImgGeom* __restrict__ g4,
                                                     const ImgGeom* __restrict__ g3, const ImgGeom* __restrict__ g2,
-                                                    int Cq, float* __restrict__ out) {
+                                                    int Cq, float* __restrict__ out, const float* __restrict__ s5,
+                                                    const float* __restrict__ s4, const float* __restrict__ s3,
+                                                    const float* __restrict__ s2) {
   const ImgGeom G2 = g2[blockIdx.y];
   const int Q4 = Cq >> 2, C4 = Q4 * 4;
   long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -1823,23 +1830,27 @@ __global__ __launch_bounds__(256) void k_fpn_concat(const float* __restrict__ p5
   int y = (int)(p / G2.W), x = (int)(p % G2.W);
   int lvl = c4 / Q4, cc = c4 % Q4;
   const float* src;
+  const float* sc;  // optional squeeze-excite scale of that level ([image][Cq]), folded into the gather
   ImgGeom G;
   int sh;
-  if (lvl == 0) { src = p5; G = g5[blockIdx.y]; sh = 3; }
-  else if (lvl == 1) { src = p4; G = g4[blockIdx.y]; sh = 2; }
-  else if (lvl == 2) { src = p3; G = g3[blockIdx.y]; sh = 1; }
-  else { src = p2; G = G2; sh = 0; }
+  if (lvl == 0) { src = p5; sc = s5; G = g5[blockIdx.y]; sh = 3; }
+  else if (lvl == 1) { src = p4; sc = s4; G = g4[blockIdx.y]; sh = 2; }
+  else if (lvl == 2) { src = p3; sc = s3; G = g3[blockIdx.y]; sh = 1; }
+  else { src = p2; sc = s2; G = G2; sh = 0; }
   int sy = min(y >> sh, G.H - 1), sx = min(x >> sh, G.W - 1);
   f32x4 v = *reinterpret_cast<const f32x4*>(src + (G.off + (long long)sy * G.W + sx) * Cq + cc * 4);
+  if (sc) v *= *reinterpret_cast<const f32x4*>(sc + (long long)blockIdx.y * Cq + cc * 4);
   *reinterpret_cast<f32x4*>(out + (G2.off + p) * (4 * Cq) + c4 * 4) = v;
 }
 void fpn_concat(hipStream_t st, const float* p5, const float* p4, const float* p3, const float* p2, const ImgGeom* g5,
                 const ImgGeom* g4, const ImgGeom* g3, const ImgGeom* g2, int n_img, long long max_pix, int Cq,
-                float* out) {
+                float* out, const float* const* scales) {
   if (n_img <= 0) return;
   long long total = max_pix * Cq;  // 4 levels * Cq/4 groups
+  const float* nul = nullptr;
   hipLaunchKernelGGL(k_fpn_concat, dim3((unsigned)((total + 255) / 256), n_img), dim3(256), 0, st, p5, p4, p3, p2, g5,
-                     g4, g3, g2, Cq, out);
+                     g4, g3, g2, Cq, out, scales ? scales[0] : nul, scales ? scales[1] : nul, scales ? scales[2] : nul,
+                     scales ? scales[3] : nul);
 }
 
 // DB head tail. w1 [24][24][2][2] (cin, cout, dy, dx), w2 [24][1][2][2].
