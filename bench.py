@@ -201,7 +201,8 @@ def main():
             work[k]["bytes"] += v["bytes"]; work[k]["flops"] += v["flops"]
         else:
             work[k] = dict(v)
-    fams = sorted(((ms, calls, name) for name, (ms, calls) in prof.items() if calls), reverse=True)
+    nets = {name[4:]: ms / a.steps for name, (ms, calls) in prof.items() if calls and name.startswith("net/")}
+    fams = sorted(((ms, calls, name) for name, (ms, calls) in prof.items() if calls and not name.startswith("net/")), reverse=True)
     total_ms = sum(f[0] for f in fams)
     if a.profile_all:
         for ms, calls, name in fams:
@@ -247,6 +248,22 @@ def main():
                              "algorithmic_flops_per_launch": int(flops_per_launch)})
             break
 
+    # ---- whole networks (HIP events around DetNet / ClsNet / RecNet::run in the same serial pass) -----------
+    # north_star's "DBNet-backbone achieved HBM": B_layer = 500 MB per 960x960 page (every conv layer's
+    # input read + output written once, fp32) over the det network's device time, against the 8 TB/s peak.
+    networks = None
+    if nets:
+        det_flops = sum(v["flops"] for v in workmodel.det_work([(S, S)] * a.pages).values())
+        rec_flops = sum(v["flops"] for v in workmodel.rec_work(widths).values())
+        b_layer = 500e6 * (S * S) / (960.0 * 960.0) * a.pages
+        networks = {"det_ms": round(nets.get("det", 0.0), 3), "cls_ms": round(nets.get("cls", 0.0), 3),
+                    "rec_ms": round(nets.get("rec", 0.0), 3),
+                    "det_tflops": round(det_flops / (nets["det"] * 1e-3) / 1e12, 2) if nets.get("det") else None,
+                    "rec_tflops": round(rec_flops / (nets["rec"] * 1e-3) / 1e12, 2) if nets.get("rec") else None,
+                    "det_b_layer_gbs": round(b_layer / (nets["det"] * 1e-3) / 1e9, 1) if nets.get("det") else None,
+                    "det_b_layer_frac_of_hbm_peak": round(b_layer / (nets["det"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if nets.get("det") else None,
+                    "note": "per step of %d pages, one lane; fp32 MFMA peak %.1f TFLOP/s, HBM peak %.0f GB/s" % (a.pages, FP32_PEAK_TFLOPS, HBM_PEAK_GBS)}
+
     # ---- CPU baseline: the oracle on a bounded sample of the same workload -------------------
     cpu_baseline = None
     if world == 1 and not a.no_cpu_baseline:
@@ -275,6 +292,7 @@ def main():
                    "weights": "seeded synthetic, PP-OCRv4 mobile shapes", "parallelism": "dp%d (pages sharded, no per-step collective)" % world},
         "roofline": roofline,
         "cpu_baseline": cpu_baseline,
+        "networks": networks,
     }
     print(json.dumps(out))
     sess.close()

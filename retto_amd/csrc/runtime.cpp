@@ -164,6 +164,16 @@ void Profiler::end(hipStream_t st) {
   RT_HIP_CHECK(hipEventRecord(b, st));
   recs_.push_back(Rec{cur_, cur_a_, b});
 }
+hipEvent_t Profiler::outer_begin(hipStream_t st) {
+  hipEvent_t a = get_event();
+  RT_HIP_CHECK(hipEventRecord(a, st));
+  return a;
+}
+void Profiler::outer_end(hipStream_t st, const char* name, hipEvent_t a) {
+  hipEvent_t b = get_event();
+  RT_HIP_CHECK(hipEventRecord(b, st));
+  recs_.push_back(Rec{id_of(name), a, b});
+}
 void Profiler::collect() {
   for (auto& r : recs_) {
     float t = 0.f;

@@ -81,6 +81,9 @@ class Profiler {
   bool detail = getenv("RT_PROFILE_DETAIL") != nullptr;  // per-layer labels "family@shape" (tools/layer_profile.py)
   void begin(hipStream_t st, const char* name);
   void end(hipStream_t st);
+  // a second, enclosing level ("net/det", "net/cls", "net/rec"): whole-network device time next to the families
+  hipEvent_t outer_begin(hipStream_t st);
+  void outer_end(hipStream_t st, const char* name, hipEvent_t a);
   void collect();  // after a stream sync: fold event pairs into the totals
   void clear();
   void merge(Profiler& other);  // adds other's totals into this one and zeroes other's
@@ -105,6 +108,11 @@ struct ProfScope {
     if (p && p->on) p->begin(st, p->detail ? (std::string(name) + "@" + shape).c_str() : name);
   }
   ~ProfScope() { if (p && p->on) p->end(st); }
+};
+struct ProfOuter {
+  Profiler* p; hipStream_t st; const char* name; hipEvent_t a{};
+  ProfOuter(Profiler* p_, hipStream_t s, const char* n) : p(p_), st(s), name(n) { if (p && p->on) a = p->outer_begin(st); }
+  ~ProfOuter() { if (p && p->on) p->outer_end(st, name, a); }
 };
 
 }  // namespace rt

@@ -435,7 +435,8 @@ rt_results* rt_session::run_pages(const uint8_t* const* rgb, const int* hs, cons
                         x + L0.h[i - g0].off * 4);
     }
     RunCtx c = ctx(&scratch);
-    float* map = det->run(c, x, L0);
+    float* map;
+    { ProfOuter po(&prof, st, "net/det"); map = det->run(c, x, L0); }
     // keep the maps beyond the scratch rewind
     float* keep = arena.alloc<float>((size_t)L0.total);
     RT_HIP_CHECK(hipMemcpyAsync(keep, map, (size_t)L0.total * 4, hipMemcpyDeviceToDevice, st));
@@ -556,7 +557,8 @@ rt_results* rt_session::run_pages(const uint8_t* const* rgb, const int* hs, cons
           pp::resize_norm(st, dl, cn, ch, cw, pool, 0, x, d_flags); }
         Level L0 = make_level(uniform_hw(cn, ch, cw));
         RunCtx c = ctx(&scratch);
-        float* probs = cls->run(c, x, L0);
+        float* probs;
+        { ProfOuter po(&prof, st, "net/cls"); probs = cls->run(c, x, L0); }
         ProfScope ps(&prof, st, "cls_post_rotate");
         pp::cls_post_rotate(st, probs, drow, cn, cfg.cls_thresh, d_refs, pool, plan.max_pix, d_label, d_cscore);
       }
@@ -627,7 +629,8 @@ rt_results* rt_session::run_pages(const uint8_t* const* rgb, const int* hs, cons
       Level L0 = make_level(hw), Lt;
       RunCtx c = ctx(&scratch);
       // (the token count per line only depends on the widths, so the offsets are known before the net runs)
-      rec->run(c, x, L0, Lt, d_idx + tok_off[l0], d_prob + tok_off[l0]);  // fused CTC head: logits never reach HBM
+      { ProfOuter po(&prof, st, "net/rec");
+        rec->run(c, x, L0, Lt, d_idx + tok_off[l0], d_prob + tok_off[l0]); }  // fused CTC head: logits never reach HBM
       if (Lt.total != tok_off[l1] - tok_off[l0]) throw RtError(RT_ERR_SHAPE, "token count mismatch");
       { ProfScope ps(&prof, st, "ctc_decode");
         pp::ctc_decode(st, d_idx + tok_off[l0], d_prob + tok_off[l0], Lt.d, ln, d_tok + tok_off[l0], d_ntok + l0, d_rscore + l0); }

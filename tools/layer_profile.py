@@ -35,7 +35,7 @@ for _ in range(steps):
     lib.rt_results_free(s.run_batch_raw(d_pages, hs, hs, retto_amd.RT_MEM_DEVICE, d_maps))
 rows = []
 for name, (ms, calls) in s.profile_get().items():
-    if calls == 0:
+    if calls == 0 or name.startswith("net/"):
         continue
     fam, _, shape = name.partition("@")
     per = ms / calls
