@@ -43,7 +43,7 @@ def parse():
     ap.add_argument("--lanes", type=int, default=0, help="concurrent page streams inside rt_run_batch (0 = library default)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for single-GPU smoke tests of the multi-rank path)")
     ap.add_argument("--share-gpu", action="store_true", help="test only: every rank uses device 0")
-    ap.add_argument("--cpu-pages", type=int, default=1, help="pages of the same workload timed on the CPU oracle")
+    ap.add_argument("--cpu-pages", type=int, default=3, help="pages of the same workload timed on the CPU oracle")
     ap.add_argument("--profile-all", action="store_true", help="print the per-family table to stderr")
     return ap.parse_args()
 
