@@ -147,3 +147,52 @@ def test_session_from_onnx_sources(tmp_path):
         assert [c.label.label for c in ra.cls_result] == [c.label.label for c in rb.cls_result]
     finally:
         a.close(); b.close()
+
+
+def test_native_directory_driver(tmp_path):
+    """examples/retto_dir.cpp: the retto-cli loop in C++ over the C ABI alone (model files by path -- RTWB and
+    .onnx --, PPM pages from a directory); its JSON lines equal the Python mirror's stage JSON."""
+    import json
+    import subprocess
+    import sys
+    sys.path.insert(0, os.path.dirname(__file__))
+    import retto_amd
+    from retto_amd import synth, workload
+    from onnx_writer import build_model_onnx
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "examples", "retto_dir")
+    if not os.path.exists(exe):  # normally built by __graft_entry__.build(); host-only C++, seconds
+        subprocess.check_call(["g++", "-std=c++17", "-O2", "-I" + os.path.join(root, "include"), os.path.join(root, "examples", "retto_dir.cpp"),
+                               "-L" + os.path.join(root, "retto_amd"), "-lretto_hip", "-Wl,-rpath,$ORIGIN/../retto_amd", "-o", exe])
+    det, cls, rec, dic = synth.synth_models(0)
+    (tmp_path / "det.rtwb").write_bytes(det)
+    (tmp_path / "cls.onnx").write_bytes(build_model_onnx(retto_amd.model_manifest(retto_amd.MODEL_CLS), synth.cls_tensors(), seed=2, style=1))
+    (tmp_path / "rec.rtwb").write_bytes(rec)
+    (tmp_path / "keys.txt").write_bytes(dic)
+    pages_dir = tmp_path / "pages"
+    pages_dir.mkdir()
+    pages = []
+    for i in range(3):
+        page, _ = workload.planted_page(96 + 32 * i, 320, 2, seed=20 + i)
+        # bright text lines on black give the random-weight detector nothing; the planted rectangles do not matter here
+        (pages_dir / ("p%d.ppm" % i)).write_bytes(b"P6\n%d %d\n255\n" % (page.shape[1], page.shape[0]) + page.tobytes())
+        pages.append(page)
+    out = subprocess.run([exe, "--det", str(tmp_path / "det.rtwb"), "--cls", str(tmp_path / "cls.onnx"), "--rec", str(tmp_path / "rec.rtwb"),
+                          "--keys", str(tmp_path / "keys.txt"), "--images", str(pages_dir), "--batch", "2"],
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    lines = [json.loads(l) for l in out.stdout.strip().split("\n")]
+    assert [os.path.basename(l["file"]) for l in lines] == ["p0.ppm", "p1.ppm", "p2.ppm"]
+    assert "Successfully processed 3 images" in out.stderr
+    S = retto_amd.RettoWorkerModelSource
+    cfg = retto_amd.RettoSessionConfig()
+    cfg.worker_config = retto_amd.RettoHipWorkerConfig(device=0, models=retto_amd.RettoWorkerModelProvider(
+        det=S.Path(str(tmp_path / "det.rtwb")), rec=S.Path(str(tmp_path / "rec.rtwb")), cls=S.Path(str(tmp_path / "cls.onnx"))))
+    cfg.rec_processor_config.character_source = S.Path(str(tmp_path / "keys.txt"))
+    s = retto_amd.RettoSession(cfg)
+    try:
+        for page, l in zip(pages, lines):
+            det_j, cls_j, rec_j = (json.loads(j) for j in s.stage_json(page))
+            assert l["det"] == det_j and l["cls"] == cls_j and l["rec"] == rec_j
+    finally:
+        s.close()
