@@ -37,6 +37,9 @@ def parse():
     ap.add_argument("--pages", type=int, default=32, help="pages per GPU per step (C3: 32)")
     ap.add_argument("--size", type=int, default=960)
     ap.add_argument("--lines", type=int, default=32, help="planted text lines per page")
+    ap.add_argument("--workload", default="c3", choices=["c3", "c4"],
+                    help="c3 (default, the metric's configuration): pages of --size x --size; c4: mixed page sizes "
+                         "drawn (seeded) from SURVEY 8d's set, 2480x3508 scans included (resize_both shrinks them)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--det-sub-batch", type=int, default=0)
     ap.add_argument("--variants", type=str, default="", help="debug: gemm,dw,fuse kernel variants")
@@ -97,17 +100,23 @@ def main():
     # ---- synthetic pages + planted maps, staged to HBM once -------------------------------
     import ctypes as C
     S = a.size
-    pages, maps, d_pages, d_maps = [], [], [], []
+    C4_SIZES = [(640, 640), (960, 960), (720, 1280), (1080, 1920), (1754, 1240), (3508, 2480)]
+    rng_sizes = np.random.default_rng(77 + rank)
+    pages, maps, d_pages, d_maps, det_dims = [], [], [], [], []
     for i in range(a.pages):
-        page, rects = workload.planted_page(S, S, a.lines, seed=1000 * rank + i)
-        m = workload.planted_map(S, S, S, S, rects)
-        pages.append(page); maps.append(m)
+        ph, pw = (S, S) if a.workload == "c3" else C4_SIZES[int(rng_sizes.integers(0, len(C4_SIZES)))]
+        page, rects = workload.planted_page(ph, pw, a.lines, seed=1000 * rank + i)
+        rh, rw, dh, dw = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        assert lib.rt_resize_both_dims(h, ph, pw, C.byref(rh), C.byref(rw)) == 0      # a2: session size limits
+        assert lib.rt_det_input_dims(h, rh.value, rw.value, C.byref(dh), C.byref(dw)) == 0  # a3: det input size
+        m = workload.planted_map(dh.value, dw.value, ph, pw, rects)
+        pages.append(page); maps.append(m); det_dims.append((dh.value, dw.value))
         for arr, lst in ((page, d_pages), (m, d_maps)):
             p = C.c_void_p()
             assert lib.rt_device_malloc(h, arr.nbytes, C.byref(p)) == 0
             assert lib.rt_memcpy_h2d(h, p, arr.ctypes.data, arr.nbytes) == 0
             lst.append(p.value)
-    hs = [S] * a.pages; ws = [S] * a.pages
+    hs = [p.shape[0] for p in pages]; ws = [p.shape[1] for p in pages]
 
     def step():
         r = sess.run_batch_raw(d_pages, hs, ws, retto_amd.RT_MEM_DEVICE, d_maps)
@@ -195,7 +204,7 @@ def main():
             for i in idx:
                 ratio = max(ratio, np.float32(dims[i][1]) / np.float32(dims[i][0]))
             widths += [lib.rt_resize_norm_width(48, 320, float(ratio))] * len(idx)
-    work = workmodel.det_work([(S, S)] * a.pages)
+    work = workmodel.det_work(det_dims)
     for k, v in workmodel.rec_work(widths).items():
         if k in work:
             work[k]["bytes"] += v["bytes"]; work[k]["flops"] += v["flops"]
@@ -236,7 +245,7 @@ def main():
                           "gemm_pw/k_gemm_wide<2,5,4,3>+se": "k_gemm_wide<2, 5, 4, 3, 0, 0, 1, 0, 0>",
                           "gemm_pw/k_gemm_wide<2,4,4,2>": "k_gemm_wide<2, 4, 4, 2, 0, 0, 0, 0, 0>"}.get(name)
             pmc_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_traffic.json")
-            if pmc_symbol and (a.pages, a.size, a.lines) == (32, 960, 32) and os.path.exists(pmc_path):
+            if pmc_symbol and (a.workload, a.pages, a.size, a.lines) == ("c3", 32, 960, 32) and os.path.exists(pmc_path):
                 k = json.load(open(pmc_path))["kernels"].get(pmc_symbol)
                 if k:
                     roofline["traffic"] = k["fetch_bytes_per_launch"] + k["write_bytes_per_launch"]
@@ -253,9 +262,9 @@ def main():
     # input read + output written once, fp32) over the det network's device time, against the 8 TB/s peak.
     networks = None
     if nets:
-        det_flops = sum(v["flops"] for v in workmodel.det_work([(S, S)] * a.pages).values())
+        det_flops = sum(v["flops"] for v in workmodel.det_work(det_dims).values())
         rec_flops = sum(v["flops"] for v in workmodel.rec_work(widths).values())
-        b_layer = 500e6 * (S * S) / (960.0 * 960.0) * a.pages
+        b_layer = 500e6 * sum(dh_ * dw_ for dh_, dw_ in det_dims) / (960.0 * 960.0)
         networks = {"det_ms": round(nets.get("det", 0.0), 3), "cls_ms": round(nets.get("cls", 0.0), 3),
                     "rec_ms": round(nets.get("rec", 0.0), 3),
                     "det_tflops": round(det_flops / (nets["det"] * 1e-3) / 1e12, 2) if nets.get("det") else None,
@@ -285,9 +294,11 @@ def main():
         "value": round(value, 3), "unit": "images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "C3: PP-OCRv4 mobile det+cls+rec full pipeline, batch=%d pages of %dx%d per GPU, "
+        "config": {"workload": ("C3: PP-OCRv4 mobile det+cls+rec full pipeline, batch=%d pages of %dx%d per GPU, " % (a.pages, S, S)
+                                if a.workload == "c3" else
+                                "C4: PP-OCRv4 mobile det+cls+rec full pipeline, batch=%d mixed-size pages per GPU (640x640 .. 2480x3508), " % a.pages) +
                                "%d planted lines/page (planted DB map drives box extraction; det net fully executed, "
-                               "checksum %.6g)" % (a.pages, S, S, a.lines, checksum),
+                               "checksum %.6g)" % (a.lines, checksum),
                    "pages_per_gpu_per_step": a.pages, "lines_per_step_all_gpus": n_lines_total,
                    "weights": "seeded synthetic, PP-OCRv4 mobile shapes", "parallelism": "dp%d (pages sharded, no per-step collective)" % world},
         "roofline": roofline,
