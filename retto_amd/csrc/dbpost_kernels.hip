@@ -152,16 +152,41 @@ __global__ __launch_bounds__(256) void k_ccl_stats(const DbPage* __restrict__ pa
   if (i >= H * W) return;
   int y = i / W, x = i % W;
   const DbWs& ws = pg.ws;
-  int r = uf_find(ws.parent, i);
+  // Root of this pixel's component.  A pixel still points at the first pixel of its horizontal run
+  // (k_ccl_rows); the run heads were linked by atomicMin without compression, so a find from a head can be a
+  // long walk (the page background: one hop per image row).  Lanes of a wave are consecutive pixels, i.e.
+  // whole stretches of them share a run head: only the first lane of each stretch walks, the others take its
+  // result through a segmented shuffle scan.
+  const int lane = threadIdx.x & 63;
+  const int rs = ws.parent[i];
+  const int prev = __shfl_up(rs, 1);
+  const bool head = lane == 0 || prev != rs;
+  int r = head ? uf_find(ws.parent, rs) : -1;
+  int src = head ? lane : -1;  // lane of the stretch's head: inclusive max-scan
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) { int t = __shfl_up(src, o); if (lane >= o) src = max(src, t); }
+  r = __shfl(r, src);
   ws.parent[i] = r;  // flatten (each thread writes only its own slot; readers tolerate either value)
-  if (ws.mask[i]) {
-    if (y == 0 || !ws.mask[i - W]) atomicMin(&ws.ymin[r], y);
-    if (y == H - 1 || !ws.mask[i + W]) atomicMax(&ws.ymax[r], y);
-  } else {
-    if (x == 0 || y == 0 || x == W - 1 || y == H - 1) ws.outside[r] = 1;
+  // Row range of every component (for a hole: of the fg pixels bordering it).  All lanes of a stretch sit on
+  // one image row and share r, so they would send the same (address, value) atomic -- thousands of them to
+  // the page background's root under every text line.  One atomic per stretch: the head lane sends it if any
+  // lane of its stretch asks.
+  const unsigned long long heads = __ballot(head);
+  const unsigned long long above = src >= 63 ? 0ull : (heads >> (src + 1)) << (src + 1);  // heads after mine
+  const int end = above ? __builtin_ctzll(above) : 64;                                        // my stretch = [src, end)
+  const unsigned long long smask = (end >= 64 ? ~0ull : ((1ull << end) - 1)) & ~((1ull << src) - 1);
+  const bool fg = ws.mask[i] != 0;
+  const bool up_fg = y > 0 && ws.mask[i - W], dn_fg = y < H - 1 && ws.mask[i + W];
+  const unsigned long long b_top = __ballot(fg && !up_fg), b_bot = __ballot(fg && !dn_fg);
+  const unsigned long long b_hole_top = __ballot(!fg && up_fg), b_hole_bot = __ballot(!fg && dn_fg);
+  const unsigned long long b_edge = __ballot(!fg && (x == 0 || y == 0 || x == W - 1 || y == H - 1));
+  if (head) {
+    if (b_top & smask) atomicMin(&ws.ymin[r], y);
+    if (b_bot & smask) atomicMax(&ws.ymax[r], y);
     // border rows of a hole: the fg pixels above its top / below its bottom
-    if (y > 0 && ws.mask[i - W]) atomicMin(&ws.ymin[r], y - 1);
-    if (y < H - 1 && ws.mask[i + W]) atomicMax(&ws.ymax[r], y + 1);
+    if (b_hole_top & smask) atomicMin(&ws.ymin[r], y - 1);
+    if (b_hole_bot & smask) atomicMax(&ws.ymax[r], y + 1);
+    if (b_edge & smask) ws.outside[r] = 1;
   }
 }
 // one contour per fg component (outer border) and per hole (bg component not touching
