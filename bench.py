@@ -250,6 +250,9 @@ def main():
                 if k:
                     roofline["traffic"] = k["fetch_bytes_per_launch"] + k["write_bytes_per_launch"]
                     roofline["traffic_source"] = "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload, FETCH_SIZE x2)"
+                    if "sq" in k:  # SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8) and the clock of that pass
+                        roofline["mfma_util_pmc"] = k["sq"]["mfma_util"]
+                        roofline["clock_ghz_pmc"] = k["sq"]["clock_ghz"]
             roofline.update({"kernel": name, "avg_launch_ms": round(avg_ms, 4), "launches_per_step": launches_per_step,
                              "measured": "HIP events on the session stream, serial pass (lanes=1) of the same %d steps, %.2f ms/step" % (a.steps, serial_ms),
                              "share_of_kernel_time": round(ms / total_ms, 3),

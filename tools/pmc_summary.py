@@ -3,12 +3,17 @@ per-kernel HBM bytes per launch.
 
     rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_fetch -o f -- python3 bench.py --steps 2 --warmup 2 --no-cpu-baseline --lanes 1
     rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_write -o w -- python3 bench.py --steps 2 --warmup 2 --no-cpu-baseline --lanes 1
-    python tools/pmc_summary.py gpurun_out/pmc_fetch/f_counter_collection.csv gpurun_out/pmc_write/w_counter_collection.csv profiles/pmc_traffic.json
+    rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d gpurun_out/pmc_sq -o s -- python3 bench.py ... (same flags)
+    python tools/pmc_summary.py gpurun_out/pmc_fetch/f_counter_collection.csv gpurun_out/pmc_write/w_counter_collection.csv profiles/pmc_traffic.json [gpurun_out/pmc_sq/s_counter_collection.csv]
 
 Units / corrections (MI355X_MICROARCH.md, HBM section): both counters are in KiB; on gfx950 FETCH_SIZE
 reports half of the bytes of 16-byte-per-lane coalesced reads (128-byte requests tallied at 64 bytes), so
 it is doubled; WRITE_SIZE is exact for 16-byte-per-lane stores.  Every load/store in these kernels is a
 16-byte vector access.
+
+Optional SQ pass: mfma_util = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8) -- the busy counter
+is summed over the SIMDs (it equals 32 cycles x the number of v_mfma_f32_16x16x4_f32 issued), GRBM_GUI_ACTIVE is
+summed over the 8 XCDs; clock_ghz = GRBM_GUI_ACTIVE / 8 / kernel time.  SQ_WAVE_CYCLES / WAIT_* are quad-cycles.
 """
 import collections
 import csv
@@ -30,19 +35,43 @@ def short(name):
     return m.group(1) if m else name
 
 
+def agg_multi(path):
+    d = collections.defaultdict(lambda: collections.defaultdict(lambda: [0, 0.0, 0.0]))
+    for r in csv.DictReader(open(path)):
+        e = d[r["Kernel_Name"]][r["Counter_Name"]]
+        e[0] += 1
+        e[1] += float(r["Counter_Value"])
+        e[2] += float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
+    return d
+
+
 def main():
     f, w, out = agg(sys.argv[1]), agg(sys.argv[2]), sys.argv[3]
+    sq = agg_multi(sys.argv[4]) if len(sys.argv) > 4 else {}
     res = {}
     for k, (n, fv) in f.items():
         wn, wv = w.get(k, [0, 0.0])
         res[short(k)] = {"launches": n, "fetch_bytes_per_launch": int(fv / n * 1024 * 2),
                          "write_bytes_per_launch": int(wv / max(wn, 1) * 1024)}
+    for k, ctrs in sq.items():
+        if short(k) not in res or "GRBM_GUI_ACTIVE" not in ctrs:
+            continue
+        avg = {c: v[1] / v[0] for c, v in ctrs.items()}
+        ns = ctrs["GRBM_GUI_ACTIVE"][2] / ctrs["GRBM_GUI_ACTIVE"][0]
+        xcd_cycles = avg["GRBM_GUI_ACTIVE"] / 8.0
+        res[short(k)]["sq"] = {
+            "mfma_util": round(avg.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (1024.0 * xcd_cycles), 4),
+            "clock_ghz": round(xcd_cycles / ns, 3),
+            "wave_wait_any_frac": round(avg.get("SQ_WAIT_ANY", 0.0) / max(avg.get("SQ_WAVE_CYCLES", 1.0), 1.0), 3),
+            "wave_wait_inst_frac": round(avg.get("SQ_WAIT_INST_ANY", 0.0) / max(avg.get("SQ_WAVE_CYCLES", 1.0), 1.0), 3),
+            "wave_active_inst_frac": round(avg.get("SQ_ACTIVE_INST_ANY", 0.0) / max(avg.get("SQ_WAVE_CYCLES", 1.0), 1.0), 3)}
     top = dict(sorted(res.items(), key=lambda kv: -(kv[1]["fetch_bytes_per_launch"] + kv[1]["write_bytes_per_launch"]) * kv[1]["launches"])[:40])
     json.dump({"command": "bench.py --steps 2 --warmup 2 --no-cpu-baseline --lanes 1 (C3 workload), separate --pmc FETCH_SIZE / --pmc WRITE_SIZE passes",
                "corrections": "KiB -> bytes; FETCH_SIZE x2 (gfx950 128-byte requests tallied at 64 bytes); WRITE_SIZE as is",
                "kernels": top}, open(out, "w"), indent=1)
     for k, v in list(top.items())[:12]:
-        print("%-44s n=%4d fetch %.3f GB write %.3f GB" % (k[:44], v["launches"], v["fetch_bytes_per_launch"] / 1e9, v["write_bytes_per_launch"] / 1e9))
+        print("%-44s n=%4d fetch %.3f GB write %.3f GB %s" % (k[:44], v["launches"], v["fetch_bytes_per_launch"] / 1e9,
+                                                             v["write_bytes_per_launch"] / 1e9, v.get("sq", "")))
 
 
 if __name__ == "__main__":
