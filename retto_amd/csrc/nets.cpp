@@ -231,8 +231,9 @@ static float* run_lc(RunCtx& c, const LcBlock& b, const float* x, const Level& L
   const int tile_rows = b.se ? nn::gemm_tile_rows(Lout.total, b.pw.Npad) : 0;
   long long min_pix = Lout.maxPix;
   for (const ImgGeom& g : Lout.h) min_pix = std::min<long long>(min_pix, (long long)g.H * g.W);
+  static const bool no_se_fusion = getenv("RT_NO_SE_FUSION") != nullptr;  // A/B switch
   const bool fuse_se = b.se && tile_rows > 0 && min_pix >= tile_rows && b.pw.K <= 512 && (b.dw.k == 3 || b.dw.k == 5) &&
-                       !getenv("RT_NO_SE_FUSION");
+                       !no_se_fusion;
   float* pool = nullptr; int chunks = 0, strip_R = 0;
   if (fuse_se) {
     nn::dwconv_pool_layout(b.sh, Lout.maxH, Lout.maxW, &chunks, &strip_R);

@@ -63,7 +63,7 @@ class Arena {
 class Pinned {
  public:
   ~Pinned();
-  void reset() { off_ = 0; }
+  void reset() { cur_ = 0; off_ = 0; }  // back to the first block: staging of the previous call has been consumed
   void* alloc_bytes(size_t bytes);
   template <typename T>
   T* alloc(size_t count) { return reinterpret_cast<T*>(alloc_bytes(count * sizeof(T))); }
