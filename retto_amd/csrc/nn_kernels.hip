@@ -955,6 +955,153 @@ __global__ __launch_bounds__(512) void k_gemm_dma(const float* __restrict__ A, i
     }
   }
 }
+// ---------------------------------------------------------------------------
+// Fused thin LCNetV3 block (3x3 depthwise stride 1, no SE, C_in <= 64, N <= 128):
+//   y = epi_pw( W_pw . lab(act(dw3x3(x) + b_dw)) )
+// These layers are HBM bound (a few channels per pixel): run separately they move 3*C_in + C_out floats per
+// pixel (depthwise read + write, GEMM read + write); fused, the depthwise result only ever exists as the
+// GEMM's A tile in LDS and the block moves C_in (+ halo) + C_out.  One workgroup = TH waves on a TH x 16 pixel
+// tile with ALL input channels: input patch ((TH+2) x 18 pixels) -> LDS, depthwise from LDS (taps in registers) -> A tile
+// [K/32][TH*16][36] in LDS, then the same mma_chunk / epilogue as k_gemm (TH/2 x 2 waves, 32 pixels x 16*NT
+// columns each) against the whole pointwise weight matrix, resident in LDS for the `tiles_per_block` tiles a
+// block walks.  TH = 4 (64 pixels, 256 threads, 22-66 KB of LDS) keeps several workgroups per CU.
+// Same accumulation order as k_dwconv_rows + k_gemm: bit-identical to the unfused pair.
+// ---------------------------------------------------------------------------
+template <int C4, int NT, int TH>
+__global__ __launch_bounds__(64 * TH) void k_lc_thin(const float* __restrict__ x, const ImgGeom* __restrict__ geom, int C,
+                                                     const float* __restrict__ Wd, const float* __restrict__ bd, int dw_act,
+                                                     int dw_has_lab, float dw_a, float dw_c, const float* __restrict__ Wp,
+                                                     int N, int Npad, float* __restrict__ y, int ldy, Epilogue epi,
+                                                     int tiles_per_block) {
+  constexpr int CP = C4 * 4, TW = 16, ROWS = TH * TW, NTHR = 64 * TH, PH = TH + 2, PW = TW + 2, PPITCH = CP + 4;
+  constexpr int NKC = (CP + KC - 1) / KC, NCOL = 32 * NT;
+  constexpr int NPF = (PH * PW * C4 + NTHR - 1) / NTHR;
+  __shared__ __attribute__((aligned(16))) float patch[PH * PW * PPITCH];
+  __shared__ __attribute__((aligned(16))) float at[NKC * ROWS * LROW];
+  __shared__ __attribute__((aligned(16))) float wt[NKC * NCOL * LROW];
+  const ImgGeom g = geom[blockIdx.y];
+  const int tiles_x = (g.W + TW - 1) / TW, n_tiles = tiles_x * ((g.H + TH - 1) / TH);
+  int tile = blockIdx.x * tiles_per_block;
+  if (tile >= n_tiles) return;
+  const int tile_end = min(n_tiles, tile + tiles_per_block);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, q = lane >> 4;
+  const int wm = wave >> 1, wn = wave & 1;
+  for (int idx = tid; idx < NKC * NCOL * 8; idx += NTHR) {
+    const int c4i = idx & 7, row = (idx >> 3) % NCOL, kc = (idx >> 3) / NCOL;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (row < Npad) v = *reinterpret_cast<const f32x4*>(Wp + ((long long)kc * Npad + row) * KC + c4i * 4);
+    *reinterpret_cast<f32x4*>(wt + (kc * NCOL + row) * LROW + c4i * 4) = v;
+  }
+  for (int idx = tid; idx < NKC * ROWS * LROW / 4; idx += NTHR) *reinterpret_cast<f32x4*>(at + idx * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
+  // depthwise work items: strips of SL pixels x C4 channel groups, one per thread (SL shrinks with C4 so that
+  // the threads stay busy: 16 groups -> 4 pixels, 8 -> 2, 4 -> 1); taps and bias of the item's group in registers
+  constexpr int SL = C4 >= 12 ? 4 : (C4 == 8 ? 2 : 1), ITEMS = (ROWS / SL) * C4;
+  static_assert(ITEMS <= NTHR, "one depthwise item per thread");
+  const int ic4 = tid % C4, ip0 = (tid / C4) * SL, ipy = ip0 / TW, ipx = ip0 % TW;
+  f32x4 dww[9], dwb;
+#pragma unroll
+  for (int t = 0; t < 9; t++) dww[t] = *reinterpret_cast<const f32x4*>(Wd + t * CP + ic4 * 4);
+  dwb = *reinterpret_cast<const f32x4*>(bd + ic4 * 4);
+  const int nt_valid = max(0, min(NT, Npad / 16 - wn * NT));
+  const int nstore = (N + 3) & ~3;
+  for (; tile < tile_end; tile++) {
+    const int oy0 = (tile / tiles_x) * TH, ox0 = (tile % tiles_x) * TW;
+    // input patch -> LDS (zero outside the image).  No cross-tile register prefetch: hipcc's s_waitcnt vmcnt(0)
+    // before the LDS writes would drain the prefetch and the previous tile's stores anyway; the 64-pixel variant
+    // keeps 2-7 workgroups per CU and lets them cover each other's load latency instead.
+    f32x4 pf[NPF];
+#pragma unroll
+    for (int i = 0; i < NPF; i++) {
+      const int e = tid + NTHR * i;
+      pf[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (e < PH * PW * C4) {
+        const int c4i = e % C4, px = e / C4, iy = oy0 - 1 + px / PW, ix = ox0 - 1 + px % PW;
+        if (iy >= 0 && iy < g.H && ix >= 0 && ix < g.W)
+          pf[i] = *reinterpret_cast<const f32x4*>(x + (g.off + (long long)iy * g.W + ix) * CP + c4i * 4);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NPF; i++) {
+      const int e = tid + NTHR * i;
+      if (e < PH * PW * C4) *reinterpret_cast<f32x4*>(patch + (e / C4) * PPITCH + (e % C4) * 4) = pf[i];
+    }
+    __syncthreads();  // patch complete; also: every wave is past the previous tile's reads of `at`
+    // depthwise: a 3 x (SL + 2) window of patch vectors feeds SL outputs
+    act_dispatch(dw_act, dw_has_lab, false, [&](auto atag, auto ltag, auto) {
+      constexpr int A = decltype(atag)::value, L = decltype(ltag)::value;
+      if (tid < ITEMS) {
+        f32x4 acc[SL];
+#pragma unroll
+        for (int j = 0; j < SL; j++) acc[j] = dwb;
+#pragma unroll
+        for (int dy = 0; dy < 3; dy++) {
+          f32x4 v[SL + 2];
+#pragma unroll
+          for (int j = 0; j < SL + 2; j++)
+            v[j] = *reinterpret_cast<const f32x4*>(patch + ((ipy + dy) * PW + ipx + j) * PPITCH + ic4 * 4);
+#pragma unroll
+          for (int dx = 0; dx < 3; dx++)
+#pragma unroll
+            for (int j = 0; j < SL; j++)
+#pragma unroll
+              for (int e = 0; e < 4; e++) acc[j][e] = fmaf(v[j + dx][e], dww[dy * 3 + dx][e], acc[j][e]);
+        }
+#pragma unroll
+        for (int j = 0; j < SL; j++) {
+          f32x4 o;
+#pragma unroll
+          for (int e = 0; e < 4; e++) o[e] = (ic4 * 4 + e < C) ? epi_val<A, L>(acc[j][e], dw_act, dw_has_lab, dw_a, dw_c) : 0.f;
+          *reinterpret_cast<f32x4*>(at + (((ic4 * 4) / KC) * ROWS + ip0 + j) * LROW + (ic4 * 4) % KC) = o;
+        }
+      }
+    });
+    __syncthreads();
+    f32x4 acc[2][NT];
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+      for (int j = 0; j < NT; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kc = 0; kc < NKC; kc++)
+      mma_chunk<NT>(at + (kc * ROWS + wm * 32 + r) * LROW, at + (kc * ROWS + wm * 32 + 16 + r) * LROW,
+                    wt + (kc * NCOL + wn * NT * 16) * LROW, nt_valid, acc, r, q);
+    const int p0 = wm * 32 + r, p1 = p0 + 16;
+    const int oya = oy0 + p0 / TW, oxa = ox0 + p0 % TW, oyb = oy0 + p1 / TW, oxb = ox0 + p1 % TW;
+    const long long pa = g.off + (long long)oya * g.W + oxa, pb = g.off + (long long)oyb * g.W + oxb;
+    epilogue_store<NT>(acc, nt_valid, epi, wn * NT * 16, N, nstore, y + pa * ldy, y + pb * ldy, oya < g.H && oxa < g.W,
+                       oyb < g.H && oxb < g.W, nullptr, nullptr, q);
+  }
+}
+
+int g_lc_thin = 1;  // 1 = fuse the thin stride-1 3x3 blocks (default); 0 = separate depthwise + GEMM kernels (A/B)
+bool lc_thin_supported(int K, int sh, int sw, int Cp, int C, int Npad16) {
+  if (!g_lc_thin || K != 3 || sh != 1 || sw != 1 || Cp != round_up(C, 4)) return false;
+  const int c4 = Cp / 4, nt = (Npad16 + 31) / 32;
+  return (c4 == 4 && nt == 1) || (c4 == 8 && nt == 2) || (c4 == 12 && nt == 2) || (c4 == 16 && nt == 2);
+}
+void lc_thin(hipStream_t st, const float* x, const ImgGeom* geom, int n_img, int maxH, int maxW, int Cp, int C,
+             const float* Wd, const float* bd, int dw_act, int dw_has_lab, float dw_a, float dw_c, const float* Wp, int N,
+             int Npad16, float* y, int ldy, const Epilogue& epi) {
+  if (n_img <= 0) return;
+  if (epi.residual || epi.a_scale) throw RtError(8, "lc_thin: residual / a_scale epilogues are not supported");
+  // measured per shape: 64-pixel tiles (more workgroups per CU) win from 48 channels up, 128-pixel tiles below
+  const int TH = g_lc_thin == 2 ? 8 : (g_lc_thin == 3 ? 4 : (Cp >= 48 ? 4 : 8));  // 2 / 3 force a variant (A/B)
+  const int tiles = ((maxW + 15) / 16) * ((maxH + TH - 1) / TH), tpb = 8;
+  dim3 grid((tiles + tpb - 1) / tpb, n_img);
+  const int c4 = Cp / 4, nt = (Npad16 + 31) / 32;
+#define RT_LCT(CC, NN)                                                                                                       \
+  do {                                                                                                                       \
+    if (TH == 4) hipLaunchKernelGGL((k_lc_thin<CC, NN, 4>), grid, dim3(256), 0, st, x, geom, C, Wd, bd, dw_act, dw_has_lab, dw_a, dw_c, Wp, N, Npad16, y, ldy, epi, tpb); \
+    else hipLaunchKernelGGL((k_lc_thin<CC, NN, 8>), grid, dim3(512), 0, st, x, geom, C, Wd, bd, dw_act, dw_has_lab, dw_a, dw_c, Wp, N, Npad16, y, ldy, epi, tpb); \
+  } while (0)
+  if (c4 == 4 && nt == 1) RT_LCT(4, 1);
+  else if (c4 == 8 && nt == 2) RT_LCT(8, 2);
+  else if (c4 == 12 && nt == 2) RT_LCT(12, 2);
+  else if (c4 == 16 && nt == 2) RT_LCT(16, 2);
+  else throw RtError(8, "lc_thin: unsupported shape (check lc_thin_supported)");
+#undef RT_LCT
+}
+
 static const float* zero_page() {
   static float* z = nullptr;
   if (!z) {

@@ -35,6 +35,15 @@ def gemm_pw_label(M: int, N: int, se: bool = False) -> str:
     return "gemm_pw/thin"
 
 
+def lc_thin_fused(k: int, sh: int, sw: int, cin: int, cout: int, se: bool) -> bool:
+    """Mirror of nn::lc_thin_supported: thin stride-1 3x3 blocks run as ONE kernel (k_lc_thin), whose algorithmic
+    traffic is the block's input + output (the depthwise result never reaches HBM)."""
+    if se or k != 3 or sh != 1 or sw != 1 or cin % 4:
+        return False
+    c4, nt = cin // 4, ((cout + 15) // 16 * 16 + 31) // 32
+    return (c4, nt) in ((4, 1), (8, 2), (12, 2), (16, 2))
+
+
 DET_GROUP_PX = 32 * 960 * 960   # session.cpp: det launch-group budget (det-input pixels)
 REC_GROUP_PX = 24000000         # session.cpp: rec launch-group budget (48 x W pixels)
 
@@ -70,10 +79,13 @@ def det_work(pages: Iterable[Tuple[int, int]]) -> Dict[str, Dict[str, float]]:
         taps = {}
         for name, k, cin, cout, sh, sw, se in synth.DET_BLOCKS:
             ho, wo = _down(h, sh), _down(ww, sw)
-            add("dwconv%d" % k, (h * ww + ho * wo) * cin * F + k * k * cin * F, 2 * ho * wo * cin * k * k)
-            scale = (ho * wo) / float(H * W)
-            m_group = int(round(sum(gh * gw for gh, gw in grp) * scale))
-            add(gemm_pw_label(m_group, cout, se), ho * wo * (cin + cout) * F + cin * cout * F, 2 * ho * wo * cin * cout)
+            if lc_thin_fused(k, sh, sw, cin, cout, se):
+                add("lc_thin", ho * wo * (cin + cout) * F + (k * k * cin + cin * cout) * F, 2 * ho * wo * cin * (k * k + cout))
+            else:
+                add("dwconv%d" % k, (h * ww + ho * wo) * cin * F + k * k * cin * F, 2 * ho * wo * cin * k * k)
+                scale = (ho * wo) / float(H * W)
+                m_group = int(round(sum(gh * gw for gh, gw in grp) * scale))
+                add(gemm_pw_label(m_group, cout, se), ho * wo * (cin + cout) * F + cin * cout * F, 2 * ho * wo * cin * cout)
             h, ww = ho, wo
             for j, (tn, tc, oc) in enumerate(synth.DET_TAPS):
                 if tn == name:
@@ -116,9 +128,12 @@ def rec_work(widths: Iterable[int], classes: int = synth.REC_CLASSES) -> Dict[st
         add("stem", H * W * 3 * F + h * ww * 16 * F, 2 * h * ww * 27 * 16)
         for name, k, cin, cout, sh, sw, se in synth.REC_BLOCKS:
             ho, wo = _down(h, sh), _down(ww, sw)
-            add("dwconv%d" % k, (h * ww + ho * wo) * cin * F + k * k * cin * F, 2 * ho * wo * cin * k * k)
-            m_group = int(round(grp_px * (ho * wo) / float(H * W)))
-            add(gemm_pw_label(m_group, cout, se), ho * wo * (cin + cout) * F + cin * cout * F, 2 * ho * wo * cin * cout)
+            if lc_thin_fused(k, sh, sw, cin, cout, se):
+                add("lc_thin", ho * wo * (cin + cout) * F + (k * k * cin + cin * cout) * F, 2 * ho * wo * cin * (k * k + cout))
+            else:
+                add("dwconv%d" % k, (h * ww + ho * wo) * cin * F + k * k * cin * F, 2 * ho * wo * cin * k * k)
+                m_group = int(round(grp_px * (ho * wo) / float(H * W)))
+                add(gemm_pw_label(m_group, cout, se), ho * wo * (cin + cout) * F + cin * cout * F, 2 * ho * wo * cin * cout)
             h, ww = ho, wo
         T = (ww - 2) // 2 + 1
         add("avgpool", (h * ww + T) * 480 * F)
