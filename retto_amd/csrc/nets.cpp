@@ -227,9 +227,9 @@ static float* run_lc(RunCtx& c, const LcBlock& b, const float* x, const Level& L
   if (!b.se && nn::lc_thin_supported(b.dw.k, b.sh, b.sw, b.dw.Cp, b.dw.C, b.pw.Npad) && b.pw.K == b.dw.Cp) {
     int Cpo = chan_pitch(b.cout);
     float* y2 = c.arena->alloc<float>((size_t)Lout.total * Cpo);
-    ProfScope ps(c.prof, c.st, "lc_thin", shape_str(Lout.total, b.dw.Cp, b.pw.N, 0));
-    nn::lc_thin(c.st, x, Lout.d, Lout.n(), Lout.maxH, Lout.maxW, b.dw.Cp, b.dw.C, b.dw.w, b.dw.b, b.dw_act, b.dw_lab.has,
-                b.dw_lab.a, b.dw_lab.c, b.pw.w, b.pw.N, b.pw.Npad, y2, Cpo, make_epi(b.pw, ACT_HSWISH, &b.pw_lab));
+    ProfScope ps(c.prof, c.st, "lc_thin", shape_str(Lout.total, b.dw.Cp, b.pw.N, b.sh * 10 + b.sw));
+    nn::lc_thin(c.st, b.sh, b.sw, x, Lin.d, Lout.d, Lout.n(), Lout.maxH, Lout.maxW, b.dw.Cp, b.dw.C, b.dw.w, b.dw.b, b.dw_act,
+                b.dw_lab.has, b.dw_lab.a, b.dw_lab.c, b.pw.w, b.pw.N, b.pw.Npad, y2, Cpo, make_epi(b.pw, ACT_HSWISH, &b.pw_lab));
     return y2;
   }
   float* y1 = c.arena->alloc<float>((size_t)Lout.total * b.dw.Cp);

@@ -956,7 +956,7 @@ __global__ __launch_bounds__(512) void k_gemm_dma(const float* __restrict__ A, i
   }
 }
 // ---------------------------------------------------------------------------
-// Fused thin LCNetV3 block (3x3 depthwise stride 1, no SE, C_in <= 64, N <= 128):
+// Fused thin LCNetV3 block (3x3 depthwise, strides (1,1) / (2,1) / (2,2), no SE, C_in <= 64, N <= 128):
 //   y = epi_pw( W_pw . lab(act(dw3x3(x) + b_dw)) )
 // These layers are HBM bound (a few channels per pixel): run separately they move 3*C_in + C_out floats per
 // pixel (depthwise read + write, GEMM read + write); fused, the depthwise result only ever exists as the
@@ -967,19 +967,21 @@ __global__ __launch_bounds__(512) void k_gemm_dma(const float* __restrict__ A, i
 // block walks.  TH = 4 (64 pixels, 256 threads, 22-66 KB of LDS) keeps several workgroups per CU.
 // Same accumulation order as k_dwconv_rows + k_gemm: bit-identical to the unfused pair.
 // ---------------------------------------------------------------------------
-template <int C4, int NT, int TH>
-__global__ __launch_bounds__(64 * TH) void k_lc_thin(const float* __restrict__ x, const ImgGeom* __restrict__ geom, int C,
+template <int C4, int NT, int TH, int SH, int SW>
+__global__ __launch_bounds__(64 * TH) void k_lc_thin(const float* __restrict__ x, const ImgGeom* __restrict__ gin,
+                                                     const ImgGeom* __restrict__ gout, int C,
                                                      const float* __restrict__ Wd, const float* __restrict__ bd, int dw_act,
                                                      int dw_has_lab, float dw_a, float dw_c, const float* __restrict__ Wp,
                                                      int N, int Npad, float* __restrict__ y, int ldy, Epilogue epi,
                                                      int tiles_per_block) {
-  constexpr int CP = C4 * 4, TW = 16, ROWS = TH * TW, NTHR = 64 * TH, PH = TH + 2, PW = TW + 2, PPITCH = CP + 4;
+  constexpr int CP = C4 * 4, TW = 16, ROWS = TH * TW, NTHR = 64 * TH, PPITCH = CP + 4;
+  constexpr int PH = (TH - 1) * SH + 3, PW = (TW - 1) * SW + 3;  // input patch of a TH x 16 output tile
   constexpr int NKC = (CP + KC - 1) / KC, NCOL = 32 * NT;
   constexpr int NPF = (PH * PW * C4 + NTHR - 1) / NTHR;
   __shared__ __attribute__((aligned(16))) float patch[PH * PW * PPITCH];
   __shared__ __attribute__((aligned(16))) float at[NKC * ROWS * LROW];
   __shared__ __attribute__((aligned(16))) float wt[NKC * NCOL * LROW];
-  const ImgGeom g = geom[blockIdx.y];
+  const ImgGeom g = gout[blockIdx.y], gi = gin[blockIdx.y];
   const int tiles_x = (g.W + TW - 1) / TW, n_tiles = tiles_x * ((g.H + TH - 1) / TH);
   int tile = blockIdx.x * tiles_per_block;
   if (tile >= n_tiles) return;
@@ -1015,9 +1017,9 @@ __global__ __launch_bounds__(64 * TH) void k_lc_thin(const float* __restrict__ x
       const int e = tid + NTHR * i;
       pf[i] = f32x4{0.f, 0.f, 0.f, 0.f};
       if (e < PH * PW * C4) {
-        const int c4i = e % C4, px = e / C4, iy = oy0 - 1 + px / PW, ix = ox0 - 1 + px % PW;
-        if (iy >= 0 && iy < g.H && ix >= 0 && ix < g.W)
-          pf[i] = *reinterpret_cast<const f32x4*>(x + (g.off + (long long)iy * g.W + ix) * CP + c4i * 4);
+        const int c4i = e % C4, px = e / C4, iy = oy0 * SH - 1 + px / PW, ix = ox0 * SW - 1 + px % PW;
+        if (iy >= 0 && iy < gi.H && ix >= 0 && ix < gi.W)
+          pf[i] = *reinterpret_cast<const f32x4*>(x + (gi.off + (long long)iy * gi.W + ix) * CP + c4i * 4);
       }
     }
 #pragma unroll
@@ -1026,7 +1028,7 @@ __global__ __launch_bounds__(64 * TH) void k_lc_thin(const float* __restrict__ x
       if (e < PH * PW * C4) *reinterpret_cast<f32x4*>(patch + (e / C4) * PPITCH + (e % C4) * 4) = pf[i];
     }
     __syncthreads();  // patch complete; also: every wave is past the previous tile's reads of `at`
-    // depthwise: a 3 x (SL + 2) window of patch vectors feeds SL outputs
+    // depthwise: a 3 x ((SL-1)*SW + 3) window of patch vectors feeds SL outputs
     act_dispatch(dw_act, dw_has_lab, false, [&](auto atag, auto ltag, auto) {
       constexpr int A = decltype(atag)::value, L = decltype(ltag)::value;
       if (tid < ITEMS) {
@@ -1035,16 +1037,17 @@ __global__ __launch_bounds__(64 * TH) void k_lc_thin(const float* __restrict__ x
         for (int j = 0; j < SL; j++) acc[j] = dwb;
 #pragma unroll
         for (int dy = 0; dy < 3; dy++) {
-          f32x4 v[SL + 2];
+          constexpr int NVW = (SL - 1) * SW + 3;
+          f32x4 v[NVW];
 #pragma unroll
-          for (int j = 0; j < SL + 2; j++)
-            v[j] = *reinterpret_cast<const f32x4*>(patch + ((ipy + dy) * PW + ipx + j) * PPITCH + ic4 * 4);
+          for (int j = 0; j < NVW; j++)
+            v[j] = *reinterpret_cast<const f32x4*>(patch + ((ipy * SH + dy) * PW + ipx * SW + j) * PPITCH + ic4 * 4);
 #pragma unroll
           for (int dx = 0; dx < 3; dx++)
 #pragma unroll
             for (int j = 0; j < SL; j++)
 #pragma unroll
-              for (int e = 0; e < 4; e++) acc[j][e] = fmaf(v[j + dx][e], dww[dy * 3 + dx][e], acc[j][e]);
+              for (int e = 0; e < 4; e++) acc[j][e] = fmaf(v[j * SW + dx][e], dww[dy * 3 + dx][e], acc[j][e]);
         }
 #pragma unroll
         for (int j = 0; j < SL; j++) {
@@ -1074,32 +1077,45 @@ __global__ __launch_bounds__(64 * TH) void k_lc_thin(const float* __restrict__ x
 }
 
 int g_lc_thin = 1;  // 1 = fuse the thin stride-1 3x3 blocks (default); 0 = separate depthwise + GEMM kernels (A/B)
-bool lc_thin_supported(int K, int sh, int sw, int Cp, int C, int Npad16) {
-  if (!g_lc_thin || K != 3 || sh != 1 || sw != 1 || Cp != round_up(C, 4)) return false;
+static int lc_thin_code(int sh, int sw, int Cp, int Npad16) {  // instantiated (stride, C_in/4, column tiles) combinations
   const int c4 = Cp / 4, nt = (Npad16 + 31) / 32;
-  return (c4 == 4 && nt == 1) || (c4 == 8 && nt == 2) || (c4 == 12 && nt == 2) || (c4 == 16 && nt == 2);
+  if (sh == 1 && sw == 1) {
+    if (c4 == 4 && nt == 1) return 1;
+    if (c4 == 8 && nt == 2) return 2;
+    if (c4 == 12 && nt == 2) return 3;
+    if (c4 == 16 && nt == 2) return 4;
+  } else if (sh == 2 && sw == 2) {  // ((2,1) 64 -> 128 of the rec net measured slower fused: 1.37 vs 1.05 ms)
+    if (c4 == 8 && nt == 2) return 6;   // det s3.0: 32 -> 48
+    if (c4 == 12 && nt == 3) return 7;  // det s4.0: 48 -> 96
+  }
+  return 0;
 }
-void lc_thin(hipStream_t st, const float* x, const ImgGeom* geom, int n_img, int maxH, int maxW, int Cp, int C,
-             const float* Wd, const float* bd, int dw_act, int dw_has_lab, float dw_a, float dw_c, const float* Wp, int N,
-             int Npad16, float* y, int ldy, const Epilogue& epi) {
+bool lc_thin_supported(int K, int sh, int sw, int Cp, int C, int Npad16) {
+  return g_lc_thin && K == 3 && Cp == round_up(C, 4) && lc_thin_code(sh, sw, Cp, Npad16) != 0;
+}
+void lc_thin(hipStream_t st, int sh, int sw, const float* x, const ImgGeom* gin, const ImgGeom* gout, int n_img, int maxHo,
+             int maxWo, int Cp, int C, const float* Wd, const float* bd, int dw_act, int dw_has_lab, float dw_a, float dw_c,
+             const float* Wp, int N, int Npad16, float* y, int ldy, const Epilogue& epi) {
   if (n_img <= 0) return;
   if (epi.residual || epi.a_scale) throw RtError(8, "lc_thin: residual / a_scale epilogues are not supported");
   // measured per shape: 64-pixel tiles (more workgroups per CU) win from 48 channels up, 128-pixel tiles below
-  const int TH = g_lc_thin == 2 ? 8 : (g_lc_thin == 3 ? 4 : (Cp >= 48 ? 4 : 8));  // 2 / 3 force a variant (A/B)
-  const int tiles = ((maxW + 15) / 16) * ((maxH + TH - 1) / TH), tpb = 8;
+  const int code = lc_thin_code(sh, sw, Cp, Npad16);
+  const int TH = code >= 6 ? 4 : (g_lc_thin == 2 ? 8 : (g_lc_thin == 3 ? 4 : (Cp >= 48 ? 4 : 8)));  // 2 / 3 force a variant (A/B)
+  const int tiles = ((maxWo + 15) / 16) * ((maxHo + TH - 1) / TH), tpb = 8;
   dim3 grid((tiles + tpb - 1) / tpb, n_img);
-  const int c4 = Cp / 4, nt = (Npad16 + 31) / 32;
-#define RT_LCT(CC, NN)                                                                                                       \
-  do {                                                                                                                       \
-    if (TH == 4) hipLaunchKernelGGL((k_lc_thin<CC, NN, 4>), grid, dim3(256), 0, st, x, geom, C, Wd, bd, dw_act, dw_has_lab, dw_a, dw_c, Wp, N, Npad16, y, ldy, epi, tpb); \
-    else hipLaunchKernelGGL((k_lc_thin<CC, NN, 8>), grid, dim3(512), 0, st, x, geom, C, Wd, bd, dw_act, dw_has_lab, dw_a, dw_c, Wp, N, Npad16, y, ldy, epi, tpb); \
-  } while (0)
-  if (c4 == 4 && nt == 1) RT_LCT(4, 1);
-  else if (c4 == 8 && nt == 2) RT_LCT(8, 2);
-  else if (c4 == 12 && nt == 2) RT_LCT(12, 2);
-  else if (c4 == 16 && nt == 2) RT_LCT(16, 2);
-  else throw RtError(8, "lc_thin: unsupported shape (check lc_thin_supported)");
+#define RT_LCT_T(CC, NN, TT, S1, S2) hipLaunchKernelGGL((k_lc_thin<CC, NN, TT, S1, S2>), grid, dim3(64 * TT), 0, st, x, gin, gout, C, Wd, bd, dw_act, dw_has_lab, dw_a, dw_c, Wp, N, Npad16, y, ldy, epi, tpb)
+#define RT_LCT(CC, NN) do { if (TH == 4) RT_LCT_T(CC, NN, 4, 1, 1); else RT_LCT_T(CC, NN, 8, 1, 1); } while (0)
+  switch (code) {
+    case 1: RT_LCT(4, 1); break;
+    case 2: RT_LCT(8, 2); break;
+    case 3: RT_LCT(12, 2); break;
+    case 4: RT_LCT(16, 2); break;
+    case 6: RT_LCT_T(8, 2, 4, 2, 2); break;
+    case 7: RT_LCT_T(12, 3, 4, 2, 2); break;
+    default: throw RtError(8, "lc_thin: unsupported shape (check lc_thin_supported)");
+  }
 #undef RT_LCT
+#undef RT_LCT_T
 }
 
 static const float* zero_page() {

@@ -38,10 +38,14 @@ def gemm_pw_label(M: int, N: int, se: bool = False) -> str:
 def lc_thin_fused(k: int, sh: int, sw: int, cin: int, cout: int, se: bool) -> bool:
     """Mirror of nn::lc_thin_supported: thin stride-1 3x3 blocks run as ONE kernel (k_lc_thin), whose algorithmic
     traffic is the block's input + output (the depthwise result never reaches HBM)."""
-    if se or k != 3 or sh != 1 or sw != 1 or cin % 4:
+    if se or k != 3 or cin % 4:
         return False
     c4, nt = cin // 4, ((cout + 15) // 16 * 16 + 31) // 32
-    return (c4, nt) in ((4, 1), (8, 2), (12, 2), (16, 2))
+    if (sh, sw) == (1, 1):
+        return (c4, nt) in ((4, 1), (8, 2), (12, 2), (16, 2))
+    if (sh, sw) == (2, 2):
+        return (c4, nt) in ((8, 2), (12, 3))
+    return False
 
 
 DET_GROUP_PX = 32 * 960 * 960   # session.cpp: det launch-group budget (det-input pixels)
@@ -80,7 +84,7 @@ def det_work(pages: Iterable[Tuple[int, int]]) -> Dict[str, Dict[str, float]]:
         for name, k, cin, cout, sh, sw, se in synth.DET_BLOCKS:
             ho, wo = _down(h, sh), _down(ww, sw)
             if lc_thin_fused(k, sh, sw, cin, cout, se):
-                add("lc_thin", ho * wo * (cin + cout) * F + (k * k * cin + cin * cout) * F, 2 * ho * wo * cin * (k * k + cout))
+                add("lc_thin", (h * ww * cin + ho * wo * cout) * F + (k * k * cin + cin * cout) * F, 2 * ho * wo * cin * (k * k + cout))
             else:
                 add("dwconv%d" % k, (h * ww + ho * wo) * cin * F + k * k * cin * F, 2 * ho * wo * cin * k * k)
                 scale = (ho * wo) / float(H * W)
@@ -129,7 +133,7 @@ def rec_work(widths: Iterable[int], classes: int = synth.REC_CLASSES) -> Dict[st
         for name, k, cin, cout, sh, sw, se in synth.REC_BLOCKS:
             ho, wo = _down(h, sh), _down(ww, sw)
             if lc_thin_fused(k, sh, sw, cin, cout, se):
-                add("lc_thin", ho * wo * (cin + cout) * F + (k * k * cin + cin * cout) * F, 2 * ho * wo * cin * (k * k + cout))
+                add("lc_thin", (h * ww * cin + ho * wo * cout) * F + (k * k * cin + cin * cout) * F, 2 * ho * wo * cin * (k * k + cout))
             else:
                 add("dwconv%d" % k, (h * ww + ho * wo) * cin * F + k * k * cin * F, 2 * ho * wo * cin * k * k)
                 m_group = int(round(grp_px * (ho * wo) / float(H * W)))
