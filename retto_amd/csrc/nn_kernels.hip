@@ -1006,22 +1006,26 @@ __global__ __launch_bounds__(64 * TH) void k_lc_thin(const float* __restrict__ x
   dwb = *reinterpret_cast<const f32x4*>(bd + ic4 * 4);
   const int nt_valid = max(0, min(NT, Npad / 16 - wn * NT));
   const int nstore = (N + 3) & ~3;
-  for (; tile < tile_end; tile++) {
-    const int oy0 = (tile / tiles_x) * TH, ox0 = (tile % tiles_x) * TW;
-    // input patch -> LDS (zero outside the image).  No cross-tile register prefetch: hipcc's s_waitcnt vmcnt(0)
-    // before the LDS writes would drain the prefetch and the previous tile's stores anyway; the 64-pixel variant
-    // keeps 2-7 workgroups per CU and lets them cover each other's load latency instead.
-    f32x4 pf[NPF];
+  // Input patch of a tile -> registers (zero outside the image).  The next tile's patch is requested right
+  // after the depthwise phase, so its latency overlaps the MFMAs and the stores of the current tile (hipcc
+  // drains vmcnt to 0 before the LDS writes anyway, so a longer prefetch distance buys nothing).
+  f32x4 pf[NPF];
+  auto fetch = [&](int t) {
+    const int ty0 = (t / tiles_x) * TH, tx0 = (t % tiles_x) * TW;
 #pragma unroll
     for (int i = 0; i < NPF; i++) {
       const int e = tid + NTHR * i;
       pf[i] = f32x4{0.f, 0.f, 0.f, 0.f};
       if (e < PH * PW * C4) {
-        const int c4i = e % C4, px = e / C4, iy = oy0 * SH - 1 + px / PW, ix = ox0 * SW - 1 + px % PW;
+        const int c4i = e % C4, px = e / C4, iy = ty0 * SH - 1 + px / PW, ix = tx0 * SW - 1 + px % PW;
         if (iy >= 0 && iy < gi.H && ix >= 0 && ix < gi.W)
           pf[i] = *reinterpret_cast<const f32x4*>(x + (gi.off + (long long)iy * gi.W + ix) * CP + c4i * 4);
       }
     }
+  };
+  fetch(tile);
+  for (; tile < tile_end; tile++) {
+    const int oy0 = (tile / tiles_x) * TH, ox0 = (tile % tiles_x) * TW;
 #pragma unroll
     for (int i = 0; i < NPF; i++) {
       const int e = tid + NTHR * i;
@@ -1059,6 +1063,7 @@ __global__ __launch_bounds__(64 * TH) void k_lc_thin(const float* __restrict__ x
       }
     });
     __syncthreads();
+    if (tile + 1 < tile_end) fetch(tile + 1);
     f32x4 acc[2][NT];
 #pragma unroll
     for (int i = 0; i < 2; i++)
