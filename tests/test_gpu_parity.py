@@ -341,3 +341,50 @@ def test_pipeline_raw_det_map(hip_session, oracle_session):
     _teacher_forced(oracle_session, hip_session)
     o = oracle_session.run(page)
     _assert_page_equal(r, o)
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_det_postprocess_rotated_fuzz(hip_session, seed):
+    """Random rotated text boxes (all angles, thin to fat, some touching each other or the frame) with soft
+    edges: the f64 calipers / Clipper trigonometry of the device must give the oracle's boxes bit for bit."""
+    rng = np.random.default_rng(1000 + seed)
+    H, W = int(rng.integers(6, 24)) * 32, int(rng.integers(6, 24)) * 32
+    boxes = []
+    for _ in range(int(rng.integers(1, 14))):
+        bw = float(rng.uniform(20, 0.6 * W)); bh = float(rng.uniform(4, 40))
+        boxes.append((float(rng.uniform(0, W)), float(rng.uniform(0, H)), bw, bh, float(rng.uniform(-90, 90))))
+    m = workload.planted_map_rotated(H, W, boxes)
+    m = np.clip(m + rng.normal(0, 0.08, m.shape).astype(np.float32), 0.0, 1.0).astype(np.float32)  # ragged borders
+    oh, ow = int(H * rng.uniform(0.5, 1.5)), int(W * rng.uniform(0.5, 1.5))
+    gb, gs = hip_session.det_postprocess(m, oh, ow)
+    rb, rs = R.det_postprocess(m, oh, ow)
+    assert len(gb) == len(rb)
+    assert np.array_equal(gb, rb)
+    assert np.array_equal(gs.view(np.uint32), rs.view(np.uint32))
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_crops_fuzz(hip_session, seed):
+    """Random (integer-cornered, as DB post produces them) quadrilaterals, including ones that stick out of the
+    page (white fill) and tall ones (rotate270): bicubic perspective crops and their resize-normalised tensors
+    are bit-exact."""
+    rng = np.random.default_rng(2000 + seed)
+    H, W = int(rng.integers(80, 500)), int(rng.integers(120, 700))
+    img = _rand_page(H, W, 3000 + seed)
+    boxes = []
+    for _ in range(6):
+        cx, cy = rng.uniform(0, W), rng.uniform(0, H)
+        hl, ht, th = rng.uniform(8, 0.4 * W), rng.uniform(3, 30), np.deg2rad(rng.uniform(-90, 90))
+        if rng.uniform() < 0.25:
+            hl, ht = ht, hl  # tall box -> rotate270 path
+        c, s_ = np.cos(th), np.sin(th)
+        pts = [(cx + sx * hl * c - sy * ht * s_, cy + sx * hl * s_ + sy * ht * c) for sx, sy in ((-1, -1), (1, -1), (1, 1), (-1, 1))]
+        boxes.append(np.round(np.array(pts, np.float32)))
+    boxes = np.stack(boxes).reshape(-1, 8).astype(np.float32)
+    got = hip_session.crop_images(img, boxes)
+    for b, g in zip(boxes, got):
+        ref = R.get_crop_img(img, b)
+        assert g.shape == ref.shape and np.array_equal(g, ref)
+        a = hip_session.resize_norm_image(g, g.shape[0], g.shape[1], 48, 320, max(320 / 48, g.shape[1] / g.shape[0]))
+        r = R.resize_norm_image(ref, ref.shape[0], ref.shape[1], 48, 320, max(320 / 48, ref.shape[1] / ref.shape[0]))
+        assert np.array_equal(a.view(np.uint32), r.view(np.uint32))
