@@ -242,9 +242,9 @@ static float* run_lc(RunCtx& c, const LcBlock& b, const float* x, const Level& L
   static const bool no_se_fusion = getenv("RT_NO_SE_FUSION") != nullptr;  // A/B switch
   const bool fuse_se = b.se && tile_rows > 0 && min_pix >= tile_rows && b.pw.K <= 512 && (b.dw.k == 3 || b.dw.k == 5) &&
                        !no_se_fusion;
-  float* pool = nullptr; int chunks = 0, strip_R = 0;
+  float* pool = nullptr; int chunks = 0, strip_R = 0, strips_pb = 32;
   if (fuse_se) {
-    nn::dwconv_pool_layout(b.sh, Lout.maxH, Lout.maxW, &chunks, &strip_R);
+    nn::dwconv_pool_layout(b.dw.k, b.sh, b.dw.Cp, Lout.maxH, Lout.maxW, &chunks, &strip_R, &strips_pb);
     pool = c.arena->alloc<float>((size_t)Lout.n() * chunks * b.dw.Cp);
   }
   { ProfScope ps(c.prof, c.st, b.dw.k == 3 ? "dwconv3" : "dwconv5", shape_str(Lin.total, Lout.total, b.dw.Cp, b.sh * 10 + b.sw));
@@ -254,7 +254,7 @@ static float* run_lc(RunCtx& c, const LcBlock& b, const float* x, const Level& L
   if (fuse_se) {
     float* scale = c.arena->alloc<float>((size_t)Lout.n() * b.dw.Cp);
     { ProfScope ps(c.prof, c.st, "se_pool_fc");
-      nn::se_fc_from_dw(c.st, pool, Lout.d, Lout.n(), chunks, strip_R, b.sew.C, b.dw.Cp, b.sew.w1, b.sew.b1, b.sew.w2,
+      nn::se_fc_from_dw(c.st, pool, Lout.d, Lout.n(), chunks, strip_R, strips_pb, b.sew.C, b.dw.Cp, b.sew.w1, b.sew.b1, b.sew.w2,
                         b.sew.b2, b.sew.Cr, HSIG_LCNET, 0, scale); }
     const long long tiles = (Lout.total + tile_rows - 1) / tile_rows;
     int* htab = c.pinned->alloc<int>((size_t)tiles * 2);

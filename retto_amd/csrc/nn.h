@@ -13,6 +13,8 @@ constexpr int KC = 32;  // K-chunk of the MFMA GEMM / conv kernels (weights are 
 void gemm(hipStream_t st, const float* A, int lda, long long M, int K, const float* Wp, int N, int Npad16, float* C,
           int ldc, int coff, const Epilogue& epi);
 const char* gemm_pw_label(long long M, int Npad16, bool a_scale = false);
+void set_dw_xcd(int v);  // A/B: XCD-aware block order of the depthwise kernel (default on)
+extern int g_dw_wide_slab_min, g_dw_wide_lp;
 extern int g_dw_variant;    // same for dwconv
 extern int g_gemm_variant;  // kernel micro-benchmark hook (0 = production dispatch)
 
@@ -27,10 +29,10 @@ void dwconv(hipStream_t st, int K, int sh, int sw, const float* x, const ImgGeom
             float lab_a, float lab_c, float* y, float* pool = nullptr);  // Cp = channel pitch (chan_pitch), C = real channels
 // Fused squeeze-excite pooling: with `pool` (n_img * chunks * Cp floats, dwconv_pool_layout) the depthwise
 // kernel also writes per-block channel sums of its output; se_fc_from_dw turns them into the scales.
-void dwconv_pool_layout(int sh, int maxHo, int maxWo, int* chunks, int* strip_R);
-void se_fc_from_dw(hipStream_t st, const float* partial, const ImgGeom* geom, int n_img, int chunks, int strip_R, int C,
-                   int Cp, const float* w1, const float* b1, const float* w2, const float* b2, int Cr, float slope,
-                   int residual, float* scale);
+void dwconv_pool_layout(int K, int sh, int Cp, int maxHo, int maxWo, int* chunks, int* strip_R, int* strips_per_block);
+void se_fc_from_dw(hipStream_t st, const float* partial, const ImgGeom* geom, int n_img, int chunks, int strip_R,
+                   int strips_per_block, int C, int Cp, const float* w1, const float* b1, const float* w2, const float* b2,
+                   int Cr, float slope, int residual, float* scale);
 // Row-tile height of the wide GEMM the dispatcher picks for (M, Npad16), 0 when it picks the narrow
 // kernel: Epilogue::a_scale (squeeze-excite scale folded into the A staging) needs a wide tile and
 // every image at least that many rows.

@@ -1579,7 +1579,8 @@ __global__ __launch_bounds__(256) void k_dwconv_lds(const float* __restrict__ x,
 // 128 VGPRs (4 waves/SIMD): +15 % over 3 waves at C = 480.  Measured and rejected: lane groups
 // spanning whole pixels with all the weights in LDS (1.2-1.5x slower), one-row-ahead register
 // prefetch (hipcc hoists every load: spills).
-template <int K, int R, int SH, int SW, int POOL>
+__device__ int g_dw_xcd_dev = 1;  // XCD-aware block order of k_dwconv_rows (A/B: set_dw_xcd)
+template <int K, int R, int SH, int SW, int POOL, int LP = 8>  // LP lanes (16 bytes each) side by side on a pixel: 32- or 64-channel slabs
 __global__ __launch_bounds__(256, 4) void k_dwconv_rows(const float* __restrict__ x, const ImgGeom* __restrict__ gin,
                                                      const ImgGeom* __restrict__ gout, int Cp, int C,
                                                      const float* __restrict__ Wd, const float* __restrict__ bias, int act,
@@ -1587,23 +1588,39 @@ __global__ __launch_bounds__(256, 4) void k_dwconv_rows(const float* __restrict_
                                                      float* __restrict__ pool) {
   constexpr int NV = 3 * SW + K;       // input columns feeding 4 output pixels
   constexpr int NI = (R - 1) * SH + K; // input rows feeding R output rows
-  __shared__ __attribute__((aligned(16))) float wl[K * K * 32];
-  const ImgGeom gi = gin[blockIdx.y], go = gout[blockIdx.y];
+  constexpr int SPB = 256 / LP;  // strips per block
+  __shared__ __attribute__((aligned(16))) float wl[K * K * LP * 4];
+  // XCD-aware block order: workgroups are dealt round-robin to the 8 XCDs (own L2 each), so neighbouring block
+  // ids -- which share halo columns / rows -- would sit on different L2s and each fetch the overlap.  Block id
+  // (xcd, seq) is mapped to work item xcd * (total / 8) + seq: every XCD walks one contiguous eighth of the
+  // (strip block, image, slab) space, neighbours meet in the same L2 shortly after each other.
+  unsigned bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+  if (g_dw_xcd_dev) {
+    // (within one channel slab: an XCD per slab -- the same remap over all three grid dimensions -- measured
+    // 1.4x slower at C = 256)
+    const unsigned gx = gridDim.x, gy = gridDim.y, total = gx * gy, per = total >> 3;
+    const unsigned lin = by * gx + bx, xcd = (lin + bz * total) & 7;
+    if (lin < per * 8 && (total & 7) == 0) {
+      const unsigned w = xcd * per + (lin >> 3);
+      bx = w % gx; by = w / gx;
+    }
+  }
+  const ImgGeom gi = gin[by], go = gout[by];
   const int strips_x = (go.W + 3) >> 2, strips_y = (go.H + R - 1) / R;
   // (Measured and rejected: channel slab as the fastest block coordinate -- 1.4x slower at C = 256.)
-  const int bx = blockIdx.x, nbx = gridDim.x;
-  if ((long long)bx * 32 >= (long long)strips_x * strips_y) return;
-  const int cbase = blockIdx.z * 32;
+  const int nbx = gridDim.x;
+  if ((long long)bx * SPB >= (long long)strips_x * strips_y) return;
+  const int cbase = bz * LP * 4;
   const int tid = threadIdx.x;
-  if (tid < K * K * 8) {
-    int t = tid >> 3, cc = tid & 7;
+  for (int i = tid; i < K * K * LP; i += 256) {
+    int t = i / LP, cc = i % LP;
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
     if (cbase + cc * 4 < Cp) v = *reinterpret_cast<const f32x4*>(Wd + t * Cp + cbase + cc * 4);
-    *reinterpret_cast<f32x4*>(wl + tid * 4) = v;
+    *reinterpret_cast<f32x4*>(wl + i * 4) = v;
   }
   __syncthreads();
-  const int c4 = tid & 7, ch = cbase + c4 * 4;
-  const long long strip = (long long)bx * 32 + (tid >> 3);
+  const int c4 = tid % LP, ch = cbase + c4 * 4;
+  const long long strip = (long long)bx * SPB + tid / LP;
   const bool active = ch < Cp && strip < (long long)strips_x * strips_y;
   f32x4 psum;  // squeeze-excite pooling: this thread's share of the channel sums (summed only in the store loop)
   if (active) {
@@ -1633,7 +1650,7 @@ __global__ __launch_bounds__(256, 4) void k_dwconv_rows(const float* __restrict_
       if (dy < 0 || dy >= K) continue;
 #pragma unroll
       for (int dx = 0; dx < K; dx++) {
-        const f32x4 w = *reinterpret_cast<const f32x4*>(wl + ((dy * K + dx) * 8 + c4) * 4);
+        const f32x4 w = *reinterpret_cast<const f32x4*>(wl + ((dy * K + dx) * LP + c4) * 4);
 #pragma unroll
         for (int j = 0; j < 4; j++)
 #pragma unroll
@@ -1666,23 +1683,26 @@ __global__ __launch_bounds__(256, 4) void k_dwconv_rows(const float* __restrict_
   } else {
     psum = f32x4{0.f, 0.f, 0.f, 0.f};
   }
-  if (POOL) {  // fixed-order reduction: 8 strips of a wave by shuffles, 4 waves through LDS -> pool[image][block][channel]
-    __shared__ __attribute__((aligned(16))) float red[4 * 8 * 4];
+  if (POOL) {  // fixed-order reduction: the strips of a wave by shuffles, 4 waves through LDS -> pool[image][block][channel]
+    __shared__ __attribute__((aligned(16))) float red[4 * LP * 4];
 #pragma unroll
-    for (int d = 8; d < 64; d <<= 1)
+    for (int d = LP; d < 64; d <<= 1)
 #pragma unroll
       for (int e = 0; e < 4; e++) psum[e] += __shfl_xor(psum[e], d);
-    if ((tid & 63) < 8) *reinterpret_cast<f32x4*>(red + ((tid >> 6) * 8 + (tid & 7)) * 4) = psum;
+    if ((tid & 63) < LP) *reinterpret_cast<f32x4*>(red + ((tid >> 6) * LP + (tid & (LP - 1))) * 4) = psum;
     __syncthreads();
-    if (tid < 8 && cbase + tid * 4 < Cp) {
+    if (tid < LP && cbase + tid * 4 < Cp) {
       f32x4 t = *reinterpret_cast<const f32x4*>(red + tid * 4);
 #pragma unroll
-      for (int w = 1; w < 4; w++) t += *reinterpret_cast<const f32x4*>(red + (w * 8 + tid) * 4);
-      *reinterpret_cast<f32x4*>(pool + ((long long)blockIdx.y * nbx + bx) * Cp + cbase + tid * 4) = t;
+      for (int w = 1; w < 4; w++) t += *reinterpret_cast<const f32x4*>(red + (w * LP + tid) * 4);
+      *reinterpret_cast<f32x4*>(pool + ((long long)by * nbx + bx) * Cp + cbase + tid * 4) = t;
     }
   }
 }
 
+void set_dw_xcd(int v) { RT_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_dw_xcd_dev), &v, sizeof(int))); }
+int g_dw_wide_slab_min = 192;      // channel pitch from which the 5x5 kernels use wide slabs (1 << 30: never, A/B)
+int g_dw_wide_lp = 16;             // 16 = 64-channel slabs, 32 = 128-channel slabs
 int g_dw_variant = 0;
 // Output rows per thread of k_dwconv_rows: 4 (stride 1) or 2 (stride 2); 3 for the 3- and 6-row maps of the
 // recognition net's last stages, where 4-row (2-row) strips would leave a quarter of the lanes' rows empty.
@@ -1700,6 +1720,25 @@ void dwconv(hipStream_t st, int K, int sh, int sw, const float* x, const ImgGeom
   if ((K == 3 || K == 5) && sh >= 1 && sh <= 2 && sw >= 1 && sw <= 2 && (g_dw_variant == 0 || g_dw_variant == 4)) {
     const int R = dw_strip_rows(sh, maxHo);  // input rows streamed: stride 1 -> R+K-1, stride 2 -> 2R+K-2
     long long strips = (long long)((maxWo + 3) / 4) * ((maxHo + R - 1) / R);
+    // 64- / 128-channel slabs (256 / 512 contiguous bytes per pixel and load) for wide tensors: the 5x5 kernel on
+    // 256 channels goes from 2.9 to 4.1 TB/s with 64-channel slabs; 32-channel slabs otherwise
+    const int lp = (K == 5 && Cp >= g_dw_wide_slab_min) ? g_dw_wide_lp : 8;
+    if (lp != 8) {
+      const int spb = 256 / lp;
+      dim3 gridw((unsigned)((strips + spb - 1) / spb), n_img, (Cp + lp * 4 - 1) / (lp * 4));
+#define RT_DWW(RR, SH_, SW_, LL)                                                                                             \
+  do {                                                                                                                       \
+    if (pool) hipLaunchKernelGGL((k_dwconv_rows<5, RR, SH_, SW_, 1, LL>), gridw, dim3(256), 0, st, x, gin, gout, Cp, C, Wd, bias, act, has_lab, lab_a, lab_c, y, pool); \
+    else hipLaunchKernelGGL((k_dwconv_rows<5, RR, SH_, SW_, 0, LL>), gridw, dim3(256), 0, st, x, gin, gout, Cp, C, Wd, bias, act, has_lab, lab_a, lab_c, y, pool); \
+  } while (0)
+#define RT_DWW_L(RR, SH_, SW_) do { if (lp == 16) RT_DWW(RR, SH_, SW_, 16); else RT_DWW(RR, SH_, SW_, 32); } while (0)
+      if (sh == 1 && sw == 1 && R == 4) { RT_DWW_L(4, 1, 1); return; }
+      if (sh == 1 && sw == 1 && R == 3) { RT_DWW_L(3, 1, 1); return; }
+      if (sh == 2 && sw == 1 && R == 2) { RT_DWW_L(2, 2, 1); return; }
+      if (sh == 2 && sw == 2 && R == 2) { RT_DWW_L(2, 2, 2); return; }
+#undef RT_DWW_L
+#undef RT_DWW
+    }
     dim3 grid((unsigned)((strips + 31) / 32), n_img, (Cp + 31) / 32);
 #define RT_DWR(KK, RR, SH_, SW_)                                                                                              \
   do {                                                                                                                       \
@@ -1862,7 +1901,7 @@ __global__ __launch_bounds__(256) void k_se_fc(const float* __restrict__ partial
                                                int chunks_alloc, int C, int Cp, const float* __restrict__ w1,
                                                const float* __restrict__ b1, const float* __restrict__ w2,
                                                const float* __restrict__ b2, int Cr, float slope, int residual,
-                                               float* __restrict__ scale, int strip_R) {
+                                               float* __restrict__ scale, int strip_R, int strips_per_block) {
   extern __shared__ float sm[];  // mean[Cp] + hid[Cr]
   float* mean = sm;
   float* hid = sm + Cp;
@@ -1870,7 +1909,7 @@ __global__ __launch_bounds__(256) void k_se_fc(const float* __restrict__ partial
   const long long npix = (long long)g.H * g.W;
   // partial sums come from k_pool_partial (POOL_PIX pixels each) or, strip_R > 0, from the blocks of the
   // depthwise kernel that produced the tensor (32 strips of strip_R x 4 pixels each)
-  const int chunks = strip_R > 0 ? (((g.W + 3) >> 2) * ((g.H + strip_R - 1) / strip_R) + 31) / 32
+  const int chunks = strip_R > 0 ? (((g.W + 3) >> 2) * ((g.H + strip_R - 1) / strip_R) + strips_per_block - 1) / strips_per_block
                                  : (int)((npix + POOL_PIX - 1) / POOL_PIX);
   const float inv = 1.0f / (float)npix;
   for (int c = threadIdx.x; c < Cp; c += 256) {
@@ -1908,19 +1947,20 @@ void se_scale(hipStream_t st, const float* x, const ImgGeom* geom, int n_img, lo
   int chunks = pool_chunks(max_pix);
   hipLaunchKernelGGL(k_pool_partial, dim3(chunks, n_img), dim3(256), 0, st, x, geom, Cp, chunks, partial);
   hipLaunchKernelGGL(k_se_fc, dim3(n_img), dim3(256), (Cp + Cr + 4) * sizeof(float), st, partial, geom, chunks, C, Cp,
-                     w1, b1, w2, b2, Cr, slope, residual, scale, 0);
+                     w1, b1, w2, b2, Cr, slope, residual, scale, 0, 32);
 }
-void dwconv_pool_layout(int sh, int maxHo, int maxWo, int* chunks, int* strip_R) {
-  const int R = dw_strip_rows(sh, maxHo);
-  *strip_R = R;
-  *chunks = (int)(((long long)((maxWo + 3) / 4) * ((maxHo + R - 1) / R) + 31) / 32);
+static int dw_strips_per_block(int K, int Cp) { return (K == 5 && Cp >= g_dw_wide_slab_min) ? 256 / g_dw_wide_lp : 32; }
+void dwconv_pool_layout(int K, int sh, int Cp, int maxHo, int maxWo, int* chunks, int* strip_R, int* strips_per_block) {
+  const int R = dw_strip_rows(sh, maxHo), spb = dw_strips_per_block(K, Cp);
+  *strip_R = R; *strips_per_block = spb;
+  *chunks = (int)(((long long)((maxWo + 3) / 4) * ((maxHo + R - 1) / R) + spb - 1) / spb);
 }
-void se_fc_from_dw(hipStream_t st, const float* partial, const ImgGeom* geom, int n_img, int chunks, int strip_R, int C,
-                   int Cp, const float* w1, const float* b1, const float* w2, const float* b2, int Cr, float slope,
-                   int residual, float* scale) {
+void se_fc_from_dw(hipStream_t st, const float* partial, const ImgGeom* geom, int n_img, int chunks, int strip_R,
+                   int strips_per_block, int C, int Cp, const float* w1, const float* b1, const float* w2, const float* b2,
+                   int Cr, float slope, int residual, float* scale) {
   if (n_img <= 0) return;
   hipLaunchKernelGGL(k_se_fc, dim3(n_img), dim3(256), (Cp + Cr + 4) * sizeof(float), st, partial, geom, chunks, C, Cp,
-                     w1, b1, w2, b2, Cr, slope, residual, scale, strip_R);
+                     w1, b1, w2, b2, Cr, slope, residual, scale, strip_R, strips_per_block);
 }
 void global_mean(hipStream_t st, const float* x, const ImgGeom* geom, int n_img, long long max_pix, int Cp,
                  float* partial, float* out) {
@@ -1929,7 +1969,7 @@ void global_mean(hipStream_t st, const float* x, const ImgGeom* geom, int n_img,
   hipLaunchKernelGGL(k_pool_partial, dim3(chunks, n_img), dim3(256), 0, st, x, geom, Cp, chunks, partial);
   hipLaunchKernelGGL(k_se_fc, dim3(n_img), dim3(256), (Cp + 4) * sizeof(float), st, partial, geom, chunks, Cp, Cp,
                      (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, 0,
-                     0.f, 0, out, 0);
+                     0.f, 0, out, 0, 32);
 }
 
 __global__ __launch_bounds__(256) void k_scale_channels(float* __restrict__ x, const ImgGeom* __restrict__ geom, int Cp,
