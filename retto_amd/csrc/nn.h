@@ -14,7 +14,7 @@ void gemm(hipStream_t st, const float* A, int lda, long long M, int K, const flo
           int ldc, int coff, const Epilogue& epi);
 const char* gemm_pw_label(long long M, int Npad16, bool a_scale = false);
 void set_dw_xcd(int v);  // A/B: XCD-aware block order of the depthwise kernel (default on)
-extern int g_dw_wide_slab_min, g_dw_wide_lp;
+extern int g_dw_wide_slab_min, g_dw_wide3_min, g_dw_wide_lp;
 extern int g_dw_variant;    // same for dwconv
 extern int g_gemm_variant;  // kernel micro-benchmark hook (0 = production dispatch)
 

@@ -1702,6 +1702,8 @@ __global__ __launch_bounds__(256, 4) void k_dwconv_rows(const float* __restrict_
 
 void set_dw_xcd(int v) { RT_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_dw_xcd_dev), &v, sizeof(int))); }
 int g_dw_wide_slab_min = 192;      // channel pitch from which the 5x5 kernels use wide slabs (1 << 30: never, A/B)
+static int dw_strips_per_block(int K, int Cp);
+int g_dw_wide3_min = 128;          // same for the 3x3 kernels (64-channel slabs)
 int g_dw_wide_lp = 16;             // 16 = 64-channel slabs, 32 = 128-channel slabs
 int g_dw_variant = 0;
 // Output rows per thread of k_dwconv_rows: 4 (stride 1) or 2 (stride 2); 3 for the 3- and 6-row maps of the
@@ -1722,20 +1724,22 @@ void dwconv(hipStream_t st, int K, int sh, int sw, const float* x, const ImgGeom
     long long strips = (long long)((maxWo + 3) / 4) * ((maxHo + R - 1) / R);
     // 64- / 128-channel slabs (256 / 512 contiguous bytes per pixel and load) for wide tensors: the 5x5 kernel on
     // 256 channels goes from 2.9 to 4.1 TB/s with 64-channel slabs; 32-channel slabs otherwise
-    const int lp = (K == 5 && Cp >= g_dw_wide_slab_min) ? g_dw_wide_lp : 8;
+    const int lp = dw_strips_per_block(K, Cp) == 32 ? 8 : 256 / dw_strips_per_block(K, Cp);
     if (lp != 8) {
       const int spb = 256 / lp;
       dim3 gridw((unsigned)((strips + spb - 1) / spb), n_img, (Cp + lp * 4 - 1) / (lp * 4));
-#define RT_DWW(RR, SH_, SW_, LL)                                                                                             \
+#define RT_DWW(KK, RR, SH_, SW_, LL)                                                                                         \
   do {                                                                                                                       \
-    if (pool) hipLaunchKernelGGL((k_dwconv_rows<5, RR, SH_, SW_, 1, LL>), gridw, dim3(256), 0, st, x, gin, gout, Cp, C, Wd, bias, act, has_lab, lab_a, lab_c, y, pool); \
-    else hipLaunchKernelGGL((k_dwconv_rows<5, RR, SH_, SW_, 0, LL>), gridw, dim3(256), 0, st, x, gin, gout, Cp, C, Wd, bias, act, has_lab, lab_a, lab_c, y, pool); \
+    if (pool) hipLaunchKernelGGL((k_dwconv_rows<KK, RR, SH_, SW_, 1, LL>), gridw, dim3(256), 0, st, x, gin, gout, Cp, C, Wd, bias, act, has_lab, lab_a, lab_c, y, pool); \
+    else hipLaunchKernelGGL((k_dwconv_rows<KK, RR, SH_, SW_, 0, LL>), gridw, dim3(256), 0, st, x, gin, gout, Cp, C, Wd, bias, act, has_lab, lab_a, lab_c, y, pool); \
   } while (0)
-#define RT_DWW_L(RR, SH_, SW_) do { if (lp == 16) RT_DWW(RR, SH_, SW_, 16); else RT_DWW(RR, SH_, SW_, 32); } while (0)
-      if (sh == 1 && sw == 1 && R == 4) { RT_DWW_L(4, 1, 1); return; }
-      if (sh == 1 && sw == 1 && R == 3) { RT_DWW_L(3, 1, 1); return; }
-      if (sh == 2 && sw == 1 && R == 2) { RT_DWW_L(2, 2, 1); return; }
-      if (sh == 2 && sw == 2 && R == 2) { RT_DWW_L(2, 2, 2); return; }
+#define RT_DWW_L(KK, RR, SH_, SW_) do { if (lp == 16) RT_DWW(KK, RR, SH_, SW_, 16); else RT_DWW(KK, RR, SH_, SW_, 32); } while (0)
+      if (K == 5 && sh == 1 && sw == 1 && R == 4) { RT_DWW_L(5, 4, 1, 1); return; }
+      if (K == 5 && sh == 1 && sw == 1 && R == 3) { RT_DWW_L(5, 3, 1, 1); return; }
+      if (K == 5 && sh == 2 && sw == 1 && R == 2) { RT_DWW_L(5, 2, 2, 1); return; }
+      if (K == 5 && sh == 2 && sw == 2 && R == 2) { RT_DWW_L(5, 2, 2, 2); return; }
+      if (K == 3 && sh == 1 && sw == 1 && R == 4 && !pool) { RT_DWW(3, 4, 1, 1, 16); return; }
+      if (K == 3 && sh == 1 && sw == 2 && R == 4 && !pool) { RT_DWW(3, 4, 1, 2, 16); return; }
 #undef RT_DWW_L
 #undef RT_DWW
     }
@@ -1949,7 +1953,11 @@ void se_scale(hipStream_t st, const float* x, const ImgGeom* geom, int n_img, lo
   hipLaunchKernelGGL(k_se_fc, dim3(n_img), dim3(256), (Cp + Cr + 4) * sizeof(float), st, partial, geom, chunks, C, Cp,
                      w1, b1, w2, b2, Cr, slope, residual, scale, 0, 32);
 }
-static int dw_strips_per_block(int K, int Cp) { return (K == 5 && Cp >= g_dw_wide_slab_min) ? 256 / g_dw_wide_lp : 32; }
+static int dw_strips_per_block(int K, int Cp) {  // 32-channel slabs (32 strips per block) unless the tensor is wide
+  if (K == 5 && Cp >= g_dw_wide_slab_min) return 256 / g_dw_wide_lp;
+  if (K == 3 && Cp >= g_dw_wide3_min) return 16;
+  return 32;
+}
 void dwconv_pool_layout(int K, int sh, int Cp, int maxHo, int maxWo, int* chunks, int* strip_R, int* strips_per_block) {
   const int R = dw_strip_rows(sh, maxHo), spb = dw_strips_per_block(K, Cp);
   *strip_R = R; *strips_per_block = spb;
