@@ -203,3 +203,54 @@ def test_oracle_pipeline_runs(oracle_session):
     assert len(r.det_boxes) == 2 and len(r.rec_tokens) == 2
     assert all(w >= 320 for w in r.rec_widths)
     assert set(r.cls_labels.tolist()) <= {0, 180}
+
+
+# ---- independent cross-checks of the restated third-party algorithms ------------------------------
+def test_contours_agree_with_scipy_labelling():
+    """Suzuki-Abe's result set = one outer border per 8-connected foreground component + one hole border per
+    4-connected background component that does not touch the frame (imageproc 0.25 find_contours); counted
+    independently with scipy.ndimage.label.  Every border pixel is foreground and belongs to the right component."""
+    from scipy import ndimage
+    rng = np.random.default_rng(3)
+    for trial in range(12):
+        h, w = int(rng.integers(5, 40)), int(rng.integers(5, 60))
+        m = (rng.uniform(0, 1, (h, w)) < rng.uniform(0.2, 0.8)).astype(np.uint8) * 255
+        cs = R.find_contours(m)
+        fg, n_fg = ndimage.label(m > 0, structure=np.ones((3, 3)))
+        bg, n_bg = ndimage.label(m == 0)  # 4-connected
+        frame = set(np.unique(np.concatenate([bg[0], bg[-1], bg[:, 0], bg[:, -1]]))) - {0}
+        assert sum(1 for _, bt in cs if bt == 0) == n_fg
+        assert sum(1 for _, bt in cs if bt == 1) == n_bg - len(frame)
+        seen = set()
+        for pts, bt in cs:
+            assert all(m[y, x] for x, y in pts)
+            if bt == 0:
+                labels = {int(fg[y, x]) for x, y in pts}
+                assert len(labels) == 1 and not (labels & seen)  # one outer border per component
+                seen |= labels
+
+
+def test_min_area_rect_against_brute_force():
+    """imageproc's rotating calipers must find the minimum over hull-edge directions: compare the area with a
+    brute-force scan of every hull edge in numpy (the corner order / flooring is the restatement's own)."""
+    from scipy.spatial import ConvexHull
+    rng = np.random.default_rng(5)
+    for trial in range(20):
+        pts = rng.integers(0, 200, (int(rng.integers(5, 60)), 2)).astype(np.float64)
+        hull = pts[ConvexHull(pts).vertices]
+        best = np.inf
+        for i in range(len(hull)):
+            e = hull[(i + 1) % len(hull)] - hull[i]
+            e /= np.hypot(*e)
+            u, v = hull @ e, hull @ np.array([-e[1], e[0]])
+            best = min(best, (u.max() - u.min()) * (v.max() - v.min()))
+        r = R.min_area_rect(pts)
+        a = np.hypot(*(r[1] - r[0])) * np.hypot(*(r[2] - r[1]))
+        # corners are truncated to integers (min_area_rect returns Point<i32>): allow the perimeter's worth of slack
+        assert abs(a - best) <= 2.0 * (np.hypot(*(r[1] - r[0])) + np.hypot(*(r[2] - r[1]))) + 4.0
+        # and every input point lies inside the (1-pixel dilated) rectangle
+        c = r.mean(0); ex = (r[1] - r[0]); ey = (r[3] - r[0])
+        lx, ly = np.hypot(*ex), np.hypot(*ey)
+        if lx > 0 and ly > 0:
+            pu, pv = (pts - c) @ (ex / lx), (pts - c) @ (ey / ly)
+            assert np.abs(pu).max() <= lx / 2 + 1.5 and np.abs(pv).max() <= ly / 2 + 1.5
