@@ -154,6 +154,15 @@ RT_API int rt_ctc_decode(rt_session* s, const float* probs, int n, int t, int c,
  * synthetic-weights benchmark and the teacher-forced parity tests use. */
 RT_API int rt_run_batch(rt_session* s, const uint8_t* const* rgb, const int* hs, const int* ws, int n_pages,
                         int mem, const float* const* det_map_override, rt_results** out);
+/* RettoSession::run_stream (session.rs:133-143): as rt_run_batch, and cb(user, page, stage, json) is called for
+ * every page with the stage's RettoWorkerStageResult JSON (stage 0 = Det, 1 = Cls, 2 = Rec; the reference's
+ * mpsc::Sender order Det -> Cls -> Rec per image is kept).  Det is delivered as soon as the boxes of the page
+ * are known -- before its crops are classified or read; Cls and Rec when the call completes.  Callbacks come
+ * from the library's lane threads, one at a time; json is only valid during the call. */
+typedef void (*rt_stage_callback)(void* user, int page, int stage, const char* json);
+RT_API int rt_run_batch_stream(rt_session* s, const uint8_t* const* rgb, const int* hs, const int* ws, int n_pages,
+                               int mem, const float* const* det_map_override, rt_stage_callback cb, void* user,
+                               rt_results** out);
 RT_API void rt_results_free(rt_results* r);
 RT_API int rt_results_pages(const rt_results* r);
 RT_API int rt_results_count(const rt_results* r, int page);

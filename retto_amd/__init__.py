@@ -410,9 +410,38 @@ class RettoSession:
         return self.run_batch([page])[0]
 
     def run_stream(self, image, sender: Callable[[str, list], None]) -> None:
-        """session.rs:133-143: emits ("Det", ...), ("Cls", ...), ("Rec", ...) in that order."""
-        r = self.run(image)
-        sender("Det", r.det_result); sender("Cls", r.cls_result); sender("Rec", r.rec_result)
+        """session.rs:133-143: emits ("Det", ...), ("Cls", ...), ("Rec", ...) in that order.  Det arrives while
+        the crops are still being classified / read (rt_run_batch_stream); the payloads are the parsed
+        RettoWorkerStageResult JSON of the stage."""
+        import json
+        page = decode_image(image) if isinstance(image, (bytes, bytearray, memoryview)) else np.ascontiguousarray(image, np.uint8)
+        self.run_batch_stream([page], lambda _page, stage, payload: sender(stage, payload))
+
+    def run_batch_stream(self, pages: Sequence[np.ndarray], on_stage: Callable[[int, str, list], None], det_map_override=None) -> None:
+        """on_stage(page index, "Det" | "Cls" | "Rec", parsed stage JSON), called from the library's lane threads."""
+        import json
+        pages = [np.ascontiguousarray(p, np.uint8) for p in pages]
+        n = len(pages)
+        ptrs = (C.c_void_p * n)(*[p.ctypes.data for p in pages])
+        hs = (C.c_int * n)(*[p.shape[0] for p in pages]); ws = (C.c_int * n)(*[p.shape[1] for p in pages])
+        maps = None
+        if det_map_override is not None:
+            keep = [None if m is None else np.ascontiguousarray(m, np.float32) for m in det_map_override]
+            maps = (C.c_void_p * n)(*[None if m is None else m.ctypes.data for m in keep])
+        errors = []
+
+        def cb(_user, page, stage, js):
+            try:
+                on_stage(page, ("Det", "Cls", "Rec")[stage], json.loads(js.decode("utf-8")))
+            except BaseException as e:  # never unwind through the C frames
+                errors.append(e)
+
+        ccb = _lib.STAGE_CALLBACK(cb)
+        out = C.c_void_p()
+        _check(self._hd.lib.rt_run_batch_stream(self._hd.h, ptrs, hs, ws, n, RT_MEM_HOST, maps, ccb, None, C.byref(out)), self._hd.h)
+        self._hd.lib.rt_results_free(out)
+        if errors:
+            raise errors[0]
 
     def stage_json(self, page: np.ndarray) -> List[str]:
         """RettoWorkerStageResult JSON strings (Det, Cls, Rec) in retto-wasm's serde shape."""

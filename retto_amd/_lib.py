@@ -44,13 +44,15 @@ EXPORTS = [
     "rt_resize_both_dims", "rt_resize_both", "rt_det_input_dims", "rt_det_preprocess", "rt_det_postprocess",
     "rt_crop_dims", "rt_crop_images", "rt_scale_and_clip", "rt_resize_norm_width", "rt_resize_norm_image",
     "rt_ctc_decode",
-    "rt_run_batch", "rt_results_free", "rt_results_pages", "rt_results_count", "rt_results_boxes",
+    "rt_run_batch", "rt_run_batch_stream", "rt_results_free", "rt_results_pages", "rt_results_count", "rt_results_boxes",
     "rt_results_det_scores", "rt_results_cls_labels", "rt_results_cls_scores", "rt_results_rec_scores",
     "rt_results_rec_tokens", "rt_results_rec_text", "rt_results_det_checksum", "rt_results_json",
     "rt_device_malloc", "rt_device_free", "rt_memcpy_h2d", "rt_memcpy_d2h", "rt_synchronize",
     "rt_set_lanes", "rt_profile_enable", "rt_profile_get",
     "rt_onnx_to_rtwb", "rt_buffer_free", "rt_model_manifest",
 ]
+
+STAGE_CALLBACK = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.c_int, C.c_char_p)  # rt_stage_callback
 
 _lib = None
 
@@ -118,6 +120,8 @@ def load():
                                   C.c_void_p, C.c_void_p, C.c_void_p]
     lib.rt_run_batch.argtypes = [C.c_void_p, P(C.c_void_p), P(C.c_int), P(C.c_int), C.c_int, C.c_int, P(C.c_void_p),
                                  P(C.c_void_p)]
+    lib.rt_run_batch_stream.argtypes = [C.c_void_p, P(C.c_void_p), P(C.c_int), P(C.c_int), C.c_int, C.c_int, P(C.c_void_p),
+                                        STAGE_CALLBACK, C.c_void_p, P(C.c_void_p)]
     lib.rt_profile_get.argtypes = [C.c_void_p, P(P(C.c_char_p)), P(P(C.c_float)), P(P(C.c_int)), P(C.c_int)]
     lib.rt_onnx_to_rtwb.argtypes = [C.c_int, C.c_void_p, C.c_size_t, P(C.c_void_p), P(C.c_size_t), C.c_char_p, C.c_size_t]
     lib.rt_buffer_free.argtypes = [C.c_void_p]

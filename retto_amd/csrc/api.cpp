@@ -164,6 +164,13 @@ int rt_run_batch(rt_session* s, const uint8_t* const* rgb, const int* hs, const 
   *out = nullptr;
   return guarded(s, [&] { *out = s->run_batch(rgb, hs, ws, n_pages, mem, det_map_override); });
 }
+int rt_run_batch_stream(rt_session* s, const uint8_t* const* rgb, const int* hs, const int* ws, int n_pages, int mem,
+                        const float* const* det_map_override, rt_stage_callback cb, void* user, rt_results** out) {
+  RT_REQUIRE(s && out && cb && n_pages >= 0 && (n_pages == 0 || (rgb && hs && ws)), s, "rt_run_batch_stream: bad argument");
+  RT_REQUIRE(mem == RT_MEM_HOST || mem == RT_MEM_DEVICE, s, "rt_run_batch_stream: bad mem kind");
+  *out = nullptr;
+  return guarded(s, [&] { *out = s->run_batch(rgb, hs, ws, n_pages, mem, det_map_override, cb, user); });
+}
 void rt_results_free(rt_results* r) { delete r; }
 int rt_results_pages(const rt_results* r) { return r ? (int)r->pages.size() : 0; }
 #define RT_PAGE(r, page) ((r) && (page) >= 0 && (size_t)(page) < (r)->pages.size() ? &(r)->pages[(size_t)(page)] : nullptr)

@@ -500,6 +500,19 @@ rt_results* rt_session::run_pages(const uint8_t* const* rgb, const int* hs, cons
     for (double v : hp) res->det_checksum += v;
   }
 
+  if (stage_cb) {  // run_stream: the Det stage is complete here (session.rs:98)
+    for (int i = 0; i < n_pages; i++) {
+      rt_results::Page P;
+      P.boxes.resize((size_t)pg[i].n_boxes * 8); P.det_scores.resize((size_t)pg[i].n_boxes);
+      for (int k = 0; k < pg[i].n_boxes; k++) {
+        float b[8]; memcpy(b, pg[i].boxes[k].pts, 32);
+        gm::scale_and_clip(b, (double)pg[i].after_w, (double)pg[i].after_h, (double)pg[i].ori_w, (double)pg[i].ori_h);
+        memcpy(&P.boxes[8 * k], b, 32);
+        P.det_scores[k] = pg[i].boxes[k].score;
+      }
+      emit_stage(i, 0, P);
+    }
+  }
   tick.lap("sync #1 + box D2H");
   // ---- a6: crops --------------------------------------------------------------------
   CropPlan plan;
@@ -670,6 +683,8 @@ rt_results* rt_session::run_pages(const uint8_t* const* rgb, const int* hs, cons
       P.text[k] = t;
     }
   }
+  if (stage_cb)
+    for (int i = 0; i < n_pages; i++) { emit_stage(i, 1, res->pages[i]); emit_stage(i, 2, res->pages[i]); }
   tick.lap("results");
   last_exit = std::chrono::steady_clock::now();
   return res.release();
@@ -679,8 +694,15 @@ rt_results* rt_session::run_pages(const uint8_t* const* rgb, const int* hs, cons
 // concurrent host threads; every lane is a full pipeline on its own stream, so one lane's
 // small kernels, launch gaps and host sync points overlap the other lanes' large kernels.
 rt_results* rt_session::run_batch(const uint8_t* const* rgb, const int* hs, const int* ws, int n_pages, int mem,
-                                  const float* const* det_map_override) {
+                                  const float* const* det_map_override, rt_stage_callback cb, void* user) {
   const int nl = std::max(1, std::min<int>(std::min<int>((int)helpers.size() + 1, active_lanes), std::max(n_pages, 1)));
+  std::mutex cb_mu;
+  auto arm = [&](rt_session* s, int base) { s->stage_cb = cb; s->stage_user = user; s->stage_mu = &cb_mu; s->page_base = base; };
+  struct Disarm {  // the callback never outlives the call
+    rt_session* self;
+    ~Disarm() { self->stage_cb = nullptr; self->stage_mu = nullptr; for (auto& h : self->helpers) { h->stage_cb = nullptr; h->stage_mu = nullptr; } }
+  } disarm{this};
+  arm(this, 0);
   if (nl <= 1) return run_pages(rgb, hs, ws, n_pages, mem, det_map_override);
   std::vector<rt_results*> parts((size_t)nl, nullptr);
   std::vector<std::exception_ptr> errs((size_t)nl);
@@ -688,6 +710,7 @@ rt_results* rt_session::run_batch(const uint8_t* const* rgb, const int* hs, cons
   for (int l = 0; l < nl; l++) first[l + 1] = first[l] + n_pages / nl + (l < n_pages % nl ? 1 : 0);
   auto work = [&](int l) {
     rt_session* s = l == 0 ? this : helpers[(size_t)l - 1].get();
+    arm(s, first[l]);
     try {
       parts[l] = s->run_pages(rgb + first[l], hs + first[l], ws + first[l], first[l + 1] - first[l], mem,
                               det_map_override ? det_map_override + first[l] : nullptr);
@@ -712,8 +735,7 @@ rt_results* rt_session::run_batch(const uint8_t* const* rgb, const int* hs, cons
 }
 
 // RettoWorkerStageResult JSON (serde derive shapes; retto-wasm/fe/index.ts:5-42)
-const char* rt_results_json_impl(rt_results* r, int page, int stage) {
-  rt_results::Page& P = r->pages[(size_t)page];
+static std::string stage_json(const rt_results::Page& P, int stage) {
   std::ostringstream o;
   size_t n = P.det_scores.size();
   if (stage == 0) {
@@ -734,6 +756,17 @@ const char* rt_results_json_impl(rt_results* r, int page, int stage) {
     for (size_t k = 0; k < n; k++) { if (k) o << ","; o << "{\"text\":\"" << json_escape(P.text[k]) << "\",\"score\":" << fnum(P.rec_scores[k]) << "}"; }
     o << "]";
   }
-  P.json[stage] = o.str();
+  return o.str();
+}
+const char* rt_results_json_impl(rt_results* r, int page, int stage) {
+  rt_results::Page& P = r->pages[(size_t)page];
+  P.json[stage] = stage_json(P, stage);
   return P.json[stage].c_str();
+}
+void rt_session::emit_stage(int page, int stage, const rt_results::Page& P) {
+  if (!stage_cb) return;
+  const std::string j = stage_json(P, stage);
+  std::unique_lock<std::mutex> lk;
+  if (stage_mu) lk = std::unique_lock<std::mutex>(*stage_mu);
+  stage_cb(stage_user, page_base + page, stage, j.c_str());
 }

@@ -3,6 +3,7 @@
 // tensor-level worker entry points (worker.rs:69-73) and the stage functions.
 #pragma once
 #include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -45,6 +46,13 @@ struct rt_session {
   std::vector<std::string> dict;  // RecCharacter (rec_processor.rs:29-46)
   std::string last_error;
   int* d_flags = nullptr;         // [0] thumbnail/resize error flag
+  // run_stream (session.rs:133-143): stage results are handed to the callback as soon as the stage is complete --
+  // Det after the box round trip (before any crop is classified or read), Cls and Rec when the call ends.
+  rt_stage_callback stage_cb = nullptr;
+  void* stage_user = nullptr;
+  std::mutex* stage_mu = nullptr;  // callbacks of concurrent lanes are serialised
+  int page_base = 0;               // global index of this lane's first page
+  void emit_stage(int page, int stage, const rt_results::Page& P);
 
   rt::RunCtx ctx(rt::Arena* a) { return rt::RunCtx{st, a, &pinned, &prof}; }
   void begin_call();
@@ -67,7 +75,7 @@ struct rt_session {
                   int32_t* n_tokens, float* scores);
   // L2
   rt_results* run_batch(const uint8_t* const* rgb, const int* hs, const int* ws, int n_pages, int mem,
-                        const float* const* det_map_override);
+                        const float* const* det_map_override, rt_stage_callback cb = nullptr, void* user = nullptr);
   rt_results* run_pages(const uint8_t* const* rgb, const int* hs, const int* ws, int n_pages, int mem,
                         const float* const* det_map_override);  // one lane
 };

@@ -196,3 +196,34 @@ def test_native_directory_driver(tmp_path):
             assert l["det"] == det_j and l["cls"] == cls_j and l["rec"] == rec_j
     finally:
         s.close()
+
+
+def test_run_stream_order_and_payloads(hip_session):
+    """session.rs:133-143: per image Det, then Cls, then Rec; payloads equal the stage JSON of a plain run.  With
+    several pages (3 lanes) every page still sees its own stages in order and each exactly once."""
+    import json
+    from retto_amd import workload
+    pages, maps = [], []
+    for i in range(5):
+        page, rects = workload.planted_page(160 + 32 * i, 320, 2 + i % 2, seed=60 + i)
+        pages.append(page)
+        dh, dw = hip_session.det_preprocess(page).shape[2:]
+        maps.append(workload.planted_map(dh, dw, page.shape[0], page.shape[1], rects))
+    events = []
+    hip_session.run_batch_stream(pages, lambda p, stage, payload: events.append((p, stage, payload)), det_map_override=maps)
+    assert len(events) == 15
+    for p in range(5):
+        mine = [(s, pl) for q, s, pl in events if q == p]
+        assert [s for s, _ in mine] == ["Det", "Cls", "Rec"]
+        plain = hip_session.run_batch([pages[p]], det_map_override=[maps[p]])[0]
+        assert len(mine[0][1]) == len(plain.det_result) > 0
+        assert [d["score"] for d in mine[0][1]] == [float(np.float32(d.score)) for d in plain.det_result] or \
+            np.allclose([d["score"] for d in mine[0][1]], [d.score for d in plain.det_result], rtol=1e-6)
+        assert [[(pt["x"], pt["y"]) for pt in d["boxes"]["inner"]] for d in mine[0][1]] == \
+            [[(pt.x, pt.y) for pt in d.boxes.inner] for d in plain.det_result]
+        assert [c["label"]["label"] for c in mine[1][1]] == [c.label.label for c in plain.cls_result]
+        assert [t["text"] for t in mine[2][1]] == [t.text for t in plain.rec_result]
+    # the reference entry: one image, a sender
+    got = []
+    hip_session.run_stream(pages[0], lambda stage, payload: got.append(stage))
+    assert got == ["Det", "Cls", "Rec"]
