@@ -12,6 +12,9 @@ void thumbnail_rgb8(hipStream_t st, const uint8_t* src, int h, int w, uint8_t* d
 
 // det_processor.rs:151-160 + image_helper.rs:211-221: RGB8 HWC -> normalised BGR f32.
 // layout 0: NHWC pitch 4 (B,G,R,0); layout 1: CHW planes
+struct NormDesc { const uint8_t* rgb; long long npix; long long out_pix; };  // one page of a det launch group
+void det_normalize_batch(hipStream_t st, const NormDesc* d_descs, int n, long long max_pix, float scale, const float* mean3,
+                         const float* std3, float* out);
 void det_normalize(hipStream_t st, const uint8_t* rgb, int h, int w, float scale, const float* mean3,
                    const float* std3, int layout, float* out);
 

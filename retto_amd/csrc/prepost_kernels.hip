@@ -128,6 +128,26 @@ __global__ __launch_bounds__(256) void k_det_normalize(const u8* __restrict__ rg
     out[p] = v[0]; out[npix + p] = v[1]; out[2 * npix + p] = v[2];
   }
 }
+// all pages of a det launch group in one launch (layout 0: [pixel][4] f32, the stem's input)
+__global__ __launch_bounds__(256) void k_det_normalize_batch(const NormDesc* __restrict__ descs, Norm3 nm, float* __restrict__ out) {
+  const NormDesc d = descs[blockIdx.y];
+  long long p = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (p >= d.npix) return;
+  float v[3];
+#pragma unroll
+  for (int c = 0; c < 3; c++) {  // channel c of BGR
+    float x = (float)d.rgb[p * 3 + (2 - c)];
+    v[c] = (x * nm.scale - nm.mean[c]) / nm.stdv[c];
+  }
+  reinterpret_cast<float4*>(out)[d.out_pix + p] = make_float4(v[0], v[1], v[2], 0.0f);
+}
+void det_normalize_batch(hipStream_t st, const NormDesc* d_descs, int n, long long max_pix, float scale, const float* mean3,
+                         const float* std3, float* out) {
+  if (n <= 0 || max_pix <= 0) return;
+  Norm3 nm; nm.scale = scale;
+  for (int i = 0; i < 3; i++) { nm.mean[i] = mean3[i]; nm.stdv[i] = std3[i]; }
+  hipLaunchKernelGGL(k_det_normalize_batch, dim3((unsigned)((max_pix + 255) / 256), n), dim3(256), 0, st, d_descs, nm, out);
+}
 void det_normalize(hipStream_t st, const uint8_t* rgb, int h, int w, float scale, const float* mean3,
                    const float* std3, int layout, float* out) {
   long long npix = (long long)h * w;

@@ -429,10 +429,18 @@ rt_results* rt_session::run_pages(const uint8_t* const* rgb, const int* hs, cons
     Level L0 = make_level(hw);
     scratch.rewind();
     float* x = scratch.alloc<float>((size_t)L0.total * 4);
-    for (int i = g0; i < g1; i++) {
+    {  // a3 normalise: every page of the group in one launch
+      const int gn = g1 - g0;
+      pp::NormDesc* hd = pinned.alloc<pp::NormDesc>((size_t)gn);
+      pp::NormDesc* dd = scratch.alloc<pp::NormDesc>((size_t)gn);
+      long long max_pix = 0;
+      for (int i = g0; i < g1; i++) {
+        hd[i - g0] = pp::NormDesc{det_img[i], (long long)pg[i].det_h * pg[i].det_w, L0.h[i - g0].off};
+        max_pix = std::max(max_pix, hd[i - g0].npix);
+      }
+      RT_HIP_CHECK(hipMemcpyAsync(dd, hd, (size_t)gn * sizeof(pp::NormDesc), hipMemcpyHostToDevice, st));
       ProfScope ps(&prof, st, "det_normalize");
-      pp::det_normalize(st, det_img[i], pg[i].det_h, pg[i].det_w, cfg.det_scale, cfg.det_mean, cfg.det_std, 0,
-                        x + L0.h[i - g0].off * 4);
+      pp::det_normalize_batch(st, dd, gn, max_pix, cfg.det_scale, cfg.det_mean, cfg.det_std, x);
     }
     RunCtx c = ctx(&scratch);
     float* map;
