@@ -1352,26 +1352,53 @@ __global__ __launch_bounds__(256) void k_conv_sp(const float* __restrict__ x, in
   const int py0 = p0 / TW, px0 = p0 % TW, py1 = p1 / TW, px1 = p1 % TW;
 
   const int nkc = (Cin + KC - 1) / KC;
-  for (int kc = 0; kc < nkc; kc++) {
+  // The next 32-channel slab (halo pixels + taps) is requested into registers before the MFMAs of the current one
+  // and written to LDS after them: its latency hides behind TAPS x mma_chunk instead of sitting between barriers.
+  constexpr int XLD = (HH * HW * 8 + 255) / 256, WLD = (TAPS * 16 * NT * 8 + 255) / 256;
+  f32x4 px_[XLD], pw_[WLD];
+  auto fetch = [&](int kc) {
     const int k0 = kc * KC;
-    for (int idx = tid; idx < HH * HW * 8; idx += 256) {
-      int hp = idx >> 3, c4 = idx & 7;
-      int hy = hp / HW, hx = hp % HW;
-      int gy = ty * TH + hy - KH / 2, gx = tx * TW + hx - KW / 2;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (gy >= 0 && gy < g.H && gx >= 0 && gx < g.W && k0 + c4 * 4 < Cin)
-        v = *reinterpret_cast<const f32x4*>(x + (g.off + (long long)gy * g.W + gx) * ldx + k0 + c4 * 4);
-      *reinterpret_cast<f32x4*>(xs + hp * LROW + c4 * 4) = v;
+#pragma unroll
+    for (int i = 0; i < XLD; i++) {
+      const int idx = tid + 256 * i;
+      px_[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (idx < HH * HW * 8) {
+        int hp = idx >> 3, c4 = idx & 7;
+        int hy = hp / HW, hx = hp % HW;
+        int gy = ty * TH + hy - KH / 2, gx = tx * TW + hx - KW / 2;
+        if (gy >= 0 && gy < g.H && gx >= 0 && gx < g.W && k0 + c4 * 4 < Cin)
+          px_[i] = *reinterpret_cast<const f32x4*>(x + (g.off + (long long)gy * g.W + gx) * ldx + k0 + c4 * 4);
+      }
     }
-    for (int idx = tid; idx < TAPS * 16 * NT * 8; idx += 256) {
-      int row = idx >> 3, c4 = idx & 7;
-      int tap = row / (16 * NT), n = row % (16 * NT);
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (n0 + n < Npad)
-        v = *reinterpret_cast<const f32x4*>(Wp + (((long long)kc * TAPS + tap) * Npad + n0 + n) * KC + c4 * 4);
-      *reinterpret_cast<f32x4*>(ws + row * LROW + c4 * 4) = v;
+#pragma unroll
+    for (int i = 0; i < WLD; i++) {
+      const int idx = tid + 256 * i;
+      pw_[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (idx < TAPS * 16 * NT * 8) {
+        int row = idx >> 3, c4 = idx & 7;
+        int tap = row / (16 * NT), n = row % (16 * NT);
+        if (n0 + n < Npad)
+          pw_[i] = *reinterpret_cast<const f32x4*>(Wp + (((long long)kc * TAPS + tap) * Npad + n0 + n) * KC + c4 * 4);
+      }
     }
+  };
+  auto stash = [&]() {
+#pragma unroll
+    for (int i = 0; i < XLD; i++) {
+      const int idx = tid + 256 * i;
+      if (idx < HH * HW * 8) *reinterpret_cast<f32x4*>(xs + (idx >> 3) * LROW + (idx & 7) * 4) = px_[i];
+    }
+#pragma unroll
+    for (int i = 0; i < WLD; i++) {
+      const int idx = tid + 256 * i;
+      if (idx < TAPS * 16 * NT * 8) *reinterpret_cast<f32x4*>(ws + (idx >> 3) * LROW + (idx & 7) * 4) = pw_[i];
+    }
+  };
+  fetch(0);
+  for (int kc = 0; kc < nkc; kc++) {
+    stash();
     __syncthreads();
+    if (kc + 1 < nkc) fetch(kc + 1);
 #pragma unroll
     for (int dy = 0; dy < KH; dy++)
 #pragma unroll
