@@ -140,26 +140,40 @@ __global__ __launch_bounds__(256) void k_gemm(const float* __restrict__ A, int l
     for (int j = 0; j < NT; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int nkc = (K + KC - 1) / KC;
-  for (int kc = 0; kc < nkc; kc++) {
+  // next K-slab (128 activation rows + 16*NT weight rows) in registers while the current one is multiplied
+  constexpr int W_LD = (16 * NT * 8 + 255) / 256;
+  f32x4 pa[4], pw[W_LD];
+  auto fetch = [&](int kc) {
     const int k0 = kc * KC;
-    // stage X: 128 rows x 32 floats
 #pragma unroll
     for (int i = 0; i < 4; i++) {
       int idx = tid + 256 * i;
       int row = idx >> 3, c4 = idx & 7;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      pa[i] = f32x4{0.f, 0.f, 0.f, 0.f};
       long long m = m0 + row;
-      if (m < M && k0 + c4 * 4 < K) v = *reinterpret_cast<const f32x4*>(A + m * lda + k0 + c4 * 4);
-      *reinterpret_cast<f32x4*>(xs + row * LROW + c4 * 4) = v;
+      if (m < M && k0 + c4 * 4 < K) pa[i] = *reinterpret_cast<const f32x4*>(A + m * lda + k0 + c4 * 4);
     }
-    // stage W: 16*NT rows x 32 floats
-    for (int idx = tid; idx < 16 * NT * 8; idx += 256) {
-      int row = idx >> 3, c4 = idx & 7;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (n0 + row < Npad) v = *reinterpret_cast<const f32x4*>(Wp + ((long long)kc * Npad + n0 + row) * KC + c4 * 4);
-      *reinterpret_cast<f32x4*>(ws + row * LROW + c4 * 4) = v;
+#pragma unroll
+    for (int i = 0; i < W_LD; i++) {
+      int idx = tid + 256 * i, row = idx >> 3, c4 = idx & 7;
+      pw[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (idx < 16 * NT * 8 && n0 + row < Npad) pw[i] = *reinterpret_cast<const f32x4*>(Wp + ((long long)kc * Npad + n0 + row) * KC + c4 * 4);
+    }
+  };
+  fetch(0);
+  for (int kc = 0; kc < nkc; kc++) {
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      int idx = tid + 256 * i;
+      *reinterpret_cast<f32x4*>(xs + (idx >> 3) * LROW + (idx & 7) * 4) = pa[i];
+    }
+#pragma unroll
+    for (int i = 0; i < W_LD; i++) {
+      int idx = tid + 256 * i;
+      if (idx < 16 * NT * 8) *reinterpret_cast<f32x4*>(ws + (idx >> 3) * LROW + (idx & 7) * 4) = pw[i];
     }
     __syncthreads();
+    if (kc + 1 < nkc) fetch(kc + 1);
     mma_chunk<NT>(xs + (wave * 32 + r) * LROW, xs + (wave * 32 + 16 + r) * LROW, ws, nt_valid, acc, r, q);
     __syncthreads();
   }
