@@ -272,7 +272,7 @@ __global__ __launch_bounds__(256) void k_gemm_stream(const float* __restrict__ A
 // and the next K-slab is prefetched into registers while the MFMAs of the current one run.
 // ---------------------------------------------------------------------------
 template <int MT, int NT, int WM, int WN, int RASTER = 0, int DBG = 0, int ASC = 0, int EPIM = 0, int DBUF = 0>
-__global__ __launch_bounds__(64 * WM * WN) void k_gemm_wide(const float* __restrict__ A, int lda, long long M, int K,
+__global__ __launch_bounds__(64 * WM * WN, (NT > 8 ? 2 : 1)) void k_gemm_wide(const float* __restrict__ A, int lda, long long M, int K,
                                                              const float* __restrict__ Wp, int N, int Npad,
                                                              float* __restrict__ C, int ldc, int coff, Epilogue epi) {
   constexpr int NTHR = 64 * WM * WN, BM = 16 * MT * WM, BN = 16 * NT * WN;
@@ -370,6 +370,26 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm_wide(const float* __restr
     // waits for its own reads (in-order LDS returns), hiding group 1's latency.  Branch-free:
     // padding tiles multiply zero weights (W rows past Npad are zero in LDS) and are dropped at
     // the store.
+    if constexpr (NT > 8) {
+      // fat waves (few rows x all columns): the weight fragments are streamed one column tile at a time so that
+      // the accumulators (MT x NT x 4 registers) leave room for two workgroups per CU
+#pragma unroll
+      for (int g = 0; g < KC / 16; g++) {
+        if (g > 0 && kc * KC + g * 16 >= K) break;
+        f32x4 a[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++) a[mt] = *reinterpret_cast<const f32x4*>(xr + mt * 16 * LROW + g * 16 + 4 * q);
+#pragma unroll
+        for (int nt = 0; nt < NT; nt++) {
+          const f32x4 b = *reinterpret_cast<const f32x4*>(wr + nt * 16 * LROW + g * 16 + 4 * q);
+#pragma unroll
+          for (int s = 0; s < 4; s++)
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++)
+              acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[s], a[mt][s], acc[mt][nt], 0, 0, 0);
+        }
+      }
+    } else {
     f32x4 a[KC / 16][MT], b[KC / 16][NT];
 #pragma unroll
     for (int g = 0; g < KC / 16; g++) {
@@ -388,6 +408,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm_wide(const float* __restr
 #pragma unroll
           for (int mt = 0; mt < MT; mt++)
             acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[g][nt][s], a[g][mt][s], acc[mt][nt], 0, 0, 0);
+    }
     }
     if (DBUF) {
       if (kc + 1 < nkc) stash(kc + 1);
@@ -1271,6 +1292,11 @@ void gemm(hipStream_t st, const float* A, int lda, long long M, int K, const flo
     else if (ntl <= 6) RT_GS_K(6); else RT_GS_K(8);
 #undef RT_GS_K
 #undef RT_GS
+    return;
+  }
+  if (v == 18) {  // 2 workgroups per CU x 4 fat waves (32 rows x 240 columns each)
+    dim3 grid((unsigned)((M + 127) / 128), (unsigned)((Npad16 + 239) / 240));
+    hipLaunchKernelGGL((k_gemm_wide<2, 15, 4, 1>), grid, dim3(256), 0, st, A, lda, M, K, Wp, N, Npad16, C, ldc, coff, epi);
     return;
   }
   if (v == 16 || v == 17) {
