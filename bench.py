@@ -32,8 +32,8 @@ FP32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: f32 MFMA / vector peak
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--pages", type=int, default=32, help="pages per GPU per step (C3: 32)")
     ap.add_argument("--size", type=int, default=960)
     ap.add_argument("--lines", type=int, default=32, help="planted text lines per page")
