@@ -299,7 +299,8 @@ DetNet::DetNet(const Blob& b) {
   dc2_w_ = upload_raw(ws_, b, "det.head.deconv2.w", 24 * 4); dc2_b_ = upload_raw(ws_, b, "det.head.deconv2.b", 1);
 }
 
-float* DetNet::run(RunCtx& c, const float* x, Level& L0) {
+float* DetNet::run(RunCtx& c, const float* x, Level& L0, const nn::U8Page* pages, float scale, const float* mean3,
+                   const float* std3) {
   for (auto& g : L0.h)
     if (g.H % 32 != 0 || g.W % 32 != 0 || g.H == 0 || g.W == 0) throw RtError(3, "det input sides must be non-zero multiples of 32");
   Level L2 = down_level(L0, 2, 2), L4 = down_level(L2, 2, 2), L8 = down_level(L4, 2, 2), L16 = down_level(L8, 2, 2),
@@ -308,7 +309,8 @@ float* DetNet::run(RunCtx& c, const float* x, Level& L0) {
   Level* lv[6] = {&L0, &L2, &L4, &L8, &L16, &L32};
   float* t = c.arena->alloc<float>((size_t)L2.total * 16);
   { ProfScope ps(c.prof, c.st, "stem");
-    nn::stem_conv(c.st, x, L0.d, L2.d, L2.n(), L2.maxH, L2.maxW, 16, stem_w_, stem_b_, ACT_NONE, t); }
+    if (pages) nn::stem_conv_u8(c.st, pages, scale, mean3, std3, L0.d, L2.d, L2.n(), L2.maxH, L2.maxW, 16, stem_w_, stem_b_, ACT_NONE, t);
+    else nn::stem_conv(c.st, x, L0.d, L2.d, L2.n(), L2.maxH, L2.maxW, 16, stem_w_, stem_b_, ACT_NONE, t); }
   int li = 1;
   float* taps[4] = {nullptr, nullptr, nullptr, nullptr};
   Level* tap_lv[4] = {nullptr, nullptr, nullptr, nullptr};

@@ -66,8 +66,14 @@ class DetNet {
   explicit DetNet(const Blob& b);
   // x: f32 NHWC pitch-4 (B,G,R,0) at level L0 (every H,W a multiple of 32).
   // Returns the probability maps, one float per L0 pixel (arena memory).
-  float* run(RunCtx& c, const float* x, Level& L0);
+  float* run(RunCtx& c, const float* x, Level& L0) { return run(c, x, L0, nullptr, 0.f, nullptr, nullptr); }
+  // Same from the RGB8 pages themselves (device descriptors, one per image of L0): the normalisation of
+  // DetProcessor::preprocess is folded into the stem, the f32 input tensor is never built.
+  float* run_u8(RunCtx& c, const nn::U8Page* pages, float scale, const float* mean3, const float* std3, Level& L0) {
+    return run(c, nullptr, L0, pages, scale, mean3, std3);
+  }
  private:
+  float* run(RunCtx& c, const float* x, Level& L0, const nn::U8Page* pages, float scale, const float* mean3, const float* std3);
   WeightStore ws_;
   float* stem_w_; float* stem_b_;
   std::vector<LcBlock> blocks_;

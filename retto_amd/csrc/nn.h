@@ -57,6 +57,11 @@ void lc_thin(hipStream_t st, int sh, int sw, const float* x, const ImgGeom* gin,
 extern int g_fuse_dwpw;  // 1 = use the fused kernel where it applies (default)
 
 // 3x3 stride-2 stem on a 3(+1 pad)-channel f32 NHWC input. Ws packed [27][COUT]. COUT in {8,16}.
+// One RGB8 page of a det launch group (device pointer; npix = H*W; out_pix = its pixel offset in the group).
+struct U8Page { const uint8_t* rgb; long long npix; long long out_pix; };
+void stem_conv_u8(hipStream_t st, const U8Page* pages, float scale, const float* mean3, const float* std3, const ImgGeom* gin,
+                  const ImgGeom* gout, int n_img, int maxHo, int maxWo, int COUT, const float* Ws, const float* bias, int act,
+                  float* y);
 void stem_conv(hipStream_t st, const float* x, const ImgGeom* gin, const ImgGeom* gout, int n_img, int maxHo, int maxWo,
                int COUT, const float* Ws, const float* bias, int act, float* y);
 

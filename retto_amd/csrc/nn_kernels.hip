@@ -1904,6 +1904,73 @@ __global__ __launch_bounds__(256) void k_stem(const float* __restrict__ x, const
   }
 }
 
+// Det stem straight from the RGB8 pages: DetProcessor::preprocess's normalise (det_processor.rs:151-155: BGR order,
+// (v * scale - mean) / std, each operation rounded on its own like k_det_normalize) is applied while the 3x3 window
+// is read, so the [H, W, 4] f32 input tensor (16 bytes per pixel written and read back) never exists.
+template <int COUT>
+__global__ __launch_bounds__(256) void k_stem_u8(const U8Page* __restrict__ pages, float scale, float m0, float m1, float m2,
+                                                 float s0, float s1, float s2, const ImgGeom* __restrict__ gin,
+                                                 const ImgGeom* __restrict__ gout, const float* __restrict__ Ws,
+                                                 const float* __restrict__ bias, int act, float* __restrict__ y) {
+  __shared__ float w[27 * COUT + COUT];
+  for (int i = threadIdx.x; i < 27 * COUT; i += 256) w[i] = Ws[i];
+  for (int i = threadIdx.x; i < COUT; i += 256) w[27 * COUT + i] = bias[i];
+  __syncthreads();
+  const ImgGeom gi = gin[blockIdx.y], go = gout[blockIdx.y];
+  const uint8_t* rgb = pages[blockIdx.y].rgb;
+  long long p = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (p >= (long long)go.H * go.W) return;
+  int oy = (int)(p / go.W), ox = (int)(p % go.W);
+  const float mean[3] = {m0, m1, m2}, stdv[3] = {s0, s1, s2};
+  float acc[COUT];
+#pragma unroll
+  for (int c = 0; c < COUT; c++) acc[c] = w[27 * COUT + c];
+#pragma unroll
+  for (int dy = 0; dy < 3; dy++) {
+    int iy = oy * 2 - 1 + dy;
+    if (iy < 0 || iy >= gi.H) continue;
+#pragma unroll
+    for (int dx = 0; dx < 3; dx++) {
+      int ix = ox * 2 - 1 + dx;
+      if (ix < 0 || ix >= gi.W) continue;
+      const uint8_t* px = rgb + ((long long)iy * gi.W + ix) * 3;
+      const float* wt = w + (dy * 3 + dx) * 3 * COUT;
+#pragma unroll
+      for (int ci = 0; ci < 3; ci++) {  // channel ci of BGR
+        float v;
+        {
+          // this file is compiled with -ffp-contract=fast; HIP's __fmul_rn / __fsub_rn are plain operators and
+          // `#pragma clang fp contract(off)` did not stop the fusion either (caught by the checksum test): the
+          // multiply and the subtract are pinned as separate instructions so that the value is k_det_normalize's
+          float t, u;
+          const float xf = (float)px[2 - ci], mc = mean[ci];
+          asm volatile("v_mul_f32_e32 %0, %1, %2" : "=v"(t) : "v"(xf), "v"(scale));
+          asm volatile("v_sub_f32_e32 %0, %1, %2" : "=v"(u) : "v"(t), "v"(mc));
+          v = u / stdv[ci];
+        }
+#pragma unroll
+        for (int c = 0; c < COUT; c++) acc[c] = fmaf(v, wt[ci * COUT + c], acc[c]);
+      }
+    }
+  }
+  float* o = y + (go.off + p) * COUT;
+#pragma unroll
+  for (int c = 0; c < COUT; c += 4) {
+    f32x4 t = {act_apply(acc[c], act), act_apply(acc[c + 1], act), act_apply(acc[c + 2], act),
+               act_apply(acc[c + 3], act)};
+    *reinterpret_cast<f32x4*>(o + c) = t;
+  }
+}
+void stem_conv_u8(hipStream_t st, const U8Page* pages, float scale, const float* mean3, const float* std3, const ImgGeom* gin,
+                  const ImgGeom* gout, int n_img, int maxHo, int maxWo, int COUT, const float* Ws, const float* bias, int act,
+                  float* y) {
+  if (n_img <= 0) return;
+  if (COUT != 16) throw RtError(8, "stem_conv_u8: unsupported COUT");
+  dim3 grid((unsigned)(((long long)maxHo * maxWo + 255) / 256), n_img);
+  hipLaunchKernelGGL(k_stem_u8<16>, grid, dim3(256), 0, st, pages, scale, mean3[0], mean3[1], mean3[2], std3[0], std3[1],
+                     std3[2], gin, gout, Ws, bias, act, y);
+}
+
 void stem_conv(hipStream_t st, const float* x, const ImgGeom* gin, const ImgGeom* gout, int n_img, int maxHo, int maxWo,
                int COUT, const float* Ws, const float* bias, int act, float* y) {
   if (n_img <= 0) return;

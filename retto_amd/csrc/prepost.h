@@ -2,6 +2,7 @@
 // retto-core's DetProcessor / ClsProcessor / RecProcessor / ImageHelper that is not a
 // network forward.  Bit-exact integer / f32 / f64 arithmetic (no FMA contraction).
 #pragma once
+#include "nn.h"
 #include "common.h"
 
 namespace rt {
@@ -12,7 +13,7 @@ void thumbnail_rgb8(hipStream_t st, const uint8_t* src, int h, int w, uint8_t* d
 
 // det_processor.rs:151-160 + image_helper.rs:211-221: RGB8 HWC -> normalised BGR f32.
 // layout 0: NHWC pitch 4 (B,G,R,0); layout 1: CHW planes
-struct NormDesc { const uint8_t* rgb; long long npix; long long out_pix; };  // one page of a det launch group
+typedef nn::U8Page NormDesc;  // one page of a det launch group
 void det_normalize_batch(hipStream_t st, const NormDesc* d_descs, int n, long long max_pix, float scale, const float* mean3,
                          const float* std3, float* out);
 void det_normalize(hipStream_t st, const uint8_t* rgb, int h, int w, float scale, const float* mean3,

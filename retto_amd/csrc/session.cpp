@@ -428,23 +428,26 @@ rt_results* rt_session::run_pages(const uint8_t* const* rgb, const int* hs, cons
     std::vector<std::pair<int, int>> hw(det_hw.begin() + g0, det_hw.begin() + g1);
     Level L0 = make_level(hw);
     scratch.rewind();
-    float* x = scratch.alloc<float>((size_t)L0.total * 4);
-    {  // a3 normalise: every page of the group in one launch
-      const int gn = g1 - g0;
-      pp::NormDesc* hd = pinned.alloc<pp::NormDesc>((size_t)gn);
-      pp::NormDesc* dd = scratch.alloc<pp::NormDesc>((size_t)gn);
-      long long max_pix = 0;
-      for (int i = g0; i < g1; i++) {
-        hd[i - g0] = pp::NormDesc{det_img[i], (long long)pg[i].det_h * pg[i].det_w, L0.h[i - g0].off};
-        max_pix = std::max(max_pix, hd[i - g0].npix);
-      }
-      RT_HIP_CHECK(hipMemcpyAsync(dd, hd, (size_t)gn * sizeof(pp::NormDesc), hipMemcpyHostToDevice, st));
-      ProfScope ps(&prof, st, "det_normalize");
-      pp::det_normalize_batch(st, dd, gn, max_pix, cfg.det_scale, cfg.det_mean, cfg.det_std, x);
-    }
+    // a3 normalise is folded into the det stem (DetNet::run_u8): the pages stay RGB8 until the first conv reads them
+    const int gn = g1 - g0;
+    pp::NormDesc* hd = pinned.alloc<pp::NormDesc>((size_t)gn);
+    pp::NormDesc* dd = scratch.alloc<pp::NormDesc>((size_t)gn);
+    for (int i = g0; i < g1; i++)
+      hd[i - g0] = pp::NormDesc{det_img[i], (long long)pg[i].det_h * pg[i].det_w, L0.h[i - g0].off};
+    RT_HIP_CHECK(hipMemcpyAsync(dd, hd, (size_t)gn * sizeof(pp::NormDesc), hipMemcpyHostToDevice, st));
     RunCtx c = ctx(&scratch);
     float* map;
-    { ProfOuter po(&prof, st, "net/det"); map = det->run(c, x, L0); }
+    static const bool f32_input = getenv("RT_DET_F32_INPUT") != nullptr;  // A/B: build the normalised tensor first
+    if (f32_input) {
+      float* x = scratch.alloc<float>((size_t)L0.total * 4);
+      long long max_pix = 0;
+      for (int i = 0; i < gn; i++) max_pix = std::max(max_pix, hd[i].npix);
+      { ProfScope ps(&prof, st, "det_normalize");
+        pp::det_normalize_batch(st, dd, gn, max_pix, cfg.det_scale, cfg.det_mean, cfg.det_std, x); }
+      ProfOuter po(&prof, st, "net/det"); map = det->run(c, x, L0);
+    } else {
+      ProfOuter po(&prof, st, "net/det"); map = det->run_u8(c, dd, cfg.det_scale, cfg.det_mean, cfg.det_std, L0);
+    }
     // keep the maps beyond the scratch rewind
     float* keep = arena.alloc<float>((size_t)L0.total);
     RT_HIP_CHECK(hipMemcpyAsync(keep, map, (size_t)L0.total * 4, hipMemcpyDeviceToDevice, st));

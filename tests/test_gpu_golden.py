@@ -227,3 +227,19 @@ def test_run_stream_order_and_payloads(hip_session):
     got = []
     hip_session.run_stream(pages[0], lambda stage, payload: got.append(stage))
     assert got == ["Det", "Cls", "Rec"]
+
+
+def test_det_stem_from_u8_pages_matches_tensor_path(hip_session):
+    """rt_run_batch feeds the det stem with the RGB8 pages (normalisation folded in); rt_det gets the normalised f32
+    tensor of rt_det_preprocess.  Both must produce the same probability map (checked through its checksum)."""
+    import ctypes as C
+    page = np.random.default_rng(77).integers(0, 256, (224, 352, 3), dtype=np.uint8)
+    x = hip_session.det_preprocess(page)
+    ref = float(hip_session.worker.det(x).astype(np.float64).sum())
+    lib = hip_session._hd.lib
+    r = hip_session.run_batch_raw([page], [page.shape[0]], [page.shape[1]])
+    try:
+        got = lib.rt_results_det_checksum(r)
+    finally:
+        lib.rt_results_free(r)
+    assert abs(got - ref) <= 1e-9 * abs(ref) + 1e-6, (got, ref)
