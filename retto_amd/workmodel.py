@@ -77,9 +77,9 @@ def det_work(pages: Iterable[Tuple[int, int]]) -> Dict[str, Dict[str, float]]:
             group_of[i] = g
     for pi, (H, W) in enumerate(pages):
         grp = [pages[i] for i in group_of[pi]]
-        add("det_normalize", H * W * 3 + H * W * 4 * F)
         h, ww = _down(H, 2), _down(W, 2)
-        add("stem", H * W * 3 * F + h * ww * 16 * F, 2 * h * ww * 27 * 16)
+        # the det stem reads the RGB8 page itself (normalisation folded in): 3 bytes per input pixel
+        add("stem", H * W * 3 + h * ww * 16 * F, 2 * h * ww * 27 * 16)
         taps = {}
         for name, k, cin, cout, sh, sw, se in synth.DET_BLOCKS:
             ho, wo = _down(h, sh), _down(ww, sw)
