@@ -7,6 +7,7 @@ import torch
 
 from oracle import nets_torch as N
 from oracle import ref_lib as R
+import retto_amd
 from retto_amd import workload
 
 pytestmark = pytest.mark.gpu
@@ -388,3 +389,33 @@ def test_crops_fuzz(hip_session, seed):
         a = hip_session.resize_norm_image(g, g.shape[0], g.shape[1], 48, 320, max(320 / 48, g.shape[1] / g.shape[0]))
         r = R.resize_norm_image(ref, ref.shape[0], ref.shape[1], 48, 320, max(320 / 48, ref.shape[1] / ref.shape[0]))
         assert np.array_equal(a.view(np.uint32), r.view(np.uint32))
+
+
+def test_non_default_det_config():
+    """DetProcessorConfig knobs other than the defaults (det_processor.rs:44-93): limit_type Max, another limit,
+    thresholds, unclip ratio, minimum box size, no dilation -- stage results still equal the oracle's."""
+    cfg = retto_amd.synthetic_session_config(0)
+    d = cfg.det_processor_config
+    d.limit_type, d.limit_side_len = "Max", 640
+    d.threch, d.box_thresh, d.unclip_ratio, d.min_mini_box_size = 0.4, 0.6, 2.0, 5
+    d.dilation_kernel = None  # det_processor.rs:290 only consults the kernel (use_dilation is never read there either)
+    s = retto_amd.RettoSession(cfg)
+    try:
+        for (h, w) in ((900, 1300), (300, 500), (640, 640)):
+            page = _rand_page(h, w, h + w)
+            x = s.det_preprocess(page)
+            dh, dw = R.resize_either_dims(h, w, 1, 640)
+            assert x.shape == (1, 3, dh, dw)
+            page_r = R.resize_both(page)  # the stage function takes the page after the session's size limits
+            ref = R.det_preprocess(page_r, 1, 640)
+            assert np.array_equal(s.det_preprocess(page_r).view(np.uint32), ref.view(np.uint32))
+        rng = np.random.default_rng(99)
+        m = workload.planted_map_rotated(384, 512, [(256, 100, 150, 14, 12.0), (200, 250, 120, 10, -31.0), (400, 200, 100, 4, 83.0),
+                                                    (90, 330, 60, 3, 45.0)])
+        m = np.clip(m + rng.normal(0, 0.1, m.shape).astype(np.float32), 0, 1).astype(np.float32)
+        gb, gs = s.det_postprocess(m, 384, 512)
+        rb, rs = R.det_postprocess(m, 384, 512, thresh=0.4, box_thresh=0.6, unclip_ratio=2.0, min_size=5, dilate=False)
+        assert len(gb) == len(rb) > 0
+        assert np.array_equal(gb, rb) and np.array_equal(gs.view(np.uint32), rs.view(np.uint32))
+    finally:
+        s.close()
