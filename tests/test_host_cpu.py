@@ -124,3 +124,25 @@ def test_cli_parser_and_walk(tmp_path):
     assert a.batch == 4 and a.synthetic and a.rec_keys_path == "ppocr_keys_v1.txt"
     (tmp_path / "b").mkdir(); (tmp_path / "b" / "2.png").write_bytes(b"x"); (tmp_path / "a.png").write_bytes(b"y")
     assert [os.path.basename(p) for p in cli.walk_files(str(tmp_path))] == ["a.png", "2.png"]
+
+
+def test_integration_doc_config_matches_header():
+    """The Rust #[repr(C)] mirror in INTEGRATION.md and ctypes' Config list the fields of rt_config in the header's order."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hdr = open(os.path.join(root, "include", "retto_hip.h")).read()
+    body = re.search(r"typedef struct rt_config \{(.*?)\} rt_config;", hdr, re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    fields = []
+    for decl in body.split(";"):
+        decl = decl.strip()
+        if not decl:
+            continue
+        names = decl.split(None, 1)[1]
+        fields += [re.sub(r"\[.*?\]", "", n).strip() for n in names.split(",")]
+    doc = open(os.path.join(root, "INTEGRATION.md")).read()
+    rs = re.search(r"pub struct RtConfig \{(.*?)\n\}", doc, re.S).group(1)
+    rs_fields = re.findall(r"(\w+)\s*:", rs)
+    assert rs_fields == fields
+    from retto_amd._lib import Config
+    assert [f[0] for f in Config._fields_] == fields
