@@ -273,7 +273,8 @@ RT_API void rt_debug_set_variants(int gemm_variant, int dw_variant, int fuse_dwp
   nn::g_gemm_variant = gemm_variant; nn::g_dw_variant = dw_variant; nn::g_fuse_dwpw = fuse_dwpw & 1; nn::g_lc_thin = (fuse_dwpw & 2) ? 0 : ((fuse_dwpw & 4) ? 2 : 1);
   nn::set_dw_xcd((fuse_dwpw & 8) ? 0 : 1);
   nn::g_dw_wide_slab_min = (fuse_dwpw & 16) ? (1 << 30) : 192; nn::g_dw_wide3_min = (fuse_dwpw & 16) ? (1 << 30) : 128;  // bit 4 = 32-channel slabs only in the 5x5 depthwise kernels
-  nn::g_dw_wide_lp = (fuse_dwpw & 32) ? 32 : 16;                // bit 5 = 128- instead of 64-channel wide slabs  // bit 3 = plain block order in the depthwise kernel
+  nn::g_dw_wide_lp = (fuse_dwpw & 32) ? 32 : 16;
+  nn::g_argmax_wide = (fuse_dwpw & 64) ? 1 : 0;                  // bit 6 = CTC head on the 256 x 240 tile                // bit 5 = 128- instead of 64-channel wide slabs  // bit 3 = plain block order in the depthwise kernel
 }
 // Kernel micro-benchmark (not part of the drop-in surface): times nn::gemm on random data.
 RT_API int rt_bench_gemm(rt_session* s, long long M, int K, int N, int variant, int iters, float* ms_out, float* maxdiff_out) {

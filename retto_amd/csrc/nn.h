@@ -40,6 +40,7 @@ int gemm_tile_rows(long long M, int Npad16);
 // Fused CTC head: gemm() with Epilogue::am_* set (am_tiles = gemm_argmax_tiles(Npad16), buffers of
 // M * am_tiles elements) leaves softmax statistics per column tile; argmax_merge gives, per row, the
 // argmax over the N logits and softmax(logits)[argmax] -- the [M, 6625] logits never reach HBM.
+extern int g_argmax_wide;
 int gemm_argmax_tiles(int Npad16);
 void argmax_merge(hipStream_t st, const float* pm, const int* pi, const float* ps, int tiles, long long rows, int* idx,
                   float* prob);

@@ -1189,7 +1189,8 @@ const char* gemm_pw_label(long long M, int Npad16, bool a_scale) {
   }
 }
 
-int gemm_argmax_tiles(int Npad16) { return (Npad16 + 127) / 128; }
+int g_argmax_wide = 0;  // CTC head on the 128 x 128 tile (0: 0.92 ms) or the 256 x 240 tile (1: 0.97 ms, A/B)
+int gemm_argmax_tiles(int Npad16) { return g_argmax_wide ? (Npad16 + 239) / 240 : (Npad16 + 127) / 128; }
 
 // one thread per row: fold the column tiles in ascending order -> argmax (first maximum) and softmax(max) = 1 / sum
 __global__ __launch_bounds__(256) void k_argmax_merge(const float* __restrict__ pm, const int* __restrict__ pi,
@@ -1226,10 +1227,15 @@ void gemm(hipStream_t st, const float* A, int lda, long long M, int K, const flo
   if (M <= 0) return;
   int v = g_gemm_variant;
   if (v == 0) v = gemm_dispatch(M, Npad16);
-  if (epi.am_max) {  // CTC head: softmax statistics per 128-column tile instead of the logits (argmax_merge folds them)
-    if (epi.am_tiles != (Npad16 + 127) / 128) throw RtError(8, "gemm: am_tiles must be gemm_argmax_tiles(Npad16)");
-    dim3 grid((unsigned)((M + 127) / 128), (unsigned)((Npad16 + 127) / 128));
-    hipLaunchKernelGGL((k_gemm_wide<2, 4, 4, 2, 0, 0, 0, 1>), grid, dim3(512), 0, st, A, lda, M, K, Wp, N, Npad16, C, ldc, coff, epi);
+  if (epi.am_max) {  // CTC head: softmax statistics per column tile instead of the logits (argmax_merge folds them)
+    if (epi.am_tiles != gemm_argmax_tiles(Npad16)) throw RtError(8, "gemm: am_tiles must be gemm_argmax_tiles(Npad16)");
+    if (g_argmax_wide) {
+      dim3 grid((unsigned)((M + 255) / 256), (unsigned)((Npad16 + 239) / 240));
+      hipLaunchKernelGGL((k_gemm_wide<4, 5, 4, 3, 0, 0, 0, 1>), grid, dim3(768), 0, st, A, lda, M, K, Wp, N, Npad16, C, ldc, coff, epi);
+    } else {
+      dim3 grid((unsigned)((M + 127) / 128), (unsigned)((Npad16 + 127) / 128));
+      hipLaunchKernelGGL((k_gemm_wide<2, 4, 4, 2, 0, 0, 0, 1>), grid, dim3(512), 0, st, A, lda, M, K, Wp, N, Npad16, C, ldc, coff, epi);
+    }
     return;
   }
   if (epi.a_scale) {  // squeeze-excite scale folded into the A staging: wide tiles only (gemm_tile_rows)
