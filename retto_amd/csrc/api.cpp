@@ -268,13 +268,21 @@ size_t rt_model_manifest(int which, char* buf, size_t cap) {
   return s.size() + 1;
 }
 
-RT_API void rt_debug_set_variants(int gemm_variant, int dw_variant, int fuse_dwpw) {
-  // fuse_dwpw: bit 0 = experimental k_dwpw, bit 1 = DISABLE the fused thin blocks (k_lc_thin), bit 2 = their 128-pixel variant
-  nn::g_gemm_variant = gemm_variant; nn::g_dw_variant = dw_variant; nn::g_fuse_dwpw = fuse_dwpw & 1; nn::g_lc_thin = (fuse_dwpw & 2) ? 0 : ((fuse_dwpw & 4) ? 2 : 1);
-  nn::set_dw_xcd((fuse_dwpw & 8) ? 0 : 1);
-  nn::g_dw_wide_slab_min = (fuse_dwpw & 16) ? (1 << 30) : 192; nn::g_dw_wide3_min = (fuse_dwpw & 16) ? (1 << 30) : 128;  // bit 4 = 32-channel slabs only in the 5x5 depthwise kernels
-  nn::g_dw_wide_lp = (fuse_dwpw & 32) ? 32 : 16;
-  nn::g_argmax_wide = (fuse_dwpw & 64) ? 1 : 0;                  // bit 6 = CTC head on the 256 x 240 tile                // bit 5 = 128- instead of 64-channel wide slabs  // bit 3 = plain block order in the depthwise kernel
+// A/B switches for tools/ (not part of the drop-in surface).  `flags` bits:
+//   0  experimental k_dwpw                         1  fused thin blocks (k_lc_thin) OFF
+//   2  k_lc_thin: force the 128-pixel tile         3  depthwise: plain (not XCD-aware) block order
+//   4  depthwise: 32-channel slabs only            5  depthwise: 128- instead of 64-channel wide slabs
+//   6  CTC head on the 256 x 240 tile
+RT_API void rt_debug_set_variants(int gemm_variant, int dw_variant, int flags) {
+  nn::g_gemm_variant = gemm_variant;
+  nn::g_dw_variant = dw_variant;
+  nn::g_fuse_dwpw = flags & 1;
+  nn::g_lc_thin = (flags & 2) ? 0 : ((flags & 4) ? 2 : 1);
+  nn::set_dw_xcd((flags & 8) ? 0 : 1);
+  nn::g_dw_wide_slab_min = (flags & 16) ? (1 << 30) : 192;
+  nn::g_dw_wide3_min = (flags & 16) ? (1 << 30) : 128;
+  nn::g_dw_wide_lp = (flags & 32) ? 32 : 16;
+  nn::g_argmax_wide = (flags & 64) ? 1 : 0;
 }
 // Kernel micro-benchmark (not part of the drop-in surface): times nn::gemm on random data.
 RT_API int rt_bench_gemm(rt_session* s, long long M, int K, int N, int variant, int iters, float* ms_out, float* maxdiff_out) {
