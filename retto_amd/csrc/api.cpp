@@ -272,12 +272,12 @@ size_t rt_model_manifest(int which, char* buf, size_t cap) {
 //   0  experimental k_dwpw                         1  fused thin blocks (k_lc_thin) OFF
 //   2  k_lc_thin: force the 128-pixel tile         3  depthwise: plain (not XCD-aware) block order
 //   4  depthwise: 32-channel slabs only            5  depthwise: 128- instead of 64-channel wide slabs
-//   6  CTC head on the 256 x 240 tile
+//   6  CTC head on the 256 x 240 tile              7  k_lc_thin: producer/consumer wave form
 RT_API void rt_debug_set_variants(int gemm_variant, int dw_variant, int flags) {
   nn::g_gemm_variant = gemm_variant;
   nn::g_dw_variant = dw_variant;
   nn::g_fuse_dwpw = flags & 1;
-  nn::g_lc_thin = (flags & 2) ? 0 : ((flags & 4) ? 2 : 1);
+  nn::g_lc_thin = (flags & 2) ? 0 : ((flags & 4) ? 2 : ((flags & 128) ? 1 : 4));
   nn::set_dw_xcd((flags & 8) ? 0 : 1);
   nn::g_dw_wide_slab_min = (flags & 16) ? (1 << 30) : 192;
   nn::g_dw_wide3_min = (flags & 16) ? (1 << 30) : 128;
