@@ -689,9 +689,9 @@ rt_results* rt_session::run_pages(const uint8_t* const* rgb, const int* hs, cons
       P.cls_labels[k] = LABELS[h_label[li] ? 1 : 0]; P.cls_scores[k] = h_cscore[li];
       P.rec_scores[k] = h_rscore[li];
       P.tokens[k].assign(h_tokens.begin() + tok_off[li], h_tokens.begin() + tok_off[li] + h_ntok[li]);
-      std::string t;
+      std::string& t = P.text[k];
+      t.reserve(P.tokens[k].size() * 3);  // CJK dictionary entries are 3 UTF-8 bytes
       for (int id : P.tokens[k]) t += dict[(size_t)id];
-      P.text[k] = t;
     }
   }
   if (stage_cb)
