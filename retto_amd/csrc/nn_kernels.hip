@@ -1319,17 +1319,17 @@ int g_gemm_variant = 0;  // 0 = production choice; others are forced by the kern
 static int gemm_dispatch(long long M, int Npad16) {
   if (Npad16 % 240 == 0 && M >= 131072) return 15;  // 256 x 240 tile: halves the weight re-fetch per row
   if (Npad16 % 240 == 0 && M >= 16384) return 10;
-  if (Npad16 >= 128 && M >= 8192) return 8;  // 128 x 128 register-prefetch tile (N = 128: 71 vs 61 TFLOP/s narrow)
-  return 0;  // thin: gemm() picks the streaming kernel when K <= 64 as well, else the narrow LDS kernel
+  // (the 128 x 128 tile, variant 8, lost to the narrow kernel once that prefetched its next K-slab: 192 x 192 at
+  // 115200 rows 85 vs 65 TFLOP/s, 128 x 128 at 2.4 M rows 76 vs 72; it remains the squeeze-excite (a_scale) and CTC tile)
+  return 0;  // gemm() picks the streaming kernel when K, N <= 64, else the narrow LDS kernel
 }
 // Profiler label of a pointwise-conv GEMM: family + the kernel symbol the dispatcher picks, so the
 // per-kernel numbers of bench.py can be compared with rocprofv3's kernel stats one to one.
 const char* gemm_pw_label(long long M, int Npad16, bool a_scale) {
-  if (a_scale && !g_gemm_variant) return gemm_dispatch(M, Npad16) == 8 ? "gemm_pw/k_gemm_wide<2,4,4,2>+se" : "gemm_pw/k_gemm_wide<2,5,4,3>+se";
+  if (a_scale && !g_gemm_variant) return gemm_dispatch(M, Npad16) == 0 ? "gemm_pw/k_gemm_wide<2,4,4,2>+se" : "gemm_pw/k_gemm_wide<2,5,4,3>+se";
   switch (g_gemm_variant ? -1 : gemm_dispatch(M, Npad16)) {
     case 15: return "gemm_pw/k_gemm_wide<4,5,4,3>";
     case 10: return "gemm_pw/k_gemm_wide<2,5,4,3>";
-    case 8: return "gemm_pw/k_gemm_wide<2,4,4,2>";
     case 0: return "gemm_pw/thin";  // k_gemm_stream (K, N <= 64) or k_gemm<NT>
     default: return "gemm_pw/variant";
   }
@@ -1362,10 +1362,9 @@ void argmax_merge(hipStream_t st, const float* pm, const int* pi, const float* p
 }
 
 int gemm_tile_rows(long long M, int Npad16) {
-  switch (g_gemm_variant ? -1 : gemm_dispatch(M, Npad16)) {
-    case 15: case 10: case 8: return 128;  // (a_scale runs the 256 x 240 shapes on the 128 x 240 tile)
-    default: return 0;
-  }
+  if (g_gemm_variant) return 0;
+  if (gemm_dispatch(M, Npad16) != 0) return 128;  // (a_scale runs the 256 x 240 shapes on the 128 x 240 tile)
+  return (Npad16 >= 128 && M >= 8192) ? 128 : 0;  // a_scale on the 128 x 128 tile
 }
 
 void gemm(hipStream_t st, const float* A, int lda, long long M, int K, const float* Wp, int N, int Npad16, float* C,
@@ -1387,6 +1386,7 @@ void gemm(hipStream_t st, const float* A, int lda, long long M, int K, const flo
   if (epi.a_scale) {  // squeeze-excite scale folded into the A staging: wide tiles only (gemm_tile_rows)
     if (K > 512 || !epi.a_tab) throw RtError(8, "gemm: a_scale needs K <= 512 and a row-tile table");
     if (v == 15) v = 10;  // the 256-row tile has no registers to spare for the scaling (spills): 128 x 240 measured faster
+    if (v == 0 && Npad16 >= 128) v = 8;
     if (v == 10) {
       dim3 grid((unsigned)((M + 127) / 128), (unsigned)((Npad16 + 239) / 240));
       hipLaunchKernelGGL((k_gemm_wide<2, 5, 4, 3, 0, 0, 1>), grid, dim3(768), 0, st, A, lda, M, K, Wp, N, Npad16, C, ldc, coff, epi);

@@ -30,8 +30,6 @@ def gemm_pw_label(M: int, N: int, se: bool = False) -> str:
         return "gemm_pw/k_gemm_wide<4,5,4,3>"
     if npad % 240 == 0 and M >= 16384:
         return "gemm_pw/k_gemm_wide<2,5,4,3>"
-    if npad >= 128 and M >= 8192:
-        return "gemm_pw/k_gemm_wide<2,4,4,2>"
     return "gemm_pw/thin"
 
 
