@@ -272,7 +272,7 @@ size_t rt_model_manifest(int which, char* buf, size_t cap) {
 //   0  experimental k_dwpw                         1  fused thin blocks (k_lc_thin) OFF
 //   2  k_lc_thin: force the 128-pixel tile         3  depthwise: plain (not XCD-aware) block order
 //   4  depthwise: 32-channel slabs only            5  depthwise: 128- instead of 64-channel wide slabs
-//   6  CTC head on the 256 x 240 tile              7  k_lc_thin: producer/consumer wave form
+//   6  CTC head on the 128 x 128 wide tile             7  k_lc_thin: producer/consumer wave form
 RT_API void rt_debug_set_variants(int gemm_variant, int dw_variant, int flags) {
   nn::g_gemm_variant = gemm_variant;
   nn::g_dw_variant = dw_variant;
@@ -282,7 +282,7 @@ RT_API void rt_debug_set_variants(int gemm_variant, int dw_variant, int flags) {
   nn::g_dw_wide_slab_min = (flags & 16) ? (1 << 30) : 192;
   nn::g_dw_wide3_min = (flags & 16) ? (1 << 30) : 128;
   nn::g_dw_wide_lp = (flags & 32) ? 32 : 16;
-  nn::g_argmax_wide = (flags & 64) ? 1 : 0;
+  nn::g_argmax_wide = (flags & 64) ? 2 : 0;
 }
 // Kernel micro-benchmark (not part of the drop-in surface): times nn::gemm on random data.
 RT_API int rt_bench_gemm(rt_session* s, long long M, int K, int N, int variant, int iters, float* ms_out, float* maxdiff_out) {

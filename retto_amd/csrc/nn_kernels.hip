@@ -122,7 +122,7 @@ __device__ __forceinline__ void epilogue_store(f32x4 (&acc)[2][NT], int nt_valid
 // Flat GEMM: rows = pixels (any ragged batch is just a longer M).
 // Block 256 threads (4 waves), tile 128 rows x 16*NT cols, K in 32-chunks.
 // ---------------------------------------------------------------------------
-template <int NT>
+template <int NT, int EPIM = 0>
 __global__ __launch_bounds__(256) void k_gemm(const float* __restrict__ A, int lda, long long M, int K,
                                               const float* __restrict__ Wp, int N, int Npad, float* __restrict__ C,
                                               int ldc, int coff, Epilogue epi) {
@@ -178,6 +178,44 @@ __global__ __launch_bounds__(256) void k_gemm(const float* __restrict__ A, int l
     __syncthreads();
   }
   long long ma = m0 + wave * 32 + r, mb = ma + 16;
+  if (EPIM) {
+    // CTC head (see k_gemm_wide's EPIM): softmax statistics of this block's 16*NT columns per row; a wave owns
+    // whole rows here, so the reduction is in-lane over the columns and across the 4 lane quarters only
+#pragma unroll
+    for (int mt = 0; mt < 2; mt++) {
+      float m = -INFINITY, sum = 0.f;
+      int mi = 0x7fffffff;
+#pragma unroll
+      for (int nt = 0; nt < NT; nt++) {
+        if (nt >= nt_valid) continue;
+        const int col = n0 + nt * 16 + q * 4;
+        f32x4 bias = {0.f, 0.f, 0.f, 0.f};
+        if (epi.bias) bias = *reinterpret_cast<const f32x4*>(epi.bias + col);
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          if (col + j >= N) continue;
+          const float v = acc[mt][nt][j] + bias[j];
+          if (v > m) { sum = sum * __expf(m - v) + 1.0f; m = v; mi = col + j; }
+          else sum += __expf(v - m);
+        }
+      }
+#pragma unroll
+      for (int d = 16; d < 64; d <<= 1) {
+        const float om = __shfl_xor(m, d), os = __shfl_xor(sum, d);
+        const int oi = __shfl_xor(mi, d);
+        const float nm = fmaxf(m, om);
+        sum = sum * (m == nm ? 1.0f : __expf(m - nm)) + os * (om == nm ? 1.0f : __expf(om - nm));
+        if (om > m || (om == m && oi < mi)) mi = oi;
+        m = nm;
+      }
+      const long long row = mt == 0 ? ma : mb;
+      if (q == 0 && row < M) {
+        const long long o = row * epi.am_tiles + blockIdx.y;
+        epi.am_max[o] = m; epi.am_sum[o] = sum; epi.am_idx[o] = mi;
+      }
+    }
+    return;
+  }
   const int nstore = (N + 3) & ~3;
   epilogue_store<NT>(acc, nt_valid, epi, n0, N, nstore, C + ma * ldc + coff, C + mb * ldc + coff, ma < M, mb < M,
                      epi.residual ? epi.residual + ma * epi.ld_res : nullptr,
@@ -1335,8 +1373,8 @@ const char* gemm_pw_label(long long M, int Npad16, bool a_scale) {
   }
 }
 
-int g_argmax_wide = 0;  // CTC head on the 128 x 128 tile (0: 0.92 ms) or the 256 x 240 tile (1: 0.97 ms, A/B)
-int gemm_argmax_tiles(int Npad16) { return g_argmax_wide ? (Npad16 + 239) / 240 : (Npad16 + 127) / 128; }
+int g_argmax_wide = 0;  // CTC head: 0 = narrow kernel with 128-column blocks; 2 = 128 x 128 wide tile (0.92 ms); 1 = 256 x 240 tile (0.97 ms)
+int gemm_argmax_tiles(int Npad16) { return g_argmax_wide == 1 ? (Npad16 + 239) / 240 : (Npad16 + 127) / 128; }
 
 // one thread per row: fold the column tiles in ascending order -> argmax (first maximum) and softmax(max) = 1 / sum
 __global__ __launch_bounds__(256) void k_argmax_merge(const float* __restrict__ pm, const int* __restrict__ pi,
@@ -1374,12 +1412,15 @@ void gemm(hipStream_t st, const float* A, int lda, long long M, int K, const flo
   if (v == 0) v = gemm_dispatch(M, Npad16);
   if (epi.am_max) {  // CTC head: softmax statistics per column tile instead of the logits (argmax_merge folds them)
     if (epi.am_tiles != gemm_argmax_tiles(Npad16)) throw RtError(8, "gemm: am_tiles must be gemm_argmax_tiles(Npad16)");
-    if (g_argmax_wide) {
+    if (g_argmax_wide == 1) {
       dim3 grid((unsigned)((M + 255) / 256), (unsigned)((Npad16 + 239) / 240));
       hipLaunchKernelGGL((k_gemm_wide<4, 5, 4, 3, 0, 0, 0, 1>), grid, dim3(768), 0, st, A, lda, M, K, Wp, N, Npad16, C, ldc, coff, epi);
-    } else {
+    } else if (g_argmax_wide == 2) {
       dim3 grid((unsigned)((M + 127) / 128), (unsigned)((Npad16 + 127) / 128));
       hipLaunchKernelGGL((k_gemm_wide<2, 4, 4, 2, 0, 0, 0, 1>), grid, dim3(512), 0, st, A, lda, M, K, Wp, N, Npad16, C, ldc, coff, epi);
+    } else {  // narrow kernel, 128-column blocks
+      dim3 grid((unsigned)((M + 127) / 128), (unsigned)((Npad16 + 127) / 128));
+      hipLaunchKernelGGL((k_gemm<8, 1>), grid, dim3(256), 0, st, A, lda, M, K, Wp, N, Npad16, C, ldc, coff, epi);
     }
     return;
   }
