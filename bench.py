@@ -62,7 +62,7 @@ def main():
             sys.exit(2)
     import torch
     import torch.distributed as dist
-    dist_on = world > 1
+    dist_on = world > 1 or os.environ.get("RT_BENCH_FORCE_DIST") == "1"  # (test hook: run the RCCL path with a single rank)
     tdev = "cuda" if a.backend == "nccl" else "cpu"
     if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")

@@ -243,3 +243,31 @@ def test_det_stem_from_u8_pages_matches_tensor_path(hip_session):
     finally:
         lib.rt_results_free(r)
     assert abs(got - ref) <= 1e-9 * abs(ref) + 1e-6, (got, ref)
+
+
+def test_rccl_weight_broadcast_single_rank():
+    """The N > 1 bench path over RCCL (backend "nccl"), exercised with the one GPU this box has: process group on
+    the device, weight-blob broadcast through device tensors, MAX / SUM all-reduce and barrier as bench.py uses them."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r'''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, %r)
+from retto_amd import synth
+from retto_amd.dist import broadcast_blobs, digest
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+blobs = list(synth.synth_models(0))
+got = broadcast_blobs(blobs, 4, 0, device="cuda")
+assert digest(got) == digest(blobs)
+t = torch.tensor([1.5], dtype=torch.float64, device="cuda"); dist.all_reduce(t, op=dist.ReduceOp.MAX)
+c = torch.tensor([7], dtype=torch.int64, device="cuda"); dist.all_reduce(c)
+dist.barrier(); torch.cuda.synchronize()
+assert float(t.item()) == 1.5 and int(c.item()) == 7
+dist.destroy_process_group()
+print("rccl ok")
+''' % root
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0 and "rccl ok" in out.stdout, out.stderr[-2000:]
