@@ -29,6 +29,14 @@ HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 FP32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: f32 MFMA / vector peak
 
 
+def _flush_c_stdio():
+    import ctypes
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -176,9 +184,13 @@ def main():
     else:
         n_lines_total = n_lines
 
+    # RCCL prints a version banner through C stdio at init; in a pipe it would only come out at process exit,
+    # i.e. after (rank 0) or interleaved with (other ranks) the JSON line.  Push it out now, on every rank.
+    _flush_c_stdio()
     if rank != 0:
         if dist_on:
             dist.destroy_process_group()
+        _flush_c_stdio()
         return
 
     total_pages = world * a.pages * a.steps
@@ -308,10 +320,12 @@ def main():
         "cpu_baseline": cpu_baseline,
         "networks": networks,
     }
-    print(json.dumps(out))
     sess.close()
     if dist_on:
         dist.destroy_process_group()
+    _flush_c_stdio()
+    sys.stdout.flush()
+    print(json.dumps(out), flush=True)  # the ONE line of the contract, last thing on stdout
 
 
 if __name__ == "__main__":
