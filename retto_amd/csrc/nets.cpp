@@ -290,6 +290,14 @@ DetNet::DetNet(const Blob& b) {
     std::string js = std::to_string(j);
     out_[j] = pack_conv(ws_, b, "det.out" + js, out_c[j], tap_c[j], 1, 1);
     ins_[j] = pack_conv(ws_, b, "det.fpn.ins" + js, 96, out_c[j], 1, 1);
+    {  // the same weights as [cin][96] (bias-free conv: checked by the manifest)
+      const BlobTensor& w = b.get("det.fpn.ins" + js + ".w");
+      std::vector<float> lin((size_t)out_c[j] * 96);
+      for (int n = 0; n < 96; n++)
+        for (int k = 0; k < out_c[j]; k++) lin[(size_t)k * 96 + n] = w.data[(size_t)n * out_c[j] + k];
+      ins_lin_[j] = ws_.upload(lin);
+      has_bias_[j] = b.has("det.fpn.ins" + js + ".b");
+    }
     ins_se_[j] = get_se(ws_, b, "det.fpn.ins" + js + ".se", 96);
     inp_[j] = pack_conv(ws_, b, "det.fpn.inp" + js, 24, 96, 3, 3);
     inp_se_[j] = get_se(ws_, b, "det.fpn.inp" + js + ".se", 24);
@@ -333,18 +341,29 @@ float* DetNet::run(RunCtx& c, const float* x, Level& L0, const nn::U8Page* pages
   // of their own: ins[j]'s go into the top-down add that consumes it (out = ins[j] * s + up(ins[j+1]); the
   // coarsest level, which has no add, is rescaled in place), inp[j]'s into the concat gather.
   float* in[4];
-  float* in_scale[4];
   for (int j = 3; j >= 0; j--) {
     in[j] = c.arena->alloc<float>((size_t)tap_lv[j]->total * 96);
-    { ProfScope ps(c.prof, c.st, "gemm_misc", shape_str(tap_lv[j]->total, ins_[j].K, 96, 0));
-      nn::gemm(c.st, taps[j], round_up(out_[j].N, 4), tap_lv[j]->total, ins_[j].K, ins_[j].w, 96, ins_[j].Npad, in[j], 96,
-               0, make_epi(ins_[j], ACT_NONE)); }
-    in_scale[j] = run_se(c, in[j], *tap_lv[j], ins_se_[j], HSIG_MBV3, 1, j == 3);
-  }
-  for (int j = 2; j >= 0; j--) {
-    ProfScope ps(c.prof, c.st, "upsample_add");
-    nn::upsample_add(c.st, in[j], in[j + 1], tap_lv[j]->d, tap_lv[j + 1]->d, tap_lv[j]->n(), tap_lv[j]->maxPix, 96, in[j],
-                     in_scale[j]);
+    const int cin = out_[j].N, cin_p = round_up(cin, 4);
+    if (j == 3 || has_bias_[j]) {  // coarsest level (no add to fold into), or a lateral conv that carries a bias: GEMM + SE in place
+      { ProfScope ps(c.prof, c.st, "gemm_misc", shape_str(tap_lv[j]->total, ins_[j].K, 96, 0));
+        nn::gemm(c.st, taps[j], cin_p, tap_lv[j]->total, ins_[j].K, ins_[j].w, 96, ins_[j].Npad, in[j], 96, 0, make_epi(ins_[j], ACT_NONE)); }
+      float* sc = run_se(c, in[j], *tap_lv[j], ins_se_[j], HSIG_MBV3, 1, j == 3);
+      if (j < 3) {
+        ProfScope ps(c.prof, c.st, "upsample_add");
+        nn::upsample_add(c.st, in[j], in[j + 1], tap_lv[j]->d, tap_lv[j + 1]->d, tap_lv[j]->n(), tap_lv[j]->maxPix, 96, in[j], sc);
+      }
+      continue;
+    }
+    // lateral conv (cin -> 96, no bias) + SE factor + top-down add in one pass over the 96-channel tensor: the squeeze
+    // only needs the channel means, and mean(x . W) = mean(x) . W
+    const Level& L = *tap_lv[j];
+    float* partial = c.arena->alloc<float>((size_t)L.n() * nn::pool_chunks(L.maxPix) * cin_p);
+    float* scale = c.arena->alloc<float>((size_t)L.n() * 96);
+    { ProfScope ps(c.prof, c.st, "se_pool_fc");
+      nn::se_scale_projected(c.st, taps[j], L.d, L.n(), L.maxPix, cin, cin_p, ins_lin_[j], 96, 96, ins_se_[j].w1, ins_se_[j].b1,
+                             ins_se_[j].w2, ins_se_[j].b2, ins_se_[j].Cr, HSIG_MBV3, 1, partial, scale); }
+    { ProfScope ps(c.prof, c.st, "lateral_add", shape_str(L.total, cin, 96, 0));
+      nn::lateral_add(c.st, taps[j], cin, cin_p, ins_lin_[j], 96, scale, in[j + 1], L.d, tap_lv[j + 1]->d, L.n(), L.maxPix, in[j]); }
   }
   float* p[4];
   const float* p_scale[4];

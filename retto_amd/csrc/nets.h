@@ -79,6 +79,8 @@ class DetNet {
   std::vector<LcBlock> blocks_;
   int tap_after_[4];
   PackedDense out_[4], ins_[4], inp_[4], head_conv1_;
+  float* ins_lin_[4];  // lateral 1x1 weights as [cin][96] for the fused lateral + top-down add
+  bool has_bias_[4] = {false, false, false, false};
   SeW ins_se_[4], inp_se_[4];
   float *dc1_w_, *dc1_b_, *dc2_w_, *dc2_b_;
 };

@@ -82,6 +82,13 @@ void scale_channels(hipStream_t st, float* x, const ImgGeom* geom, int n_img, lo
 void global_mean(hipStream_t st, const float* x, const ImgGeom* geom, int n_img, long long max_pix, int Cp,
                  float* partial, float* out);
 
+// FPN lateral without materialising the lateral conv: se_scale_projected pools the narrow tap tensor x (pitch Cin_p)
+// and maps the means through Wlin [Cin][C] before the SE FCs; lateral_add then writes (x . Wlin) * scale + up2(b).
+void se_scale_projected(hipStream_t st, const float* x_in, const ImgGeom* geom, int n_img, long long max_pix, int Cin,
+                        int Cin_p, const float* Wlin, int C, int Cp, const float* w1, const float* b1, const float* w2,
+                        const float* b2, int Cr, float slope, int residual, float* partial, float* scale);
+void lateral_add(hipStream_t st, const float* x, int Cin, int Cin_p, const float* Wlin, int C, const float* scale,
+                 const float* b, const ImgGeom* ga, const ImgGeom* gb, int n_img, long long max_pix, float* out);
 // out = a * scale_a[image] + nearest_up2(b)   (in place on a allowed; scale_a [image][Cp] optional)
 void upsample_add(hipStream_t st, const float* a, const float* b, const ImgGeom* ga, const ImgGeom* gb, int n_img,
                   long long max_pix, int Cp, float* out, const float* scale_a = nullptr);

@@ -2232,10 +2232,12 @@ __global__ __launch_bounds__(256) void k_se_fc(const float* __restrict__ partial
                                                int chunks_alloc, int C, int Cp, const float* __restrict__ w1,
                                                const float* __restrict__ b1, const float* __restrict__ w2,
                                                const float* __restrict__ b2, int Cr, float slope, int residual,
-                                               float* __restrict__ scale, int strip_R, int strips_per_block) {
-  extern __shared__ float sm[];  // mean[Cp] + hid[Cr]
+                                               float* __restrict__ scale, int strip_R, int strips_per_block,
+                                               const float* __restrict__ Wlin, int Cin, int Cin_p) {
+  extern __shared__ float sm[];  // mean[Cp] + hid[Cr] (+ mean_in[Cin_p] when projecting)
   float* mean = sm;
   float* hid = sm + Cp;
+  float* mean_in = sm + Cp + Cr + 4;
   const ImgGeom g = geom[blockIdx.x];
   const long long npix = (long long)g.H * g.W;
   // partial sums come from k_pool_partial (POOL_PIX pixels each) or, strip_R > 0, from the blocks of the
@@ -2243,10 +2245,26 @@ __global__ __launch_bounds__(256) void k_se_fc(const float* __restrict__ partial
   const int chunks = strip_R > 0 ? (((g.W + 3) >> 2) * ((g.H + strip_R - 1) / strip_R) + strips_per_block - 1) / strips_per_block
                                  : (int)((npix + POOL_PIX - 1) / POOL_PIX);
   const float inv = 1.0f / (float)npix;
-  for (int c = threadIdx.x; c < Cp; c += 256) {
-    float s = 0.f;
-    for (int k = 0; k < chunks; k++) s += partial[((long long)blockIdx.x * chunks_alloc + k) * Cp + c];
-    mean[c] = s * inv;
+  if (Wlin) {
+    // The pooled tensor is a bias-free 1x1 conv of a narrower one (FPN lateral: y = x . Wlin): mean(y) = mean(x) . Wlin,
+    // so the partial sums are those of x (pitch Cin_p) and y itself never has to exist for the squeeze.
+    for (int c = threadIdx.x; c < Cin_p; c += 256) {
+      float s = 0.f;
+      for (int k = 0; k < chunks; k++) s += partial[((long long)blockIdx.x * chunks_alloc + k) * Cin_p + c];
+      mean_in[c] = s * inv;
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < Cp; c += 256) {
+      float s = 0.f;
+      if (c < C) for (int k = 0; k < Cin; k++) s = fmaf(mean_in[k], Wlin[k * C + c], s);
+      mean[c] = s;
+    }
+  } else {
+    for (int c = threadIdx.x; c < Cp; c += 256) {
+      float s = 0.f;
+      for (int k = 0; k < chunks; k++) s += partial[((long long)blockIdx.x * chunks_alloc + k) * Cp + c];
+      mean[c] = s * inv;
+    }
   }
   __syncthreads();
   if (w1 == nullptr) {  // plain global mean
@@ -2278,7 +2296,16 @@ void se_scale(hipStream_t st, const float* x, const ImgGeom* geom, int n_img, lo
   int chunks = pool_chunks(max_pix);
   hipLaunchKernelGGL(k_pool_partial, dim3(chunks, n_img), dim3(256), 0, st, x, geom, Cp, chunks, partial);
   hipLaunchKernelGGL(k_se_fc, dim3(n_img), dim3(256), (Cp + Cr + 4) * sizeof(float), st, partial, geom, chunks, C, Cp,
-                     w1, b1, w2, b2, Cr, slope, residual, scale, 0, 32);
+                     w1, b1, w2, b2, Cr, slope, residual, scale, 0, 32, (const float*)nullptr, 0, 0);
+}
+void se_scale_projected(hipStream_t st, const float* x_in, const ImgGeom* geom, int n_img, long long max_pix, int Cin,
+                        int Cin_p, const float* Wlin, int C, int Cp, const float* w1, const float* b1, const float* w2,
+                        const float* b2, int Cr, float slope, int residual, float* partial, float* scale) {
+  if (n_img <= 0) return;
+  int chunks = pool_chunks(max_pix);
+  hipLaunchKernelGGL(k_pool_partial, dim3(chunks, n_img), dim3(256), 0, st, x_in, geom, Cin_p, chunks, partial);
+  hipLaunchKernelGGL(k_se_fc, dim3(n_img), dim3(256), (Cp + Cr + 4 + Cin_p + 4) * sizeof(float), st, partial, geom, chunks, C, Cp,
+                     w1, b1, w2, b2, Cr, slope, residual, scale, 0, 32, Wlin, Cin, Cin_p);
 }
 static int dw_strips_per_block(int K, int Cp) {  // 32-channel slabs (32 strips per block) unless the tensor is wide
   if (K == 5 && Cp >= g_dw_wide_slab_min) return 256 / g_dw_wide_lp;
@@ -2295,7 +2322,7 @@ void se_fc_from_dw(hipStream_t st, const float* partial, const ImgGeom* geom, in
                    int Cr, float slope, int residual, float* scale) {
   if (n_img <= 0) return;
   hipLaunchKernelGGL(k_se_fc, dim3(n_img), dim3(256), (Cp + Cr + 4) * sizeof(float), st, partial, geom, chunks, C, Cp,
-                     w1, b1, w2, b2, Cr, slope, residual, scale, strip_R, strips_per_block);
+                     w1, b1, w2, b2, Cr, slope, residual, scale, strip_R, strips_per_block, (const float*)nullptr, 0, 0);
 }
 void global_mean(hipStream_t st, const float* x, const ImgGeom* geom, int n_img, long long max_pix, int Cp,
                  float* partial, float* out) {
@@ -2304,7 +2331,7 @@ void global_mean(hipStream_t st, const float* x, const ImgGeom* geom, int n_img,
   hipLaunchKernelGGL(k_pool_partial, dim3(chunks, n_img), dim3(256), 0, st, x, geom, Cp, chunks, partial);
   hipLaunchKernelGGL(k_se_fc, dim3(n_img), dim3(256), (Cp + 4) * sizeof(float), st, partial, geom, chunks, Cp, Cp,
                      (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, 0,
-                     0.f, 0, out, 0, 32);
+                     0.f, 0, out, 0, 32, (const float*)nullptr, 0, 0);
 }
 
 __global__ __launch_bounds__(256) void k_scale_channels(float* __restrict__ x, const ImgGeom* __restrict__ geom, int Cp,
@@ -2331,6 +2358,66 @@ void scale_channels(hipStream_t st, float* x, const ImgGeom* geom, int n_img, lo
 // ---------------------------------------------------------------------------
 // FPN glue
 // ---------------------------------------------------------------------------
+// FPN lateral + top-down add in one pass: out = (x . Wlin) * s + nearest-2x(b).  x is the narrow tap tensor (pitch
+// Cin_p), Wlin [Cin][C] the bias-free 1x1 lateral conv, s [image][C] its squeeze-excite factor (from
+// se_scale_projected); the C-channel lateral tensor is written once, already scaled and summed.
+__global__ __launch_bounds__(256) void k_lateral_add(const float* __restrict__ x, int Cin, int Cin_p,
+                                                     const float* __restrict__ Wlin, int C, const float* __restrict__ s,
+                                                     const float* __restrict__ b, const ImgGeom* __restrict__ ga,
+                                                     const ImgGeom* __restrict__ gb, float* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) float wl[];  // [Cin][C]
+  for (int i = threadIdx.x; i < Cin * C / 4; i += 256) reinterpret_cast<f32x4*>(wl)[i] = reinterpret_cast<const f32x4*>(Wlin)[i];
+  __syncthreads();
+  const ImgGeom A = ga[blockIdx.y];
+  const int C4 = C >> 2;
+  constexpr int PPT = 4;  // consecutive pixels per thread: every weight vector read from LDS feeds 4 pixels
+  const long long npix = (long long)A.H * A.W;
+  long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  const int c4 = (int)(idx % C4);
+  const long long p0 = (idx / C4) * PPT;
+  if (p0 >= npix) return;
+  f32x4 acc[PPT];
+#pragma unroll
+  for (int i = 0; i < PPT; i++) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int k4 = 0; k4 < Cin_p; k4 += 4) {
+    f32x4 xv[PPT];
+#pragma unroll
+    for (int i = 0; i < PPT; i++)
+      xv[i] = (p0 + i < npix) ? *reinterpret_cast<const f32x4*>(x + (A.off + p0 + i) * Cin_p + k4) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+      if (k4 + e < Cin) {
+        const f32x4 w = *reinterpret_cast<const f32x4*>(wl + (k4 + e) * C + c4 * 4);
+#pragma unroll
+        for (int i = 0; i < PPT; i++)
+#pragma unroll
+          for (int j = 0; j < 4; j++) acc[i][j] = fmaf(xv[i][e], w[j], acc[i][j]);
+      }
+    }
+  }
+  const f32x4 sc = *reinterpret_cast<const f32x4*>(s + (long long)blockIdx.y * C + c4 * 4);
+  const ImgGeom B = b ? gb[blockIdx.y] : A;
+#pragma unroll
+  for (int i = 0; i < PPT; i++) {
+    const long long p = p0 + i;
+    if (p >= npix) break;
+    f32x4 o = acc[i] * sc;
+    if (b) {
+      const int y = (int)(p / A.W), xx = (int)(p % A.W);
+      const int by = min(y >> 1, B.H - 1), bx = min(xx >> 1, B.W - 1);
+      o += *reinterpret_cast<const f32x4*>(b + (B.off + (long long)by * B.W + bx) * C + c4 * 4);
+    }
+    *reinterpret_cast<f32x4*>(out + (A.off + p) * C + c4 * 4) = o;
+  }
+}
+void lateral_add(hipStream_t st, const float* x, int Cin, int Cin_p, const float* Wlin, int C, const float* scale,
+                 const float* b, const ImgGeom* ga, const ImgGeom* gb, int n_img, long long max_pix, float* out) {
+  if (n_img <= 0) return;
+  long long total = ((max_pix + 3) / 4) * (C / 4);  // 4 pixels per thread
+  hipLaunchKernelGGL(k_lateral_add, dim3((unsigned)((total + 255) / 256), n_img), dim3(256), (size_t)Cin * C * sizeof(float), st,
+                     x, Cin, Cin_p, Wlin, C, scale, b, ga, gb, out);
+}
+
 // out = a * sa + nearest-2x(b); sa (optional, [image][Cp]) is the squeeze-excite scale of `a`, folded in here
 // instead of a separate read+write pass over `a`.
 __global__ __launch_bounds__(256) void k_upsample_add(const float* __restrict__ a, const float* __restrict__ b,

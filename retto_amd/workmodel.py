@@ -95,13 +95,14 @@ def det_work(pages: Iterable[Tuple[int, int]]) -> Dict[str, Dict[str, float]]:
                     taps[j] = (h, ww, oc)
         for j in range(4):
             h, ww, oc = taps[j]
-            add("gemm_misc", h * ww * (oc + 96) * F + oc * 96 * F, 2 * h * ww * oc * 96)
-            add("se_pool_fc", h * ww * 96 * F)
-            if j == 3:  # the other levels' scales are folded into upsample_add / fpn_concat
+            if j == 3:  # coarsest level: lateral GEMM, squeeze-excite pooled on its output and applied in place
+                add("gemm_misc", h * ww * (oc + 96) * F + oc * 96 * F, 2 * h * ww * oc * 96)
+                add("se_pool_fc", h * ww * 96 * F)
                 add("scale_channels", 2 * h * ww * 96 * F)
-            if j < 3:
+            else:  # lateral conv + SE factor + top-down add in one pass (squeeze from the narrow tap tensor)
                 h2, w2, _ = taps[j + 1]
-                add("upsample_add", (2 * h * ww + h2 * w2) * 96 * F)
+                add("se_pool_fc", h * ww * oc * F)
+                add("lateral_add", (h * ww * (oc + 96) + h2 * w2 * 96) * F + oc * 96 * F, 2 * h * ww * oc * 96)
             add("conv3x3", h * ww * (96 + 24) * F + 9 * 96 * 24 * F, 2 * h * ww * 9 * 96 * 24)
             add("se_pool_fc", h * ww * 24 * F)
         h4, w4, _ = taps[0]
