@@ -718,7 +718,26 @@ rt_results* rt_session::run_batch(const uint8_t* const* rgb, const int* hs, cons
   std::vector<rt_results*> parts((size_t)nl, nullptr);
   std::vector<std::exception_ptr> errs((size_t)nl);
   std::vector<int> first((size_t)nl + 1, 0);
-  for (int l = 0; l < nl; l++) first[l + 1] = first[l] + n_pages / nl + (l < n_pages % nl ? 1 : 0);
+  {
+    // contiguous ranges of about equal work: det pixels after the session size limit (a2) plus a constant per page
+    // for its lines; equal page counts when the pages are all one size
+    std::vector<double> cost((size_t)n_pages);
+    double total = 0;
+    for (int i = 0; i < n_pages; i++) {
+      const double h = std::max(hs[i], 1), w = std::max(ws[i], 1);
+      const double r = std::min(1.0, (double)cfg.max_side_len / std::max(h, w));
+      total += cost[(size_t)i] = h * w * r * r + 250000.0;
+    }
+    double acc = 0;
+    int l = 1;
+    for (int i = 0; i < n_pages && l < nl; i++) {
+      acc += cost[(size_t)i];
+      // close range l-1 after page i once its share is reached, leaving at least one page for each later lane
+      if (acc >= total * l / nl - 1e-6 || n_pages - (i + 1) <= nl - l) first[l++] = i + 1;  // one range per page: none empty
+    }
+    for (; l <= nl; l++) first[l] = n_pages;
+    for (int k = 1; k <= nl; k++) first[k] = std::max(first[k], first[k - 1]);
+  }
   auto work = [&](int l) {
     rt_session* s = l == 0 ? this : helpers[(size_t)l - 1].get();
     arm(s, first[l]);
