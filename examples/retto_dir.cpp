@@ -2,8 +2,8 @@
 // (/root/reference/retto-cli/src/main.rs:41-95) without Python -- walk a directory, read every page,
 // run the pages through rt_run_batch in batches, print the three stage results per image in the wire
 // format retto-wasm emits (retto-wasm/fe/index.ts:5-42) and the average time per image.
-// Pages are binary PPM (P6, maxval 255): this image has no PNG/JPEG library, and the reference decodes
-// on the host as well (image_helper.rs:34-44), so decode stays outside the library.
+// Files are handed over encoded, as RettoSession::run takes them (session.rs:108): the library decodes PNG /
+// JPEG / PNM / BMP on host threads (rt_run_encoded_batch; image_helper.rs:34-44 is host code in the reference too).
 //
 //   g++ -std=c++17 -Iinclude examples/retto_dir.cpp -Lretto_amd -lretto_hip -Wl,-rpath,$PWD/retto_amd -o examples/retto_dir
 //   examples/retto_dir --det det.onnx --cls cls.onnx --rec rec.onnx --keys ppocr_keys_v1.txt --images DIR
@@ -18,30 +18,15 @@
 
 #include "retto_hip.h"
 
-struct Page { std::string path; int h = 0, w = 0; std::vector<uint8_t> rgb; };
+struct Page { std::string path; std::vector<uint8_t> bytes; };
 
-static bool read_ppm(const std::string& path, Page* p) {
+static bool read_file(const std::string& path, Page* p) {  // fs::read in main.rs:83
   FILE* f = fopen(path.c_str(), "rb");
   if (!f) return false;
-  char magic[3] = {0};
-  int w = 0, h = 0, maxv = 0;
-  bool ok = fscanf(f, "%2s", magic) == 1 && strcmp(magic, "P6") == 0;
-  for (int* v : {&w, &h, &maxv}) {
-    if (!ok) break;
-    int c = fgetc(f);
-    while (c == ' ' || c == '\n' || c == '\r' || c == '\t' || c == '#') {
-      if (c == '#') while (c != '\n' && c != EOF) c = fgetc(f);
-      c = fgetc(f);
-    }
-    ungetc(c, f);
-    ok = fscanf(f, "%d", v) == 1;
-  }
-  ok = ok && maxv == 255 && w > 0 && h > 0 && fgetc(f) != EOF;
-  if (ok) {
-    p->path = path; p->h = h; p->w = w;
-    p->rgb.resize((size_t)h * w * 3);
-    ok = fread(p->rgb.data(), 1, p->rgb.size(), f) == p->rgb.size();
-  }
+  p->path = path;
+  uint8_t buf[1 << 16];
+  for (size_t n; (n = fread(buf, 1, sizeof(buf), f)) > 0;) p->bytes.insert(p->bytes.end(), buf, buf + n);
+  const bool ok = !ferror(f);
   fclose(f);
   return ok;
 }
@@ -79,14 +64,14 @@ int main(int argc, char** argv) {
     std::vector<Page> pages;
     for (size_t i = b0; i < std::min(files.size(), b0 + (size_t)batch); i++) {
       Page p;
-      if (!read_ppm(files[i], &p)) { fprintf(stderr, "Failed to decode image %s\n", files[i].c_str()); rt_destroy(s); return 1; }
+      if (!read_file(files[i], &p)) { fprintf(stderr, "Failed to read image file %s\n", files[i].c_str()); rt_destroy(s); return 1; }
       pages.push_back(std::move(p));
     }
-    std::vector<const uint8_t*> ptr; std::vector<int> hs, ws;
-    for (auto& p : pages) { ptr.push_back(p.rgb.data()); hs.push_back(p.h); ws.push_back(p.w); }
+    std::vector<const void*> ptr; std::vector<size_t> lens;
+    for (auto& p : pages) { ptr.push_back(p.bytes.data()); lens.push_back(p.bytes.size()); }
     rt_results* r = nullptr;
-    rc = rt_run_batch(s, ptr.data(), hs.data(), ws.data(), (int)pages.size(), RT_MEM_HOST, nullptr, &r);
-    if (rc != RT_OK) { fprintf(stderr, "rt_run_batch failed (%d): %s\n", rc, rt_last_error(s)); rt_destroy(s); return 1; }
+    rc = rt_run_encoded_batch(s, ptr.data(), lens.data(), (int)pages.size(), nullptr, nullptr, &r);  // decode (host threads) + pipeline
+    if (rc != RT_OK) { fprintf(stderr, "rt_run_encoded_batch failed (%d): %s\n", rc, rt_last_error(s)); rt_destroy(s); return 1; }
     for (int i = 0; i < rt_results_pages(r); i++)
       printf("{\"file\":\"%s\",\"det\":%s,\"cls\":%s,\"rec\":%s}\n", pages[i].path.c_str(), rt_results_json(r, i, 0),
              rt_results_json(r, i, 1), rt_results_json(r, i, 2));

@@ -205,6 +205,18 @@ RT_API int rt_profile_get(rt_session* s, const char* const** names, const float*
  * (optional, err_cap bytes) receives the message and the RT_ERR_* code is returned. */
 RT_API int rt_onnx_to_rtwb(int which, const void* onnx, size_t len, void** out, size_t* out_len, char* err, size_t err_cap);
 RT_API void rt_buffer_free(void* p);
+
+/* ---- encoded pages ----------------------------------------------------
+ * rt_decode_image replaces ImageHelper::new_from_raw_img_flow (retto-core/src/image_helper.rs:34-44:
+ * image::load_from_memory(bytes)?.to_rgb8()): PNG (all colour types / depths, Adam7), sequential
+ * Huffman JPEG (grey / YCbCr, any sampling), PNM, uncompressed BMP -> tightly packed RGB8 [h][w][3],
+ * alpha dropped, 16-bit samples as (v + 128) / 257.  Host-only.  *rgb is library-owned until
+ * rt_buffer_free.  Unknown / corrupt input: RT_ERR_IMAGE with the reason in err (optional).
+ * rt_run_encoded_batch is RettoSession::run / run_stream (session.rs:108-143) over encoded
+ * bytes: pages are decoded on host threads, then processed as by rt_run_batch_stream (cb may be NULL). */
+RT_API int rt_decode_image(const void* data, size_t len, uint8_t** rgb, int* h, int* w, char* err, size_t err_cap);
+RT_API int rt_run_encoded_batch(rt_session* s, const void* const* files, const size_t* lens, int n_pages,
+                                rt_stage_callback cb, void* user, rt_results** out);
 /* The tensor list (RTWB names and shapes, forward order, -1 = read from the file) the importer
  * fills for model `which`, one "name d0 d1 ..." line per tensor; returns the length needed. */
 RT_API size_t rt_model_manifest(int which, char* buf, size_t cap);

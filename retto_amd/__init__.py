@@ -275,14 +275,19 @@ class RettoHipWorker:
 
 
 def decode_image(data: bytes) -> np.ndarray:
-    """ImageHelper::new_from_raw_img_flow (image_helper.rs:34-44): bytes -> RGB8 [H,W,3]
-    (host-side decode, like the reference)."""
-    from PIL import Image
+    """ImageHelper::new_from_raw_img_flow (image_helper.rs:34-44): encoded bytes -> RGB8 [H,W,3] through the
+    library's host decoder (rt_decode_image: PNG, sequential JPEG, PNM, BMP); raises ImageError otherwise."""
+    lib = _lib.load()
+    data = bytes(data)
+    out = C.c_void_p(); h = C.c_int(); w = C.c_int()
+    err = C.create_string_buffer(512)
+    rc = lib.rt_decode_image(data, len(data), C.byref(out), C.byref(h), C.byref(w), err, len(err))
+    if rc != 0:
+        raise _ERRS.get(rc, RettoError)(err.value.decode("utf-8", "replace"))
     try:
-        im = Image.open(io.BytesIO(data)); im.load()
-    except Exception as e:  # image::ImageError
-        raise ImageError(str(e))
-    return np.ascontiguousarray(np.asarray(im.convert("RGB"), np.uint8))
+        return np.ctypeslib.as_array(C.cast(out, C.POINTER(C.c_uint8)), (h.value, w.value, 3)).copy()
+    finally:
+        lib.rt_buffer_free(out)
 
 
 class RettoSession:
@@ -406,8 +411,22 @@ class RettoSession:
 
     def run(self, image: Union[bytes, np.ndarray]) -> RettoWorkerResult:
         """session.rs:108-131.  ``image`` is an encoded image (bytes) or an RGB8 array."""
-        page = decode_image(image) if isinstance(image, (bytes, bytearray, memoryview)) else image
-        return self.run_batch([page])[0]
+        if isinstance(image, (bytes, bytearray, memoryview)):
+            return self.run_encoded_batch([bytes(image)])[0]
+        return self.run_batch([image])[0]
+
+    def run_encoded_batch(self, files: Sequence[bytes]) -> List[RettoWorkerResult]:
+        """RettoSession::run over a batch of encoded images (rt_run_encoded_batch: decode on host threads, then
+        the batch pipeline)."""
+        n = len(files)
+        files = [bytes(f) for f in files]
+        ptrs = (C.c_char_p * n)(*files); lens = (C.c_size_t * n)(*[len(f) for f in files])
+        out = C.c_void_p()
+        _check(self._hd.lib.rt_run_encoded_batch(self._hd.h, ptrs, lens, n, None, None, C.byref(out)), self._hd.h)
+        try:
+            return [self._collect(out, i) for i in range(n)]
+        finally:
+            self._hd.lib.rt_results_free(out)
 
     def run_stream(self, image, sender: Callable[[str, list], None]) -> None:
         """session.rs:133-143: emits ("Det", ...), ("Cls", ...), ("Rec", ...) in that order.  Det arrives while

@@ -49,7 +49,7 @@ EXPORTS = [
     "rt_results_rec_tokens", "rt_results_rec_text", "rt_results_det_checksum", "rt_results_json",
     "rt_device_malloc", "rt_device_free", "rt_memcpy_h2d", "rt_memcpy_d2h", "rt_synchronize",
     "rt_set_lanes", "rt_profile_enable", "rt_profile_get",
-    "rt_onnx_to_rtwb", "rt_buffer_free", "rt_model_manifest",
+    "rt_onnx_to_rtwb", "rt_buffer_free", "rt_model_manifest", "rt_decode_image", "rt_run_encoded_batch",
 ]
 
 STAGE_CALLBACK = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.c_int, C.c_char_p)  # rt_stage_callback
@@ -127,6 +127,8 @@ def load():
     lib.rt_buffer_free.argtypes = [C.c_void_p]
     lib.rt_buffer_free.restype = None
     lib.rt_model_manifest.argtypes = [C.c_int, C.c_char_p, C.c_size_t]
+    lib.rt_decode_image.argtypes = [C.c_char_p, C.c_size_t, P(C.c_void_p), P(C.c_int), P(C.c_int), C.c_char_p, C.c_size_t]
+    lib.rt_run_encoded_batch.argtypes = [C.c_void_p, P(C.c_char_p), P(C.c_size_t), C.c_int, C.c_void_p, C.c_void_p, P(C.c_void_p)]
     lib.rt_model_manifest.restype = C.c_size_t
     _lib = lib
     return lib

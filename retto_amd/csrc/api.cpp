@@ -1,4 +1,6 @@
 // extern "C" surface of libretto_hip.so (include/retto_hip.h).
+#include <thread>
+#include <atomic>
 #include <cmath>
 #include <cstring>
 #include <new>
@@ -6,6 +8,7 @@
 #include "geom_math.h"
 #include "session.h"
 #include "onnx_import.h"
+#include "image_decode.h"
 
 using namespace rt;
 
@@ -170,6 +173,55 @@ int rt_run_batch_stream(rt_session* s, const uint8_t* const* rgb, const int* hs,
   RT_REQUIRE(mem == RT_MEM_HOST || mem == RT_MEM_DEVICE, s, "rt_run_batch_stream: bad mem kind");
   *out = nullptr;
   return guarded(s, [&] { *out = s->run_batch(rgb, hs, ws, n_pages, mem, det_map_override, cb, user); });
+}
+int rt_decode_image(const void* data, size_t len, uint8_t** rgb, int* h, int* w, char* err, size_t err_cap) {
+  if (err && err_cap) err[0] = 0;
+  if (!data || !rgb || !h || !w) { if (err && err_cap) snprintf(err, err_cap, "rt_decode_image: null argument"); return RT_ERR_INVALID; }
+  *rgb = nullptr;
+  try {
+    std::vector<uint8_t> px;
+    rt::decode_image((const uint8_t*)data, len, &px, h, w);
+    uint8_t* p = (uint8_t*)malloc(px.size());
+    if (!p) throw RtError(RT_ERR_BACKEND, "out of memory");
+    memcpy(p, px.data(), px.size());
+    *rgb = p;
+    return RT_OK;
+  } catch (const RtError& e) {
+    if (err && err_cap) snprintf(err, err_cap, "%s", e.what());
+    return e.code;
+  } catch (const std::exception& e) {
+    if (err && err_cap) snprintf(err, err_cap, "%s", e.what());
+    return RT_ERR_BACKEND;
+  }
+}
+// RettoSession::run / run_stream take the encoded bytes (session.rs:108,133): decode on host threads, then the batch path
+int rt_run_encoded_batch(rt_session* s, const void* const* files, const size_t* lens, int n_pages, rt_stage_callback cb,
+                         void* user, rt_results** out) {
+  RT_REQUIRE(s && out && n_pages >= 0 && (n_pages == 0 || (files && lens)), s, "rt_run_encoded_batch: bad argument");
+  *out = nullptr;
+  return guarded(s, [&] {
+    std::vector<std::vector<uint8_t>> px((size_t)n_pages);
+    std::vector<int> hs((size_t)n_pages), ws((size_t)n_pages);
+    std::vector<std::exception_ptr> errs((size_t)n_pages);
+    std::atomic<int> next{0};
+    auto work = [&] {
+      for (int i; (i = next.fetch_add(1)) < n_pages;) {
+        try {
+          if (!files[i]) throw RtError(RT_ERR_IMAGE, "image decode: null input");
+          rt::decode_image((const uint8_t*)files[i], lens[i], &px[(size_t)i], &hs[(size_t)i], &ws[(size_t)i]);
+        } catch (...) { errs[(size_t)i] = std::current_exception(); }
+      }
+    };
+    const int nt = std::max(1, std::min<int>(n_pages, std::min<int>(16, (int)std::thread::hardware_concurrency())));
+    std::vector<std::thread> th;
+    for (int t = 1; t < nt; t++) th.emplace_back(work);
+    work();
+    for (auto& t : th) t.join();
+    for (auto& e : errs) if (e) std::rethrow_exception(e);  // first failing page in page order, like the reference's `?`
+    std::vector<const uint8_t*> ptrs((size_t)n_pages);
+    for (int i = 0; i < n_pages; i++) ptrs[(size_t)i] = px[(size_t)i].data();
+    *out = s->run_batch(ptrs.data(), hs.data(), ws.data(), n_pages, RT_MEM_HOST, nullptr, cb, user);
+  });
 }
 void rt_results_free(rt_results* r) { delete r; }
 int rt_results_pages(const rt_results* r) { return r ? (int)r->pages.size() : 0; }

@@ -151,7 +151,7 @@ def test_session_from_onnx_sources(tmp_path):
 
 def test_native_directory_driver(tmp_path):
     """examples/retto_dir.cpp: the retto-cli loop in C++ over the C ABI alone (model files by path -- RTWB and
-    .onnx --, PPM pages from a directory); its JSON lines equal the Python mirror's stage JSON."""
+    .onnx --, PPM / PNG / JPEG files from a directory, decoded by the library); its JSON lines equal the Python mirror's stage JSON."""
     import json
     import subprocess
     import sys
@@ -175,14 +175,22 @@ def test_native_directory_driver(tmp_path):
     for i in range(3):
         page, _ = workload.planted_page(96 + 32 * i, 320, 2, seed=20 + i)
         # bright text lines on black give the random-weight detector nothing; the planted rectangles do not matter here
-        (pages_dir / ("p%d.ppm" % i)).write_bytes(b"P6\n%d %d\n255\n" % (page.shape[1], page.shape[0]) + page.tobytes())
+        if i == 0:
+            (pages_dir / "p0.ppm").write_bytes(b"P6\n%d %d\n255\n" % (page.shape[1], page.shape[0]) + page.tobytes())
+        elif i == 1:
+            from PIL import Image
+            Image.fromarray(page).save(pages_dir / "p1.png")
+        else:  # lossy: the page the driver sees is the decoded one
+            from PIL import Image
+            Image.fromarray(page).save(pages_dir / "p2.jpg", quality=90)
+            page = retto_amd.decode_image((pages_dir / "p2.jpg").read_bytes())
         pages.append(page)
     out = subprocess.run([exe, "--det", str(tmp_path / "det.rtwb"), "--cls", str(tmp_path / "cls.onnx"), "--rec", str(tmp_path / "rec.rtwb"),
                           "--keys", str(tmp_path / "keys.txt"), "--images", str(pages_dir), "--batch", "2"],
                          capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr
     lines = [json.loads(l) for l in out.stdout.strip().split("\n")]
-    assert [os.path.basename(l["file"]) for l in lines] == ["p0.ppm", "p1.ppm", "p2.ppm"]
+    assert [os.path.basename(l["file"]) for l in lines] == ["p0.ppm", "p1.png", "p2.jpg"]
     assert "Successfully processed 3 images" in out.stderr
     S = retto_amd.RettoWorkerModelSource
     cfg = retto_amd.RettoSessionConfig()
@@ -196,6 +204,35 @@ def test_native_directory_driver(tmp_path):
             assert l["det"] == det_j and l["cls"] == cls_j and l["rec"] == rec_j
     finally:
         s.close()
+
+
+def test_run_encoded_batch_equals_decoded_pages(hip_session):
+    """RettoSession::run takes encoded bytes (session.rs:108): rt_run_encoded_batch over PNG / JPEG files gives the
+    results of the decoded pages; a corrupt file fails the call with ImageError like image::load_from_memory's `?`."""
+    import io
+    from PIL import Image
+    import retto_amd
+    from retto_amd import workload
+    files, pages = [], []
+    for i, (fmt, kw) in enumerate((("PNG", {}), ("JPEG", {"quality": 92}), ("JPEG", {"quality": 80, "subsampling": 0}), ("BMP", {}))):
+        page, _ = workload.planted_page(128 + 32 * i, 352, 3, seed=40 + i)
+        b = io.BytesIO(); Image.fromarray(page).save(b, fmt, **kw)
+        files.append(b.getvalue())
+        pages.append(np.asarray(Image.open(io.BytesIO(files[-1])).convert("RGB")))
+    got = hip_session.run_encoded_batch(files)
+    want = hip_session.run_batch(pages)
+    assert len(got) == len(want) == 4
+    for g, w in zip(got, want):
+        assert len(g.det_result) == len(w.det_result)
+        for a, b_ in zip(g.det_result, w.det_result):
+            assert np.array_equal(a.boxes.as_array(), b_.boxes.as_array()) and a.score == b_.score
+        assert [c.label.label for c in g.cls_result] == [c.label.label for c in w.cls_result]
+        assert [r.text for r in g.rec_result] == [r.text for r in w.rec_result]
+    one = hip_session.run(files[0])
+    assert [r.text for r in one.rec_result] == [r.text for r in want[0].rec_result]
+    with pytest.raises(retto_amd.ImageError):
+        hip_session.run_encoded_batch([files[0], files[1][:100]])
+    assert hip_session.run_encoded_batch([]) == []
 
 
 def test_run_stream_order_and_payloads(hip_session):
