@@ -163,7 +163,7 @@ def test_native_directory_driver(tmp_path):
     exe = os.path.join(root, "examples", "retto_dir")
     if not os.path.exists(exe):  # normally built by __graft_entry__.build(); host-only C++, seconds
         subprocess.check_call(["g++", "-std=c++17", "-O2", "-I" + os.path.join(root, "include"), os.path.join(root, "examples", "retto_dir.cpp"),
-                               "-L" + os.path.join(root, "retto_amd"), "-lretto_hip", "-Wl,-rpath,$ORIGIN/../retto_amd", "-o", exe])
+                               "-L" + os.path.join(root, "retto_amd"), "-lretto_hip", "-Wl,-rpath,$ORIGIN/../retto_amd", "-pthread", "-o", exe])
     det, cls, rec, dic = synth.synth_models(0)
     (tmp_path / "det.rtwb").write_bytes(det)
     (tmp_path / "cls.onnx").write_bytes(build_model_onnx(retto_amd.model_manifest(retto_amd.MODEL_CLS), synth.cls_tensors(), seed=2, style=1))
