@@ -901,27 +901,29 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm_persist(const float* __re
     }
     const long long m0 = (tile / ncol) * BM;
     const int n0 = (int)(tile % ncol) * BN;
+    act_dispatch(epi.act, epi.has_lab, epi.residual != nullptr, [&](auto at, auto lt, auto rt_) {
+      constexpr int AC = decltype(at)::value, L = decltype(lt)::value, RES = decltype(rt_)::value;
 #pragma unroll
-    for (int nt = 0; nt < NT; nt++) {
-      int col = n0 + (wn * NT + nt) * 16 + q * 4;
-      if (col >= nstore) continue;
-      f32x4 bias = {0.f, 0.f, 0.f, 0.f};
-      if (epi.bias) bias = *reinterpret_cast<const f32x4*>(epi.bias + col);
+      for (int nt = 0; nt < NT; nt++) {
+        int col = n0 + (wn * NT + nt) * 16 + q * 4;
+        if (col >= nstore) continue;
+        f32x4 bias = {0.f, 0.f, 0.f, 0.f};
+        if (epi.bias) bias = *reinterpret_cast<const f32x4*>(epi.bias + col);
 #pragma unroll
-      for (int mt = 0; mt < MT; mt++) {
-        long long m = m0 + (wm * MT + mt) * 16 + r;
-        if (m >= M) continue;
-        f32x4 o;
+        for (int mt = 0; mt < MT; mt++) {
+          long long m = m0 + (wm * MT + mt) * 16 + r;
+          if (m >= M) continue;
+          f32x4 o;
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-          float t = act_apply(acc[mt][nt][j] + bias[j], epi.act);
-          if (epi.has_lab) t = fmaf(t, epi.lab_a, epi.lab_c);
-          if (epi.residual) t += epi.residual[m * epi.ld_res + col + j];
-          o[j] = (col + j < N) ? t : 0.0f;
+          for (int j = 0; j < 4; j++) {
+            float t = epi_val<AC, L>(acc[mt][nt][j] + bias[j], epi.act, epi.has_lab, epi.lab_a, epi.lab_c);
+            if (RES) t += epi.residual[m * epi.ld_res + col + j];
+            o[j] = (col + j < N) ? t : 0.0f;
+          }
+          *reinterpret_cast<f32x4*>(C + m * ldc + coff + col) = o;
         }
-        *reinterpret_cast<f32x4*>(C + m * ldc + coff + col) = o;
       }
-    }
+    });
   }
 }
 
@@ -1437,6 +1439,11 @@ void gemm(hipStream_t st, const float* A, int lda, long long M, int K, const flo
     } else {
       throw RtError(8, "gemm: a_scale is only implemented for the wide tiles");
     }
+    return;
+  }
+  if (v == 19) {  // A/B only: the 256 x 240 tile walked persistently needs > 168 VGPRs (171 spilled): 58 vs 93 TFLOP/s
+    long long nt = ((M + 255) / 256) * ((Npad16 + 239) / 240);
+    hipLaunchKernelGGL((k_gemm_persist<4, 5, 4, 3>), dim3((unsigned)std::min<long long>(nt, 256)), dim3(768), 0, st, A, lda, M, K, Wp, N, Npad16, C, ldc, coff, epi);
     return;
   }
   if (v == 13 || v == 14) {
