@@ -347,7 +347,7 @@ struct JpegDec {
       long z1 = (z2 + z3) * F0541;
       long t2 = z1 + z3 * (-F1847), t3 = z1 + z2 * F0765;
       z2 = p[0]; z3 = p[32];
-      long t0 = (z2 + z3) << CB, t1 = (z2 - z3) << CB;
+      long t0 = (z2 + z3) * (1L << CB), t1 = (z2 - z3) * (1L << CB);
       const long t10 = t0 + t3, t13 = t0 - t3, t11 = t1 + t2, t12 = t1 - t2;
       t0 = p[56]; t1 = p[40]; t2 = p[24]; t3 = p[8];
       z1 = t0 + t3; z2 = t1 + t2; z3 = t0 + t2; long z4 = t1 + t3;
@@ -367,7 +367,7 @@ struct JpegDec {
       long z2 = p[2], z3 = p[6];
       long z1 = (z2 + z3) * F0541;
       long t2 = z1 + z3 * (-F1847), t3 = z1 + z2 * F0765;
-      long t0 = ((long)p[0] + p[4]) << CB, t1 = ((long)p[0] - p[4]) << CB;
+      long t0 = ((long)p[0] + p[4]) * (1L << CB), t1 = ((long)p[0] - p[4]) * (1L << CB);
       const long t10 = t0 + t3, t13 = t0 - t3, t11 = t1 + t2, t12 = t1 - t2;
       t0 = p[7]; t1 = p[5]; t2 = p[3]; t3 = p[1];
       z1 = t0 + t3; z2 = t1 + t2; z3 = t0 + t2; long z4 = t1 + t3;
@@ -391,21 +391,23 @@ struct JpegDec {
     const uint16_t* q = qt[cm.tq];
     const int s = decode(hd);
     if (s > 11) bad("JPEG: corrupt DC coefficient");
-    if (s) cm.pred += extend(getbits(s), s);
-    coef[0] = cm.pred * q[0];
+    // (corrupt streams may drive the predictor or a product anywhere: wrap / clamp instead of overflowing)
+    if (s) cm.pred = (int)((unsigned)cm.pred + (unsigned)extend(getbits(s), s));
+    auto clampc = [](long v) { return (int)(v < -(1L << 24) ? -(1L << 24) : v > (1L << 24) ? (1L << 24) : v); };
+    coef[0] = clampc((long)cm.pred * q[0]);
     bool any_ac = false;
     for (int k = 1; k < 64;) {
       const int rs = decode(ha), r = rs >> 4, sz = rs & 15;
       if (sz == 0) { if (r != 15) break; k += 16; continue; }
       k += r;
       if (k > 63) bad("JPEG: corrupt AC coefficients");
-      coef[kZigzag[k]] = extend(getbits(sz), sz) * q[k];
+      coef[kZigzag[k]] = clampc((long)extend(getbits(sz), sz) * q[k]);
       any_ac = true;
       k++;
     }
     uint8_t* dst = cm.plane.data() + (size_t)by * 8 * cm.stride + (size_t)bx * 8;
     if (!any_ac) {  // flat block: both passes of the transform reduce to one rounding, (4 * dc + 16) >> 5
-      const int v = ((coef[0] * 4 + 16) >> 5) + 128;
+      const int v = (int)(((long)coef[0] * 4 + 16) >> 5) + 128;
       const uint8_t px = (uint8_t)(v < 0 ? 0 : v > 255 ? 255 : v);
       for (int r8 = 0; r8 < 8; r8++) memset(dst + (size_t)r8 * cm.stride, px, 8);
       return;

@@ -69,11 +69,11 @@ static Tensor parse_tensor(Span sp) {
     else if (f == 2) t.dtype = (int)v;
     else if (f == 4) {  // float_data
       if (wt == 5) { float x; uint32_t u = (uint32_t)v; memcpy(&x, &u, 4); t.f.push_back(x); }
-      else { size_t n = s.n / 4; size_t o = t.f.size(); t.f.resize(o + n); memcpy(t.f.data() + o, s.p, n * 4); }
+      else { size_t n = s.n / 4; size_t o = t.f.size(); t.f.resize(o + n); if (n) memcpy(t.f.data() + o, s.p, n * 4); }
     } else if (f == 8) t.name = str(s);
     else if (f == 9) { raw = s; has_raw = true; }
   }
-  if (t.dtype == 1 && has_raw) { t.f.resize(raw.n / 4); memcpy(t.f.data(), raw.p, t.f.size() * 4); }
+  if (t.dtype == 1 && has_raw) { t.f.resize(raw.n / 4); if (!t.f.empty()) memcpy(t.f.data(), raw.p, t.f.size() * 4); }
   if (t.dtype == 1 && t.f.size() != t.numel()) throw RtError(4, "ONNX: tensor " + t.name + " has " + std::to_string(t.f.size()) + " values for its dims");
   return t;
 }
@@ -163,6 +163,7 @@ static std::vector<Event> extract_events(const Graph& g) {
   struct Mul { std::string in, out, where; const Tensor* t; };
   std::vector<Mul> muls;
   for (const Node& n : g.nodes) {
+    if (n.in.empty() || n.out.empty()) continue;  // malformed or parameter-free node: nothing to take
     if (n.op == "Conv" || n.op == "ConvTranspose") {
       const Tensor* w = n.in.size() > 1 ? fparam(g, n.in[1]) : nullptr;
       if (!w || w->dims.size() != 4) continue;
@@ -173,6 +174,7 @@ static std::vector<Event> extract_events(const Graph& g) {
     } else if (n.op == "BatchNormalization" && n.in.size() >= 5) {
       const Tensor *sc = fparam(g, n.in[1]), *bi = fparam(g, n.in[2]), *mu = fparam(g, n.in[3]), *va = fparam(g, n.in[4]);
       if (!sc || !bi || !mu || !va) continue;
+      if (bi->f.size() != sc->f.size() || mu->f.size() != sc->f.size() || va->f.size() != sc->f.size()) throw RtError(4, "ONNX: BatchNormalization " + n.name + " has parameters of different lengths");
       const float eps = n.floats.count("epsilon") ? n.floats.at("epsilon") : 1e-5f;
       Event e; e.kind = EV_BN; e.in = n.in[0]; e.out = n.out[0]; e.where = "BatchNormalization " + n.name;
       const size_t C = sc->f.size(); e.dims = {(long long)C}; e.w.resize(C); e.b.resize(C); e.has_b = true;
@@ -185,8 +187,9 @@ static std::vector<Event> extract_events(const Graph& g) {
       const Tensor* w = n.in.size() > 1 ? fparam(g, n.in[1]) : nullptr;
       if (!w || w->dims.size() != 2) continue;
       Event e; e.kind = EV_MATMUL; e.in = n.in[0]; e.out = n.out[0]; e.where = n.op + " " + n.name;
-      const bool tb = n.op == "Gemm" && n.ints.count("transB") && n.ints.at("transB")[0] != 0;
+      const bool tb = n.op == "Gemm" && n.ints.count("transB") && !n.ints.at("transB").empty() && n.ints.at("transB")[0] != 0;
       const long long K = tb ? w->dims[1] : w->dims[0], N = tb ? w->dims[0] : w->dims[1];
+      if (K < 0 || N < 0) throw RtError(4, "ONNX: " + n.op + " " + n.name + " has a negative weight dimension");
       e.dims = {K, N}; e.w.resize((size_t)(K * N));
       for (long long k = 0; k < K; k++)
         for (long long j = 0; j < N; j++) e.w[(size_t)(k * N + j)] = tb ? w->f[(size_t)(j * K + k)] : w->f[(size_t)(k * N + j)];
