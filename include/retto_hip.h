@@ -208,8 +208,8 @@ RT_API void rt_buffer_free(void* p);
 
 /* ---- encoded pages ----------------------------------------------------
  * rt_decode_image replaces ImageHelper::new_from_raw_img_flow (retto-core/src/image_helper.rs:34-44:
- * image::load_from_memory(bytes)?.to_rgb8()): PNG (all colour types / depths, Adam7), sequential
- * Huffman JPEG (grey / YCbCr, any sampling), PNM, uncompressed BMP -> tightly packed RGB8 [h][w][3],
+ * image::load_from_memory(bytes)?.to_rgb8()): PNG (all colour types / depths, Adam7), Huffman
+ * JPEG (sequential and progressive; grey / YCbCr, any sampling), PNM, uncompressed BMP -> tightly packed RGB8 [h][w][3],
  * alpha dropped, 16-bit samples as (v + 128) / 257.  Host-only.  *rgb is library-owned until
  * rt_buffer_free.  Unknown / corrupt input: RT_ERR_IMAGE with the reason in err (optional).
  * rt_run_encoded_batch is RettoSession::run / run_stream (session.rs:108-143) over encoded

@@ -276,7 +276,7 @@ class RettoHipWorker:
 
 def decode_image(data: bytes) -> np.ndarray:
     """ImageHelper::new_from_raw_img_flow (image_helper.rs:34-44): encoded bytes -> RGB8 [H,W,3] through the
-    library's host decoder (rt_decode_image: PNG, sequential JPEG, PNM, BMP); raises ImageError otherwise."""
+    library's host decoder (rt_decode_image: PNG, JPEG, PNM, BMP); raises ImageError otherwise."""
     lib = _lib.load()
     data = bytes(data)
     out = C.c_void_p(); h = C.c_int(); w = C.c_int()

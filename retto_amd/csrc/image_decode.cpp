@@ -244,12 +244,13 @@ void decode_bmp(const uint8_t* d, size_t n, std::vector<uint8_t>* rgb, int* oh, 
 }
 
 // ------------------------------------------------------------------------------------------------
-// JPEG (ITU-T T.81): sequential Huffman DCT (SOF0 / SOF1, 8-bit), grey or three components, any
+// JPEG (ITU-T T.81): Huffman DCT, sequential (SOF0 / SOF1) and progressive (SOF2), 8-bit, grey or three components, any
 // sampling factors, interleaved or per-component scans, restart intervals.  Arithmetic follows
 // the IJG conventions every mainstream decoder reproduces: the 13-bit fixed-point "slow integer" inverse
 // DCT of Loeffler-Ligtenberg-Moschytz, triangle-filter ("fancy") chroma upsampling for 2:1 factors,
-// 16-bit fixed-point YCbCr -> RGB.  Progressive (SOF2), lossless, arithmetic-coded and CMYK files are
-// rejected with a message.
+// 16-bit fixed-point YCbCr -> RGB.  Progressive files (SOF2: spectral selection + successive approximation)
+// accumulate their coefficients over the scans and are transformed at the end.  Lossless, hierarchical,
+// arithmetic-coded and CMYK files are rejected with a message.
 // ------------------------------------------------------------------------------------------------
 struct Huff {
   bool ok = false;
@@ -268,6 +269,7 @@ struct JComp {
   int stride = 0, rows = 0;  // allocated plane (whole MCUs)
   int pred = 0;
   std::vector<uint8_t> plane;
+  std::vector<int> coef;   // progressive: all coefficients of the (MCU-padded) component, 64 per block, natural order
 };
 
 struct JpegDec {
@@ -278,6 +280,7 @@ struct JpegDec {
   uint16_t qt[4][64]; bool qt_ok[4] = {false, false, false, false};
   Huff dc[4], ac[4];
   uint64_t bits = 0; int nbits = 0; bool hit_marker = false;
+  bool progressive = false; int Ss = 0, Se = 63, Ah = 0, Al = 0, eobrun = 0;
 
   void fill() {
     while (nbits <= 56) {
@@ -415,6 +418,87 @@ struct JpegDec {
     idct_store(coef, dst, cm.stride);
   }
 
+  // Progressive mode (T.81 annex G): a scan carries one band [Ss, Se] of coefficients at bit position Al, either their
+  // first pass (Ah = 0) or one more bit of precision (Ah > 0); the block's coefficients accumulate in cm.coef.
+  void prog_block(JComp& cm, int bx, int by) {
+    int* blk = cm.coef.data() + ((size_t)by * (cm.stride / 8) + bx) * 64;
+    if (Ss == 0) {
+      if (Ah == 0) {
+        const int s = decode(dc[cm.td]);
+        if (s > 11) bad("JPEG: corrupt DC coefficient");
+        if (s) cm.pred = (int)((unsigned)cm.pred + (unsigned)extend(getbits(s), s));
+        const long v = (long)cm.pred * (1L << Al);
+        blk[0] = (int)(v < -(1L << 24) ? -(1L << 24) : v > (1L << 24) ? (1L << 24) : v);
+      } else if (getbits(1)) blk[0] |= 1 << Al;
+      return;
+    }
+    const Huff& ha = ac[cm.ta];
+    if (Ah == 0) {
+      if (eobrun > 0) { eobrun--; return; }
+      for (int k = Ss; k <= Se; k++) {
+        const int rs = decode(ha), r = rs >> 4, sz = rs & 15;
+        if (sz) {
+          k += r;
+          if (k > 63) bad("JPEG: corrupt AC coefficients");
+          blk[kZigzag[k]] = extend(getbits(sz), sz) * (1 << Al);
+        } else if (r == 15) k += 15;
+        else { eobrun = (1 << r) - 1; if (r) eobrun += getbits(r); break; }
+      }
+      return;
+    }
+    const int p1 = 1 << Al, m1 = -(1 << Al);
+    auto correct = [&](int* co) { if (getbits(1) && (*co & p1) == 0) *co += (*co >= 0 ? p1 : m1); };
+    int k = Ss;
+    if (eobrun == 0) {
+      for (; k <= Se; k++) {
+        const int rs = decode(ha), sz = rs & 15;
+        int r = rs >> 4, val = 0;
+        if (sz) val = getbits(1) ? p1 : m1;  // a newly non-zero coefficient is +-1 at this bit position
+        else if (r != 15) { eobrun = 1 << r; if (r) eobrun += getbits(r); break; }
+        // skip r still-zero coefficients; every already non-zero one passed on the way takes a correction bit
+        while (k <= Se) {
+          int* co = blk + kZigzag[k];
+          if (*co != 0) correct(co);
+          else if (--r < 0) break;
+          k++;
+        }
+        if (val) { if (k > 63) bad("JPEG: corrupt AC coefficients"); blk[kZigzag[k]] = val; }
+      }
+    }
+    if (eobrun > 0) {
+      for (; k <= Se; k++) { int* co = blk + kZigzag[k]; if (*co != 0) correct(co); }
+      eobrun--;
+    }
+  }
+
+  // progressive: after the last scan, dequantise and transform every block
+  void finish_progressive() {
+    for (int i = 0; i < nc; i++) {
+      JComp& cm = c[i];
+      if (!qt_ok[cm.tq]) bad("JPEG: frame refers to a missing quantisation table");
+      int qn[64];
+      for (int k = 0; k < 64; k++) qn[kZigzag[k]] = qt[cm.tq][k];
+      const int bw = cm.stride / 8, bh = cm.rows / 8;
+      for (int by = 0; by < bh; by++)
+        for (int bx = 0; bx < bw; bx++) {
+          const int* blk = cm.coef.data() + ((size_t)by * bw + bx) * 64;
+          int coef[64];
+          bool any_ac = false;
+          for (int k = 0; k < 64; k++) {
+            const long v = (long)blk[k] * qn[k];
+            coef[k] = (int)(v < -(1L << 24) ? -(1L << 24) : v > (1L << 24) ? (1L << 24) : v);
+            any_ac |= k > 0 && coef[k] != 0;
+          }
+          uint8_t* dst = cm.plane.data() + (size_t)by * 8 * cm.stride + (size_t)bx * 8;
+          if (!any_ac) {
+            const int v = (int)(((long)coef[0] * 4 + 16) >> 5) + 128;
+            const uint8_t px = (uint8_t)(v < 0 ? 0 : v > 255 ? 255 : v);
+            for (int r8 = 0; r8 < 8; r8++) memset(dst + (size_t)r8 * cm.stride, px, 8);
+          } else idct_store(coef, dst, cm.stride);
+        }
+    }
+  }
+
   void restart_marker(int& expect) {
     // discard the remaining bits, then the next two bytes must be RSTn
     bits = 0; nbits = 0;
@@ -425,15 +509,21 @@ struct JpegDec {
     pos += 2;
     expect = (expect + 1) & 7;
     for (int i = 0; i < nc; i++) c[i].pred = 0;
+    eobrun = 0;
   }
 
   void scan(const int* idx, int ns) {
     for (int i = 0; i < ns; i++) {
       JComp& cm = c[idx[i]];
-      if (!dc[cm.td].ok || !ac[cm.ta].ok) bad("JPEG: scan refers to a missing Huffman table");
-      if (!qt_ok[cm.tq]) bad("JPEG: frame refers to a missing quantisation table");
+      const bool need_dc = !progressive || (Ss == 0 && Ah == 0), need_ac = !progressive || Ss > 0;
+      if ((need_dc && !dc[cm.td].ok) || (need_ac && !ac[cm.ta].ok)) bad("JPEG: scan refers to a missing Huffman table");
+      if (!progressive && !qt_ok[cm.tq]) bad("JPEG: frame refers to a missing quantisation table");
       cm.pred = 0;
     }
+    if (progressive) {
+      if (Ss > Se || Se > 63 || Al > 13 || Ah > 13 || (Ss == 0 && Se != 0) || (Ss > 0 && ns != 1)) bad("JPEG: bad progressive scan parameters");
+    }
+    eobrun = 0;
     bits = 0; nbits = 0; hit_marker = false;
     int expect = 0;
     long count = 0;
@@ -443,7 +533,7 @@ struct JpegDec {
       for (int by = 0; by < bh; by++)
         for (int bx = 0; bx < bw; bx++) {
           if (restart && count && count % restart == 0) restart_marker(expect);
-          decode_block(cm, bx, by);
+          if (progressive) prog_block(cm, bx, by); else decode_block(cm, bx, by);
           count++;
         }
     } else {
@@ -454,7 +544,9 @@ struct JpegDec {
           for (int i = 0; i < ns; i++) {
             JComp& cm = c[idx[i]];
             for (int v = 0; v < cm.vs; v++)
-              for (int h = 0; h < cm.hs; h++) decode_block(cm, x * cm.hs + h, y * cm.vs + v);
+              for (int h = 0; h < cm.hs; h++) {
+                if (progressive) prog_block(cm, x * cm.hs + h, y * cm.vs + v); else decode_block(cm, x * cm.hs + h, y * cm.vs + v);
+              }
           }
           count++;
         }
@@ -555,7 +647,7 @@ struct JpegDec {
           build(tc ? ac[th] : dc[th], s + i + 1, s + i + 17, total);
           i += 17 + (size_t)total;
         }
-      } else if (m == 0xc0 || m == 0xc1) {  // SOF0 / SOF1
+      } else if (m == 0xc0 || m == 0xc1 || m == 0xc2) {  // SOF0 / SOF1 (sequential), SOF2 (progressive)
         if (have_sof) bad("JPEG: more than one frame header");
         if (sl < 6) bad("JPEG: bad frame header");
         if (s[0] != 8) bad("JPEG: only 8-bit samples are supported");
@@ -574,9 +666,11 @@ struct JpegDec {
           c[i].cw = (W * c[i].hs + hmax - 1) / hmax; c[i].ch = (H * c[i].vs + vmax - 1) / vmax;
           c[i].stride = mx * c[i].hs * 8; c[i].rows = my * c[i].vs * 8;
           c[i].plane.assign((size_t)c[i].stride * c[i].rows, 128);
+          if (m == 0xc2) c[i].coef.assign((size_t)c[i].stride * c[i].rows, 0);
         }
+        progressive = m == 0xc2;
         have_sof = true;
-      } else if (m == 0xc2) bad("JPEG: progressive files are not supported");
+      }
       else if (m == 0xc3 || (m >= 0xc5 && m <= 0xcf && m != 0xc8 && m != 0xcc)) bad("JPEG: lossless / hierarchical / arithmetic-coded files are not supported");
       else if (m == 0xdd) { if (sl < 2) bad("JPEG: bad DRI"); restart = (int)be16(s); }
       else if (m == 0xee) { if (sl >= 12 && !memcmp(s, "Adobe", 5)) { adobe = true; adobe_tf = s[11]; } }
@@ -595,12 +689,15 @@ struct JpegDec {
           if (c[k].td > 3 || c[k].ta > 3) bad("JPEG: bad table selector");
         }
         if (ns > 1 && ns != nc) bad("JPEG: partially interleaved scans are not supported");
+        const uint8_t* sp = s + 1 + 2 * ns;
+        Ss = sp[0]; Se = sp[1]; Ah = sp[2] >> 4; Al = sp[2] & 15;
         scan(idx, ns);
         scans++;
       }
       // everything else (APPn, COM, ...) is skipped
     }
     if (!have_sof || !scans) bad("JPEG: no image data");
+    if (progressive) finish_progressive();
     rgb->assign((size_t)W * H * 3, 0);
     if (nc == 1) {
       for (int y = 0; y < H; y++) {

@@ -39,7 +39,7 @@ void Blob::parse() {
   const uint8_t* p = bytes_.data();
   size_t n = bytes_.size();
   auto need = [&](size_t off, size_t cnt) {
-    if (off + cnt > n) throw RtError(4, "RTWB blob truncated");
+    if (cnt > n || off > n - cnt) throw RtError(4, "RTWB blob truncated");  // (no wrap-around on hostile offsets)
   };
   need(0, 16);
   if (memcmp(p, "RTWB", 4) != 0) throw RtError(4, "not an RTWB weight blob");
@@ -63,6 +63,7 @@ void Blob::parse() {
   }
   size_t base = (off + 63) / 64 * 64;
   for (auto& e : ents) {
+    if (e.o > n) throw RtError(4, "RTWB blob truncated");
     need(base + e.o, e.nb);
     BlobTensor t; t.dims = e.dims; t.data = reinterpret_cast<const float*>(p + base + e.o);
     if (t.numel() * 4 != e.nb) throw RtError(4, "RTWB: size mismatch for " + e.name);

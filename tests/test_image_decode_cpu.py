@@ -6,7 +6,8 @@ to_rgb8 rules (alpha dropped, grey replicated, (v + 128) / 257 for 16-bit sample
 two independent writers: Pillow (an independent codec implementation) and the small PNG writer below, which
 produces the cases Pillow cannot (Adam7, chosen filter types, 2/4-bit grey, 16-bit colour, split IDAT).
 JPEG: compared with Pillow's libjpeg decode of the same file -- equal, because both follow the IJG
-integer arithmetic (slow integer IDCT, triangle chroma upsampling, 16-bit fixed-point colour conversion).
+integer arithmetic (slow integer IDCT, triangle chroma upsampling, 16-bit fixed-point colour conversion);
+sequential and progressive files.
 """
 import io
 import struct
@@ -229,11 +230,23 @@ def test_jpeg_grey_optimised_tables_and_restart_intervals():
         assert np.array_equal(retto_amd.decode_image(data), np.asarray(Image.open(io.BytesIO(data)).convert("RGB"))), kw
 
 
+@pytest.mark.parametrize("subsampling", [0, 1, 2])
+@pytest.mark.parametrize("size", [(64, 64), (37, 53), (8, 130), (1, 1), (200, 120)])
+def test_progressive_jpeg_matches_libjpeg(subsampling, size):
+    h, w = size
+    a = _rng_img(h, w, 3, seed=h + 3 * w + subsampling)
+    for kw in ({"quality": 85}, {"quality": 40, "optimize": True}, {"quality": 95, "restart_marker_blocks": 5}):
+        data = _save(Image.fromarray(a, "RGB"), "JPEG", progressive=True, subsampling=subsampling, **kw)
+        assert b"\xff\xc2" in data
+        want = np.asarray(Image.open(io.BytesIO(data)).convert("RGB"))
+        got = retto_amd.decode_image(data)
+        assert np.array_equal(got, want), (kw, int(np.abs(got.astype(int) - want).max()))
+    g = _save(Image.fromarray(a[..., 0], "L"), "JPEG", progressive=True, quality=70)
+    assert np.array_equal(retto_amd.decode_image(g), np.asarray(Image.open(io.BytesIO(g)).convert("RGB")))
+
+
 def test_jpeg_unsupported_and_corrupt():
     a = _rng_img(32, 32, 3, seed=1)
-    prog = _save(Image.fromarray(a, "RGB"), "JPEG", progressive=True)
-    with pytest.raises(retto_amd.ImageError, match="progressive"):
-        retto_amd.decode_image(prog)
     base = _save(Image.fromarray(a, "RGB"), "JPEG")
     with pytest.raises(retto_amd.ImageError):
         retto_amd.decode_image(base[:30])

@@ -58,6 +58,8 @@ def test_image_decoder_survives_mutated_files(harness):
     add("e.jpg", pil(Image.fromarray(a), "JPEG", quality=80))
     add("f.jpg", pil(Image.fromarray(a), "JPEG", quality=60, subsampling=2, restart_marker_blocks=2))
     add("g.jpg", pil(Image.fromarray(a[..., 0]), "JPEG", optimize=True))
+    add("p.jpg", pil(Image.fromarray(a), "JPEG", quality=70, progressive=True, subsampling=2))
+    add("q.jpg", pil(Image.fromarray(a[..., 0]), "JPEG", quality=90, progressive=True, restart_marker_blocks=3))
     add("h.bmp", pil(Image.fromarray(a), "BMP"))
     add("i.bmp", pil(Image.fromarray(a).quantize(16), "BMP"))
     add("j.ppm", pil(Image.fromarray(a), "PPM"))
