@@ -720,5 +720,22 @@ void db_postprocess_batch(hipStream_t st, int n, const DbPageIn* in, const DbPar
   hipLaunchKernelGGL(k_sort_boxes, dim3(n), dim3(256), 0, st, dp);
 }
 
+// Sorted boxes of all pages -> one contiguous list (page order), so that the host fetches them with a single copy.
+// boxes: [n][max_boxes], counts: [n][2] as written by k_sort_boxes.  One block per page.
+__global__ __launch_bounds__(256) void k_pack_boxes(const DbBox* __restrict__ boxes, const int* __restrict__ counts,
+                                                    int max_boxes, DbBox* __restrict__ packed) {
+  const int page = blockIdx.x;
+  int off = 0;
+  for (int q = 0; q < page; q++) off += min(max(counts[2 * q], 0), max_boxes);
+  const int cnt = min(max(counts[2 * page], 0), max_boxes);
+  constexpr int WORDS = (int)(sizeof(DbBox) / 4);
+  const uint32_t* src = reinterpret_cast<const uint32_t*>(boxes + (size_t)page * max_boxes);
+  uint32_t* dst = reinterpret_cast<uint32_t*>(packed + off);
+  for (int i = threadIdx.x; i < cnt * WORDS; i += blockDim.x) dst[i] = src[i];
+}
+void pack_boxes(hipStream_t st, int n, const DbBox* boxes, const int* counts, int max_boxes, DbBox* packed) {
+  if (n > 0) hipLaunchKernelGGL(k_pack_boxes, dim3(n), dim3(256), 0, st, boxes, counts, max_boxes, packed);
+}
+
 }  // namespace pp
 }  // namespace rt

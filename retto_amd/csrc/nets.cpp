@@ -256,17 +256,21 @@ static float* run_lc(RunCtx& c, const LcBlock& b, const float* x, const Level& L
     { ProfScope ps(c.prof, c.st, "se_pool_fc");
       nn::se_fc_from_dw(c.st, pool, Lout.d, Lout.n(), chunks, strip_R, strips_pb, b.sew.C, b.dw.Cp, b.sew.w1, b.sew.b1, b.sew.w2,
                         b.sew.b2, b.sew.Cr, HSIG_LCNET, 0, scale); }
-    const long long tiles = (Lout.total + tile_rows - 1) / tile_rows;
-    int* htab = c.pinned->alloc<int>((size_t)tiles * 2);
-    int* dtab = c.arena->alloc<int>((size_t)tiles * 2);
-    size_t img = 0;
-    for (long long t = 0; t < tiles; t++) {
-      const long long m0 = t * tile_rows;
-      while (img + 1 < Lout.h.size() && Lout.h[img + 1].off <= m0) img++;
-      htab[2 * t] = (int)img;
-      htab[2 * t + 1] = img + 1 < Lout.h.size() ? (int)Lout.h[img + 1].off : 0x7fffffff;  // no next image: never crossed
+    const int*& dtab = Lout.a_tabs[tile_rows];
+    if (!dtab) {
+      const long long tiles = (Lout.total + tile_rows - 1) / tile_rows;
+      int* htab = c.pinned->alloc<int>((size_t)tiles * 2);
+      int* dt = c.arena->alloc<int>((size_t)tiles * 2);
+      size_t img = 0;
+      for (long long t = 0; t < tiles; t++) {
+        const long long m0 = t * tile_rows;
+        while (img + 1 < Lout.h.size() && Lout.h[img + 1].off <= m0) img++;
+        htab[2 * t] = (int)img;
+        htab[2 * t + 1] = img + 1 < Lout.h.size() ? (int)Lout.h[img + 1].off : 0x7fffffff;  // no next image: never crossed
+      }
+      RT_HIP_CHECK(hipMemcpyAsync(dt, htab, (size_t)tiles * 2 * sizeof(int), hipMemcpyHostToDevice, c.st));
+      dtab = dt;
     }
-    RT_HIP_CHECK(hipMemcpyAsync(dtab, htab, (size_t)tiles * 2 * sizeof(int), hipMemcpyHostToDevice, c.st));
     epi.a_scale = scale; epi.ld_scale = b.dw.Cp; epi.a_tab = dtab;
   } else if (b.se) {
     run_se(c, y1, Lout, b.sew, HSIG_LCNET, 0);

@@ -7,6 +7,7 @@
 #pragma once
 #include <memory>
 #include <string>
+#include <map>
 #include <vector>
 
 #include "nn.h"
@@ -22,6 +23,8 @@ struct Level {
   int maxH = 0, maxW = 0;
   long long maxPix = 0;   // max H*W over images
   int n() const { return (int)h.size(); }
+  // row tile -> image tables of the SE-scaled GEMMs (nets.cpp run_lc), by tile height: built and uploaded once per pass
+  mutable std::map<int, const int*> a_tabs;
 };
 
 struct RunCtx {

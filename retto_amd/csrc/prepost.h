@@ -36,6 +36,8 @@ size_t db_page_desc_bytes();
 // h_desc (pinned host) / d_desc (device): n * db_page_desc_bytes() scratch for the page table.
 void db_postprocess_batch(hipStream_t st, int n, const DbPageIn* in, const DbParams& p, void* const* workspaces,
                           int max_boxes, DbBox* const* boxes_out, int* const* count_out, void* h_desc, void* d_desc);
+// boxes [n][max_boxes] + counts [n][2] (both contiguous over the pages) -> packed list in page order
+void pack_boxes(hipStream_t st, int n, const DbBox* boxes, const int* counts, int max_boxes, DbBox* packed);
 
 // ---- crops -------------------------------------------------------------------------
 struct CropDesc {

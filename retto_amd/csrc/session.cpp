@@ -385,6 +385,8 @@ rt_results* rt_session::run_pages(const uint8_t* const* rgb, const int* hs, cons
   if (n_pages == 0) return res.release();
   std::vector<PageState> pg((size_t)n_pages);
   const int mb = max_boxes_of(cfg);
+  pp::DbBox *d_boxes_all = nullptr, *d_boxes_packed = nullptr;
+  int* d_counts_all = nullptr;
 
   // ---- a2 + a3: size limits, det resize, normalise ---------------------------------
   std::vector<std::pair<int, int>> det_hw;
@@ -448,9 +450,13 @@ rt_results* rt_session::run_pages(const uint8_t* const* rgb, const int* hs, cons
     } else {
       ProfOuter po(&prof, st, "net/det"); map = det->run_u8(c, dd, cfg.det_scale, cfg.det_mean, cfg.det_std, L0);
     }
-    // keep the maps beyond the scratch rewind
-    float* keep = arena.alloc<float>((size_t)L0.total);
-    RT_HIP_CHECK(hipMemcpyAsync(keep, map, (size_t)L0.total * 4, hipMemcpyDeviceToDevice, st));
+    // keep the maps beyond the next group's scratch rewind; the last group's map is consumed by the DB post-processing
+    // (same stream) before the classifier reuses the scratch arena, so it stays where the network left it
+    float* keep = map;
+    if (g1 < n_pages) {
+      keep = arena.alloc<float>((size_t)L0.total);
+      RT_HIP_CHECK(hipMemcpyAsync(keep, map, (size_t)L0.total * 4, hipMemcpyDeviceToDevice, st));
+    }
     for (int i = g0; i < g1; i++) pg[i].map = keep + L0.h[i - g0].off;
     int nb = pp::sum_blocks(L0.total);
     double* parts = arena.alloc<double>(nb);
@@ -466,6 +472,10 @@ rt_results* rt_session::run_pages(const uint8_t* const* rgb, const int* hs, cons
     std::vector<void*> wsp((size_t)n_pages);
     std::vector<pp::DbBox*> bo((size_t)n_pages);
     std::vector<int*> co((size_t)n_pages);
+    // box lists and counts of all pages are contiguous: one pack launch + two copies bring them to the host
+    d_boxes_all = arena.alloc<pp::DbBox>((size_t)mb * std::max(n_pages, 1));
+    d_counts_all = arena.alloc<int>((size_t)2 * std::max(n_pages, 1));
+    d_boxes_packed = arena.alloc<pp::DbBox>((size_t)mb * std::max(n_pages, 1));
     for (int i = 0; i < n_pages; i++) {
       PageState& p = pg[i];
       const float* pred = p.map;
@@ -476,8 +486,8 @@ rt_results* rt_session::run_pages(const uint8_t* const* rgb, const int* hs, cons
           pred = d;
         } else pred = det_map_override[i];
       }
-      p.d_boxes = arena.alloc<pp::DbBox>(mb);
-      p.d_count = arena.alloc<int>(2);
+      p.d_boxes = d_boxes_all + (size_t)i * mb;
+      p.d_count = d_counts_all + 2 * i;
       in[i] = pp::DbPageIn{pred, p.det_h, p.det_w, p.after_h, p.after_w};
       wsp[i] = dbws.alloc_bytes(pp::db_workspace_bytes(p.det_h, p.det_w, mb));
       bo[i] = p.d_boxes; co[i] = p.d_count;
@@ -486,25 +496,26 @@ rt_results* rt_session::run_pages(const uint8_t* const* rgb, const int* hs, cons
     void* dd = arena.alloc_bytes((size_t)n_pages * pp::db_page_desc_bytes());
     ProfScope ps(&prof, st, "db_postprocess");
     pp::db_postprocess_batch(st, n_pages, in.data(), db_params(cfg), wsp.data(), mb, bo.data(), co.data(), hd, dd);
+    pp::pack_boxes(st, n_pages, d_boxes_all, d_counts_all, mb, d_boxes_packed);
   }
   tick.lap("dbpost enqueue");
   // metadata round trip #1: box lists (a few KB per page); pixels and tensors stay on the device
-  int* h_counts = pinned.alloc<int>((size_t)2 * n_pages);
-  for (int i = 0; i < n_pages; i++)
-    RT_HIP_CHECK(hipMemcpyAsync(h_counts + 2 * i, pg[i].d_count, 8, hipMemcpyDeviceToHost, st));
+  int* h_counts = pinned.alloc<int>((size_t)2 * std::max(n_pages, 1));
+  if (n_pages > 0) RT_HIP_CHECK(hipMemcpyAsync(h_counts, d_counts_all, (size_t)2 * n_pages * sizeof(int), hipMemcpyDeviceToHost, st));
   sync(); check_flags();
   int total_lines = 0;
   for (int i = 0; i < n_pages; i++) {
     if (h_counts[2 * i + 1]) throw RtError(RT_ERR_CAPACITY, "DB post-processing work list overflow (raise max_boxes_per_page)");
-    pg[i].n_boxes = h_counts[2 * i];
+    pg[i].n_boxes = std::min(std::max(h_counts[2 * i], 0), mb);
     pg[i].first_line = total_lines;
     total_lines += pg[i].n_boxes;
-    pg[i].boxes.resize((size_t)pg[i].n_boxes);
-    if (pg[i].n_boxes)
-      RT_HIP_CHECK(hipMemcpyAsync(pg[i].boxes.data(), pg[i].d_boxes, (size_t)pg[i].n_boxes * sizeof(pp::DbBox),
-                                  hipMemcpyDeviceToHost, st));
   }
-  sync();
+  if (total_lines > 0) {
+    pp::DbBox* h_boxes = pinned.alloc<pp::DbBox>((size_t)total_lines);
+    RT_HIP_CHECK(hipMemcpyAsync(h_boxes, d_boxes_packed, (size_t)total_lines * sizeof(pp::DbBox), hipMemcpyDeviceToHost, st));
+    sync();
+    for (int i = 0; i < n_pages; i++) pg[i].boxes.assign(h_boxes + pg[i].first_line, h_boxes + pg[i].first_line + pg[i].n_boxes);
+  }
   for (size_t g = 0; g < sum_parts.size(); g++) {
     std::vector<double> hp((size_t)sum_counts[g]);
     RT_HIP_CHECK(hipMemcpy(hp.data(), sum_parts[g], hp.size() * 8, hipMemcpyDeviceToHost));
@@ -533,9 +544,13 @@ rt_results* rt_session::run_pages(const uint8_t* const* rgb, const int* hs, cons
     plan_crops(plan, pg[i].img, pg[i].after_h, pg[i].after_w, b.data(), pg[i].n_boxes);
   }
   const int NL = total_lines;
-  std::vector<int> h_label(std::max(NL, 1)), h_ntok(std::max(NL, 1));
-  std::vector<float> h_cscore(std::max(NL, 1)), h_rscore(std::max(NL, 1));
-  std::vector<int> h_tokens; std::vector<long long> tok_off((size_t)NL + 1, 0);
+  // per-line results come back in two copies into pinned memory: {label, cls score, token count, rec score} and the tokens
+  const int NLp = std::max(NL, 1);
+  int* h_meta = pinned.alloc<int>((size_t)4 * NLp);
+  memset(h_meta, 0, (size_t)4 * NLp * sizeof(int));
+  const int* h_label = h_meta; const float* h_cscore = reinterpret_cast<const float*>(h_meta + NLp);
+  const int* h_ntok = h_meta + 2 * NLp; const float* h_rscore = reinterpret_cast<const float*>(h_meta + 3 * NLp);
+  const int* h_tokens = nullptr; std::vector<long long> tok_off((size_t)NL + 1, 0);
   if (NL > 0) {
     uint8_t* pool = arena.alloc<uint8_t>(plan.pool_bytes + 64);
     pp::CropDesc* d_desc = arena.alloc<pp::CropDesc>(NL);
@@ -556,7 +571,9 @@ rt_results* rt_session::run_pages(const uint8_t* const* rgb, const int* hs, cons
     // (cls_processor.rs:127-172: batches of 6 sorted by aspect; the classifier is
     //  per-crop independent, so batch composition does not change any value)
     const int ch = cfg.cls_image_shape[1], cw = cfg.cls_image_shape[2];
-    int* d_label = arena.alloc<int>(NL); float* d_cscore = arena.alloc<float>(NL);
+    int* d_meta = arena.alloc<int>((size_t)4 * NLp);
+    int* d_label = d_meta; float* d_cscore = reinterpret_cast<float*>(d_meta + NLp);
+    int* d_ntok = d_meta + 2 * NLp; float* d_rscore = reinterpret_cast<float*>(d_meta + 3 * NLp);
     {
       const int CG = 2048;
       for (int c0 = 0; c0 < NL; c0 += CG) {
@@ -628,7 +645,6 @@ rt_results* rt_session::run_pages(const uint8_t* const* rgb, const int* hs, cons
     int* d_idx = arena.alloc<int>(std::max<long long>(total_tok, 1));
     float* d_prob = arena.alloc<float>(std::max<long long>(total_tok, 1));
     int* d_tok = arena.alloc<int>(std::max<long long>(total_tok, 1));
-    int* d_ntok = arena.alloc<int>(NL); float* d_rscore = arena.alloc<float>(NL);
     static const long long REC_GROUP_PX = getenv("RT_REC_GROUP_PX") ? atoll(getenv("RT_REC_GROUP_PX")) : (long long)24000000;  // measured sweet spot (profiles/README.md)
     for (int l0 = 0; l0 < NL;) {
       int l1 = l0; long long px = 0;
@@ -662,12 +678,10 @@ rt_results* rt_session::run_pages(const uint8_t* const* rgb, const int* hs, cons
     }
     tick.lap("rec enqueue");
     // metadata round trip #2: labels, scores, token ids
-    h_tokens.resize((size_t)std::max<long long>(total_tok, 1));
-    RT_HIP_CHECK(hipMemcpyAsync(h_label.data(), d_label, (size_t)NL * 4, hipMemcpyDeviceToHost, st));
-    RT_HIP_CHECK(hipMemcpyAsync(h_cscore.data(), d_cscore, (size_t)NL * 4, hipMemcpyDeviceToHost, st));
-    RT_HIP_CHECK(hipMemcpyAsync(h_ntok.data(), d_ntok, (size_t)NL * 4, hipMemcpyDeviceToHost, st));
-    RT_HIP_CHECK(hipMemcpyAsync(h_rscore.data(), d_rscore, (size_t)NL * 4, hipMemcpyDeviceToHost, st));
-    if (total_tok > 0) RT_HIP_CHECK(hipMemcpyAsync(h_tokens.data(), d_tok, (size_t)total_tok * 4, hipMemcpyDeviceToHost, st));
+    int* h_tok = pinned.alloc<int>((size_t)std::max<long long>(total_tok, 1));
+    h_tokens = h_tok;
+    RT_HIP_CHECK(hipMemcpyAsync(h_meta, d_meta, (size_t)4 * NLp * sizeof(int), hipMemcpyDeviceToHost, st));
+    if (total_tok > 0) RT_HIP_CHECK(hipMemcpyAsync(h_tok, d_tok, (size_t)total_tok * 4, hipMemcpyDeviceToHost, st));
     sync(); check_flags();
   }
 
@@ -688,7 +702,7 @@ rt_results* rt_session::run_pages(const uint8_t* const* rgb, const int* hs, cons
       int li = p.first_line + k;
       P.cls_labels[k] = LABELS[h_label[li] ? 1 : 0]; P.cls_scores[k] = h_cscore[li];
       P.rec_scores[k] = h_rscore[li];
-      P.tokens[k].assign(h_tokens.begin() + tok_off[li], h_tokens.begin() + tok_off[li] + h_ntok[li]);
+      P.tokens[k].assign(h_tokens + tok_off[li], h_tokens + tok_off[li] + h_ntok[li]);
       std::string& t = P.text[k];
       t.reserve(P.tokens[k].size() * 3);  // CJK dictionary entries are 3 UTF-8 bytes
       for (int id : P.tokens[k]) t += dict[(size_t)id];
