@@ -244,7 +244,7 @@ static float* run_lc(RunCtx& c, const LcBlock& b, const float* x, const Level& L
                        !no_se_fusion;
   float* pool = nullptr; int chunks = 0, strip_R = 0, strips_pb = 32;
   if (fuse_se) {
-    nn::dwconv_pool_layout(b.dw.k, b.sh, b.dw.Cp, Lout.maxH, Lout.maxW, &chunks, &strip_R, &strips_pb);
+    nn::dwconv_pool_layout(b.dw.k, b.sh, b.sw, b.dw.Cp, Lout.maxH, Lout.maxW, &chunks, &strip_R, &strips_pb);
     pool = c.arena->alloc<float>((size_t)Lout.n() * chunks * b.dw.Cp);
   }
   { ProfScope ps(c.prof, c.st, b.dw.k == 3 ? "dwconv3" : "dwconv5", shape_str(Lin.total, Lout.total, b.dw.Cp, b.sh * 10 + b.sw));

@@ -29,7 +29,7 @@ void dwconv(hipStream_t st, int K, int sh, int sw, const float* x, const ImgGeom
             float lab_a, float lab_c, float* y, float* pool = nullptr);  // Cp = channel pitch (chan_pitch), C = real channels
 // Fused squeeze-excite pooling: with `pool` (n_img * chunks * Cp floats, dwconv_pool_layout) the depthwise
 // kernel also writes per-block channel sums of its output; se_fc_from_dw turns them into the scales.
-void dwconv_pool_layout(int K, int sh, int Cp, int maxHo, int maxWo, int* chunks, int* strip_R, int* strips_per_block);
+void dwconv_pool_layout(int K, int sh, int sw, int Cp, int maxHo, int maxWo, int* chunks, int* strip_R, int* strips_per_block);
 void se_fc_from_dw(hipStream_t st, const float* partial, const ImgGeom* geom, int n_img, int chunks, int strip_R,
                    int strips_per_block, int C, int Cp, const float* w1, const float* b1, const float* w2, const float* b2,
                    int Cr, float slope, int residual, float* scale);

@@ -1969,7 +1969,7 @@ __global__ __launch_bounds__(256, 4) void k_dwconv_rows(const float* __restrict_
 
 void set_dw_xcd(int v) { RT_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_dw_xcd_dev), &v, sizeof(int))); }
 int g_dw_wide_slab_min = 192;      // channel pitch from which the 5x5 kernels use wide slabs (1 << 30: never, A/B)
-static int dw_strips_per_block(int K, int Cp);
+static int dw_lanes_per_pixel(int K, int sh, int sw, int R, int Cp, bool pool);
 int g_dw_wide3_min = 128;          // same for the 3x3 kernels (64-channel slabs)
 int g_dw_wide_lp = 16;             // 16 = 64-channel slabs, 32 = 128-channel slabs
 int g_dw_variant = 0;
@@ -1991,7 +1991,7 @@ void dwconv(hipStream_t st, int K, int sh, int sw, const float* x, const ImgGeom
     long long strips = (long long)((maxWo + 3) / 4) * ((maxHo + R - 1) / R);
     // 64- / 128-channel slabs (256 / 512 contiguous bytes per pixel and load) for wide tensors: the 5x5 kernel on
     // 256 channels goes from 2.9 to 4.1 TB/s with 64-channel slabs; 32-channel slabs otherwise
-    const int lp = dw_strips_per_block(K, Cp) == 32 ? 8 : 256 / dw_strips_per_block(K, Cp);
+    const int lp = dw_lanes_per_pixel(K, sh, sw, R, Cp, pool != nullptr);
     if (lp != 8) {
       const int spb = 256 / lp;
       dim3 gridw((unsigned)((strips + spb - 1) / spb), n_img, (Cp + lp * 4 - 1) / (lp * 4));
@@ -2004,11 +2004,13 @@ void dwconv(hipStream_t st, int K, int sh, int sw, const float* x, const ImgGeom
       if (K == 5 && sh == 1 && sw == 1 && R == 4) { RT_DWW_L(5, 4, 1, 1); return; }
       if (K == 5 && sh == 1 && sw == 1 && R == 3) { RT_DWW_L(5, 3, 1, 1); return; }
       if (K == 5 && sh == 2 && sw == 1 && R == 2) { RT_DWW_L(5, 2, 2, 1); return; }
+      if (K == 5 && sh == 2 && sw == 1 && R == 3) { RT_DWW_L(5, 3, 2, 1); return; }
       if (K == 5 && sh == 2 && sw == 2 && R == 2) { RT_DWW_L(5, 2, 2, 2); return; }
       if (K == 3 && sh == 1 && sw == 1 && R == 4 && !pool) { RT_DWW(3, 4, 1, 1, 16); return; }
       if (K == 3 && sh == 1 && sw == 2 && R == 4 && !pool) { RT_DWW(3, 4, 1, 2, 16); return; }
 #undef RT_DWW_L
 #undef RT_DWW
+      throw RtError(8, "dwconv: no wide-slab instantiation for a shape dw_lanes_per_pixel() lists");
     }
     dim3 grid((unsigned)((strips + 31) / 32), n_img, (Cp + 31) / 32);
 #define RT_DWR(KK, RR, SH_, SW_)                                                                                              \
@@ -2314,13 +2316,22 @@ void se_scale_projected(hipStream_t st, const float* x_in, const ImgGeom* geom, 
   hipLaunchKernelGGL(k_se_fc, dim3(n_img), dim3(256), (Cp + Cr + 4 + Cin_p + 4) * sizeof(float), st, partial, geom, chunks, C, Cp,
                      w1, b1, w2, b2, Cr, slope, residual, scale, 0, 32, Wlin, Cin, Cin_p);
 }
-static int dw_strips_per_block(int K, int Cp) {  // 32-channel slabs (32 strips per block) unless the tensor is wide
-  if (K == 5 && Cp >= g_dw_wide_slab_min) return 256 / g_dw_wide_lp;
-  if (K == 3 && Cp >= g_dw_wide3_min) return 16;
-  return 32;
+// Lanes side by side on a pixel in k_dwconv_rows for this layer: 16 / 32 (64- / 128-channel slabs) where the tensor is
+// wide AND a wide instantiation exists for the shape, else 8 (32-channel slabs).  The one place that decides it: the
+// launch (dwconv) and the layout of the fused pooling partials (dwconv_pool_layout -> k_se_fc) must agree.
+static int dw_lanes_per_pixel(int K, int sh, int sw, int R, int Cp, bool pool) {
+  int lp = 8;
+  if (K == 5 && Cp >= g_dw_wide_slab_min) lp = g_dw_wide_lp;
+  else if (K == 3 && Cp >= g_dw_wide3_min) lp = 16;
+  if (lp == 8) return 8;
+  if (K == 5 && sh == 1 && sw == 1 && (R == 4 || R == 3)) return lp;
+  if (K == 5 && sh == 2 && sw == 1 && (R == 2 || R == 3)) return lp;
+  if (K == 5 && sh == 2 && sw == 2 && R == 2) return lp;
+  if (K == 3 && sh == 1 && (sw == 1 || sw == 2) && R == 4 && !pool) return 16;
+  return 8;
 }
-void dwconv_pool_layout(int K, int sh, int Cp, int maxHo, int maxWo, int* chunks, int* strip_R, int* strips_per_block) {
-  const int R = dw_strip_rows(sh, maxHo), spb = dw_strips_per_block(K, Cp);
+void dwconv_pool_layout(int K, int sh, int sw, int Cp, int maxHo, int maxWo, int* chunks, int* strip_R, int* strips_per_block) {
+  const int R = dw_strip_rows(sh, maxHo), spb = 256 / dw_lanes_per_pixel(K, sh, sw, R, Cp, true);
   *strip_R = R; *strips_per_block = spb;
   *chunks = (int)(((long long)((maxWo + 3) / 4) * ((maxHo + R - 1) / R) + spb - 1) / spb);
 }

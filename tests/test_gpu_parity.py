@@ -21,7 +21,8 @@ def _rand_page(h, w, seed):
 
 
 # ---------------------------------------------------------------- a4 / a9 / a11 networks
-@pytest.mark.parametrize("n,h,w", [(1, 64, 96), (2, 160, 128), (1, 320, 320)])
+# (3 x 960^2: the squeeze-excite levels reach the sizes where the fused pooling / scaled-GEMM path is taken)
+@pytest.mark.parametrize("n,h,w", [(1, 64, 96), (2, 160, 128), (1, 320, 320), (3, 960, 960)])
 def test_det_net(hip_session, oracle_session, n, h, w):
     x = np.random.default_rng(h + w).uniform(-1, 1, (n, 3, h, w)).astype(np.float32)
     got = hip_session.worker.det(x)
@@ -41,7 +42,9 @@ def test_cls_net(hip_session, oracle_session):
     assert np.abs(got - ref).max() <= 1e-4
 
 
-@pytest.mark.parametrize("n,w", [(1, 320), (3, 321), (2, 487), (1, 960)])
+# (12 / 24 x 640: 11.5 k / 23 k pixels at the squeeze-excite levels -- the fused pooling + scaled 128 x 128 / 128 x 240
+#  GEMM tiles, which smaller batches never reach)
+@pytest.mark.parametrize("n,w", [(1, 320), (3, 321), (2, 487), (1, 960), (12, 640), (24, 640)])
 def test_rec_net(hip_session, oracle_session, n, w):
     x = np.random.default_rng(w).uniform(-1, 1, (n, 3, 48, w)).astype(np.float32)
     x[:, :, :, w // 2:] = 0.0  # zero padding like resize_norm_image
@@ -419,3 +422,60 @@ def test_non_default_det_config():
         assert np.array_equal(gb, rb) and np.array_equal(gs.view(np.uint32), rs.view(np.uint32))
     finally:
         s.close()
+
+
+def test_c3_full_size_properties(hip_session):
+    """BASELINE config C3 at full size (32 pages of 960 x 960, 32 planted lines each, the bench workload) through
+    size-independent properties: (1) batch / lane composition does not change any page's result -- the whole batch on
+    3 lanes equals the same pages in shuffled order and each page run alone, bit for bit (boxes, labels, token
+    ids, scores); (2) the det checksum of the batch is the sum of the per-page checksums to fp32 rounding; (3) the planted lines come
+    back: 32 boxes per page, each inside its planted rectangle grown by the unclip offset."""
+    n = 32
+    pages, maps, rects = [], [], []
+    for i in range(n):
+        page, rc = workload.planted_page(960, 960, 32, seed=i)
+        pages.append(page); rects.append(rc)
+        maps.append(workload.planted_map(960, 960, 960, 960, rc))
+    full = hip_session.run_batch(pages, det_map_override=maps)
+    cs_full = hip_session.last_det_checksum
+
+    def same(a, b):
+        assert len(a.det_result) == len(b.det_result) == 32
+        assert np.array_equal(np.stack([d.boxes.as_array() for d in a.det_result]), np.stack([d.boxes.as_array() for d in b.det_result]))
+        assert [d.score for d in a.det_result] == [d.score for d in b.det_result]
+        assert [(c.label.label, c.label.score) for c in a.cls_result] == [(c.label.label, c.label.score) for c in b.cls_result]
+        for x, y in zip(a.rec_result, b.rec_result):
+            assert np.array_equal(x.tokens, y.tokens) and x.text == y.text
+            assert x.score == y.score or (np.isnan(x.score) and np.isnan(y.score))
+
+    # the page inside the 1024-line batch (large fused kernels) against the oracle fed by the HIP worker in batches of 6
+    # lines (small, unfused kernels): tokens bit-exact, scores to fp32 tolerance
+    from oracle.pipeline import OracleSession
+    from retto_amd import synth
+    o = OracleSession(*synth.synth_models(0))
+    o.det_worker, o.cls_worker, o.rec_worker = hip_session.worker.det, hip_session.worker.cls, hip_session.worker.rec
+    for j in (0, 17):
+        ref = o.run(pages[j], det_map_override=maps[j])
+        _assert_page_equal(full[j], ref)
+        np.testing.assert_allclose([g.score for g in full[j].rec_result], ref.rec_scores, rtol=1e-4, equal_nan=True)
+        np.testing.assert_allclose([c.label.score for c in full[j].cls_result], ref.cls_scores, atol=1e-5)
+
+    perm = np.random.default_rng(0).permutation(n)
+    shuffled = hip_session.run_batch([pages[j] for j in perm], det_map_override=[maps[j] for j in perm])
+    for k, j in enumerate(perm):
+        same(shuffled[k], full[j])
+    cs_sum = 0.0
+    for j in (0, 7, 31):
+        alone = hip_session.run_batch([pages[j]], det_map_override=[maps[j]])[0]
+        same(alone, full[j])
+    for j in range(n):
+        hip_session.run_batch([pages[j]], det_map_override=[maps[j]])
+        cs_sum += hip_session.last_det_checksum
+    # (the det maps of a page alone and inside the batch come from different kernel shapes: fp32 rounding, not bit-equal)
+    assert abs(cs_sum - cs_full) <= 1e-6 * abs(cs_full)
+    for r, rc in zip(full, rects):
+        got = np.stack([d.boxes.as_array() for d in r.det_result]).reshape(-1, 4, 2)
+        for x0, y0, x1, y1 in rc:
+            inside = [(b[:, 0].min() >= x0 - 12 and b[:, 0].max() <= x1 + 12 and b[:, 1].min() >= y0 - 12 and b[:, 1].max() <= y1 + 12)
+                      for b in got]
+            assert sum(inside) == 1, (x0, y0, x1, y1)
