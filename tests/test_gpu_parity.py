@@ -479,3 +479,27 @@ def test_c3_full_size_properties(hip_session):
             inside = [(b[:, 0].min() >= x0 - 12 and b[:, 0].max() <= x1 + 12 and b[:, 1].min() >= y0 - 12 and b[:, 1].max() <= y1 + 12)
                       for b in got]
             assert sum(inside) == 1, (x0, y0, x1, y1)
+
+
+def test_c4_mixed_sizes_full_size_properties(hip_session, oracle_session):
+    """BASELINE config C4 at its real page sizes (640^2 ... 2480 x 3508, the largest taking the session size limit a2),
+    32 planted lines per page, 18 pages in one batch over 3 lanes: every page equals the oracle fed by the HIP worker in
+    the reference's batches of 6 (boxes, labels, token ids bit-exact; scores to fp32 tolerance), and a page run alone
+    gives the same result as inside the batch."""
+    sizes = [(640, 640), (960, 960), (720, 1280), (1080, 1920), (1754, 1240), (3508, 2480)]
+    specs = [(h, w, 32, 300 + 7 * i) for i, (h, w) in enumerate(sizes * 3)]
+    pages, maps = zip(*[_planted_for(h, w, L, s) for h, w, L, s in specs])
+    res = hip_session.run_batch(list(pages), det_map_override=list(maps))
+    _teacher_forced(oracle_session, hip_session)
+    for j in (0, 3, 5, 8, 16, 17):
+        o = oracle_session.run(pages[j], det_map_override=maps[j])
+        assert len(o.det_boxes) == 32
+        _assert_page_equal(res[j], o)
+        np.testing.assert_allclose([g.score for g in res[j].rec_result], o.rec_scores, rtol=1e-4, equal_nan=True)
+        np.testing.assert_allclose([c.label.score for c in res[j].cls_result], o.cls_scores, atol=1e-5)
+    for j in (5, 10):
+        alone = hip_session.run_batch([pages[j]], det_map_override=[maps[j]])[0]
+        assert np.array_equal(np.stack([d.boxes.as_array() for d in alone.det_result]),
+                              np.stack([d.boxes.as_array() for d in res[j].det_result]))
+        assert [(g.text, g.score) for g in alone.rec_result] == [(g.text, g.score) for g in res[j].rec_result]
+        assert [(c.label.label, c.label.score) for c in alone.cls_result] == [(c.label.label, c.label.score) for c in res[j].cls_result]
