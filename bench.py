@@ -304,6 +304,26 @@ def main():
                                   "(oracle/pipeline.py: torch-CPU fp32 nets + C++ pre/post restatement); "
                                   "reference ort-CPU itself is not runnable here" % (k, S, S, a.lines)}
 
+    # ---- self-check outside the timed region (rank 0): a page's result must not depend on what else is in the batch.
+    # Page 0 alone (small launches, other kernel shapes) against page 0 inside the batch -- boxes and token ids equal,
+    # scores to fp32 rounding.  A mismatch is a bug in a size-dependent kernel path; the run fails instead of reporting.
+    def _page0(r):
+        n0 = lib.rt_results_count(r, 0)
+        boxes = np.ctypeslib.as_array(lib.rt_results_boxes(r, 0), (n0, 8)).copy() if n0 else np.zeros((0, 8), np.float32)
+        sc = np.ctypeslib.as_array(lib.rt_results_rec_scores(r, 0), (n0,)).copy() if n0 else np.zeros(0, np.float32)
+        toks = []
+        for k in range(n0):
+            tp = C.POINTER(C.c_int32)()
+            nt = lib.rt_results_rec_tokens(r, 0, k, C.byref(tp))
+            toks.append([tp[t] for t in range(nt)])
+        return boxes, sc, toks
+    r_b = step(); in_batch = _page0(r_b); lib.rt_results_free(r_b)
+    r_a = sess.run_batch_raw(d_pages[:1], hs[:1], ws[:1], retto_amd.RT_MEM_DEVICE, d_maps[:1]); alone = _page0(r_a); lib.rt_results_free(r_a)
+    if not (np.array_equal(in_batch[0], alone[0]) and in_batch[2] == alone[2] and
+            np.allclose(in_batch[1], alone[1], rtol=1e-4, atol=1e-6, equal_nan=True)):
+        raise RuntimeError("bench self-check failed: page 0 differs between the batch and a run of its own")
+    selfcheck = {"batch_invariance_page0": True, "lines": int(len(in_batch[2]))}
+
     out = {
         "metric": "images/sec end-to-end PP-OCRv4 det+rec @960x960",
         "value": round(value, 3), "unit": "images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -319,6 +339,7 @@ def main():
         "roofline": roofline,
         "cpu_baseline": cpu_baseline,
         "networks": networks,
+        "selfcheck": selfcheck,
     }
     sess.close()
     if dist_on:
