@@ -503,3 +503,25 @@ def test_c4_mixed_sizes_full_size_properties(hip_session, oracle_session):
                               np.stack([d.boxes.as_array() for d in res[j].det_result]))
         assert [(g.text, g.score) for g in alone.rec_result] == [(g.text, g.score) for g in res[j].rec_result]
         assert [(c.label.label, c.label.score) for c in alone.cls_result] == [(c.label.label, c.label.score) for c in res[j].cls_result]
+
+
+def test_extreme_line_shapes(hip_session, oracle_session):
+    """Lines at the ends of the aspect range on one page: 76:1 (rec width 48 * 76 = 3648, 456 time steps through the
+    global-attention neck), a 6-pixel-high sliver (upscaled 8x by resize_norm_image), a tall narrow box (h/w >= 1.5: the crop
+    is rotated by 270 degrees, image_helper.rs:246) -- against the oracle fed by the HIP worker."""
+    h, w = 400, 1984
+    page = np.zeros((h, w, 3), np.uint8)
+    rng = np.random.default_rng(3)
+    rects = [(20, 30, 1930, 55), (40, 120, 300, 126), (600, 100, 640, 380), (900, 200, 1500, 240)]
+    for x0, y0, x1, y1 in rects:
+        page[y0:y1, x0:x1] = rng.integers(100, 256, (y1 - y0, x1 - x0, 3), dtype=np.uint8)
+    plan = R.resize_both_plan(h, w)
+    ah, aw = plan[-1] if plan else (h, w)
+    dh, dw = R.resize_either_dims(ah, aw)
+    m = workload.planted_map(dh, dw, h, w, rects, shrink=0.05)
+    res = hip_session.run_batch([page], det_map_override=[m])[0]
+    _teacher_forced(oracle_session, hip_session)
+    o = oracle_session.run(page, det_map_override=m)
+    assert len(o.det_boxes) >= 3
+    _assert_page_equal(res, o)
+    np.testing.assert_allclose([g.score for g in res.rec_result], o.rec_scores, rtol=1e-4, equal_nan=True)
