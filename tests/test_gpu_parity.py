@@ -22,7 +22,7 @@ def _rand_page(h, w, seed):
 
 # ---------------------------------------------------------------- a4 / a9 / a11 networks
 # (3 x 960^2: the squeeze-excite levels reach the sizes where the fused pooling / scaled-GEMM path is taken)
-@pytest.mark.parametrize("n,h,w", [(1, 64, 96), (2, 160, 128), (1, 320, 320), (3, 960, 960)])
+@pytest.mark.parametrize("n,h,w", [(1, 64, 96), (2, 160, 128), (1, 320, 320), (3, 960, 960), (1, 1984, 1408)])
 def test_det_net(hip_session, oracle_session, n, h, w):
     x = np.random.default_rng(h + w).uniform(-1, 1, (n, 3, h, w)).astype(np.float32)
     got = hip_session.worker.det(x)
@@ -44,7 +44,7 @@ def test_cls_net(hip_session, oracle_session):
 
 # (12 / 24 x 640: 11.5 k / 23 k pixels at the squeeze-excite levels -- the fused pooling + scaled 128 x 128 / 128 x 240
 #  GEMM tiles, which smaller batches never reach)
-@pytest.mark.parametrize("n,w", [(1, 320), (3, 321), (2, 487), (1, 960), (12, 640), (24, 640)])
+@pytest.mark.parametrize("n,w", [(1, 320), (3, 321), (2, 487), (1, 960), (12, 640), (24, 640), (1, 3648)])
 def test_rec_net(hip_session, oracle_session, n, w):
     x = np.random.default_rng(w).uniform(-1, 1, (n, 3, 48, w)).astype(np.float32)
     x[:, :, :, w // 2:] = 0.0  # zero padding like resize_norm_image
