@@ -33,12 +33,13 @@ def test_det_net(hip_session, oracle_session, n, h, w):
     assert err <= DET_ATOL, f"det map max abs err {err}"
 
 
-def test_cls_net(hip_session, oracle_session):
-    x = np.random.default_rng(5).uniform(-1, 1, (7, 3, 48, 192)).astype(np.float32)
+@pytest.mark.parametrize("n", [7, 600])  # 600 crops: the GEMM / depthwise shapes of a full page batch
+def test_cls_net(hip_session, oracle_session, n):
+    x = np.random.default_rng(5).uniform(-1, 1, (n, 3, 48, 192)).astype(np.float32)
     x[3] *= 0.1
     got = hip_session.worker.cls(x)
     ref = N.cls_forward(oracle_session.wc, torch.from_numpy(x)).numpy()
-    assert got.shape == (7, 2)
+    assert got.shape == (n, 2)
     assert np.abs(got - ref).max() <= 1e-4
 
 
