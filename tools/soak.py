@@ -15,7 +15,7 @@ for i in range(24):
     p, r = workload.planted_page(h, w, 4 + i % 9, seed=i)
     dh, dw = s.det_preprocess(p).shape[2:]
     pages.append(p); maps.append(workload.planted_map(dh, dw, h, w, r))
-steps = int(sys.argv[1]) if len(sys.argv) > 1 else 150
+steps = int(sys.argv[1]) if len(sys.argv) > 1 else 400
 free0 = None
 t0 = time.time()
 for it in range(steps):
@@ -25,7 +25,7 @@ for it in range(steps):
     assert all(len(r.det_result) > 0 for r in res)
     if it % 25 == 24:
         free, total = torch.cuda.mem_get_info()
-        if it >= 49 and free0 is None:
+        if it >= 199 and free0 is None:  # (the arenas reach their high-water mark once the largest batch combinations have been seen)
             free0 = free
         print("step %4d  free %.2f GB  (%.1f s)" % (it + 1, free / 2**30, time.time() - t0), flush=True)
 free, _ = torch.cuda.mem_get_info()
