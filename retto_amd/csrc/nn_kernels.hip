@@ -73,6 +73,8 @@ __device__ __forceinline__ void mma_chunk(const float* __restrict__ xs0, const f
     f32x4 a1 = *reinterpret_cast<const f32x4*>(xs1 + g * 16 + 4 * q);
 #pragma unroll
     for (int nt = 0; nt < NT; nt++) {
+      // (kept as a run-time test per column tile: the branch-free form -- what the wide kernel does -- measured 10 %
+      //  slower here, hipcc then hoists every weight fragment read ahead of the MFMAs)
       if (nt < nt_valid) {
         f32x4 b = *reinterpret_cast<const f32x4*>(ws + (nt * 16 + r) * LROW + g * 16 + 4 * q);
 #pragma unroll
@@ -398,7 +400,12 @@ __global__ __launch_bounds__(64 * WM * WN, (NT > 8 ? 2 : 1)) void k_gemm_wide(co
   fetch(0);
   stash(0);
   __syncthreads();
-  for (int kc = 0; kc < nkc; kc++) {
+  // One K slab.  NG = 16-deep groups multiplied (compile time): the slabs run as a branch-free loop over the full ones
+  // plus, when K leaves a tail of <= 16 (K = 240), one last slab with a single group.  A run-time test between the two
+  // MFMA groups (the earlier form) splits the scheduling region: 5-9 % slower on every shape.  (Compiling the tail out
+  // for K % 32 == 0 was tried: hipcc then spills 22 instead of 8 VGPRs on the 256-row tile and loses the gain.)
+  auto slab = [&](int kc, auto ngtag) {
+    constexpr int NG = decltype(ngtag)::value;
     if (DBG == 0 && kc + 1 < nkc) fetch(kc + 1);
     const float* xs = lds + (DBUF ? (kc & 1) * STAGE : 0);
     const float* ws = xs + BM * LROW;
@@ -412,8 +419,7 @@ __global__ __launch_bounds__(64 * WM * WN, (NT > 8 ? 2 : 1)) void k_gemm_wide(co
       // fat waves (few rows x all columns): the weight fragments are streamed one column tile at a time so that
       // the accumulators (MT x NT x 4 registers) leave room for two workgroups per CU
 #pragma unroll
-      for (int g = 0; g < KC / 16; g++) {
-        if (g > 0 && kc * KC + g * 16 >= K) break;
+      for (int g = 0; g < NG; g++) {
         f32x4 a[MT];
 #pragma unroll
         for (int mt = 0; mt < MT; mt++) a[mt] = *reinterpret_cast<const f32x4*>(xr + mt * 16 * LROW + g * 16 + 4 * q);
@@ -428,17 +434,16 @@ __global__ __launch_bounds__(64 * WM * WN, (NT > 8 ? 2 : 1)) void k_gemm_wide(co
         }
       }
     } else {
-    f32x4 a[KC / 16][MT], b[KC / 16][NT];
+    f32x4 a[NG][MT], b[NG][NT];
 #pragma unroll
-    for (int g = 0; g < KC / 16; g++) {
+    for (int g = 0; g < NG; g++) {
 #pragma unroll
       for (int mt = 0; mt < MT; mt++) a[g][mt] = *reinterpret_cast<const f32x4*>(xr + mt * 16 * LROW + g * 16 + 4 * q);
 #pragma unroll
       for (int nt = 0; nt < NT; nt++) b[g][nt] = *reinterpret_cast<const f32x4*>(wr + nt * 16 * LROW + g * 16 + 4 * q);
     }
 #pragma unroll
-    for (int g = 0; g < KC / 16; g++) {
-      if (g > 0 && kc * KC + g * 16 >= K) break;  // K tail (e.g. K = 240): the second 16-deep group of the last slab is all zero
+    for (int g = 0; g < NG; g++) {
 #pragma unroll
       for (int s = 0; s < 4; s++)
 #pragma unroll
@@ -456,6 +461,12 @@ __global__ __launch_bounds__(64 * WM * WN, (NT > 8 ? 2 : 1)) void k_gemm_wide(co
       if (DBG == 0 && kc + 1 < nkc) { stash(kc + 1); __syncthreads(); }
       if (DBG == 1) __syncthreads();
     }
+  };
+  {
+    const int tail = K - (nkc - 1) * KC;               // depth of the last slab: 1..32
+    const int n2 = tail > 16 ? nkc : nkc - 1;          // slabs with both 16-deep groups
+    for (int kc = 0; kc < n2; kc++) slab(kc, IntTag<KC / 16>{});
+    if (n2 < nkc) slab(nkc - 1, IntTag<1>{});
   }
   if (EPIM) {
     // Softmax statistics of this column tile, per row: (max, first column of the max, sum exp(v - max)).
