@@ -217,9 +217,31 @@ RT_API void rt_buffer_free(void* p);
 RT_API int rt_decode_image(const void* data, size_t len, uint8_t** rgb, int* h, int* w, char* err, size_t err_cap);
 RT_API int rt_run_encoded_batch(rt_session* s, const void* const* files, const size_t* lens, int n_pages,
                                 rt_stage_callback cb, void* user, rt_results** out);
+/* RecCharacter::new (retto-core/src/processor/rec_processor.rs:29-46) on the bytes of ppocr_keys_v1.txt, with
+ * Rust's semantics: strict String::from_utf8 (RT_ERR_UTF8 on overlong forms, surrogates, > U+10FFFF), str::lines,
+ * str::trim over the Unicode White_Space set (a U+3000-only line becomes ""), "blank" inserted at 0 and " "
+ * appended.  *out = the entries joined by '\n' (library-owned until rt_buffer_free), *n_entries their count.
+ * Host-only; rt_create runs the same code on rt_config.dict. */
+RT_API int rt_parse_dictionary(const void* data, size_t len, char** out, size_t* out_len, int* n_entries, char* err, size_t err_cap);
+/* The JSON text of one f32 as serde_json (ryu) writes it -- shortest round-trip digits, "1.0" / "0.9" /
+ * "1.234e-7", null for non-finite -- which rt_results_json uses for every number.  Returns the length. */
+RT_API int rt_format_f32(float v, char* buf, size_t cap);
 /* The tensor list (RTWB names and shapes, forward order, -1 = read from the file) the importer
  * fills for model `which`, one "name d0 d1 ..." line per tensor; returns the length needed. */
 RT_API size_t rt_model_manifest(int which, char* buf, size_t cap);
+
+/* ---- diagnostics for tools/ (kernel A/B switches and the GEMM micro-benchmark; no reference
+ * counterpart, not needed by a drop-in host) ------------------------------------------------
+ * rt_debug_set_variants: gemm_variant 0 = production dispatch, 8 / 10 / 15 / 20 force the
+ * 128x128 / 128x240 / 256x240 wide tiles / the streaming kernel; dw_variant 0 = production,
+ * 4 = 2-row depthwise strips; flags bits: 1 fused thin blocks OFF, 2 thin blocks on the
+ * 128-pixel tile, 3 plain (not XCD-aware) depthwise block order, 4 32-channel depthwise slabs
+ * only, 5 128- instead of 64-channel wide slabs, 6 CTC head on the 128x128 wide tile.
+ * Process-wide; every setting computes bit-identical results. */
+RT_API void rt_debug_set_variants(int gemm_variant, int dw_variant, int flags);
+/* times nn::gemm (M x K x N, random data) over `iters` launches on the session's stream and
+ * returns the average ms and the max |diff| against variant 0 */
+RT_API int rt_bench_gemm(rt_session* s, long long M, int K, int N, int variant, int iters, float* ms_out, float* maxdiff_out);
 
 #ifdef __cplusplus
 }

@@ -39,6 +39,31 @@ class OracleResult:
     det_map: np.ndarray = None
 
 
+# char::is_whitespace (Unicode White_Space), the set str::trim strips
+_RUST_WS = frozenset([0x09, 0x0A, 0x0B, 0x0C, 0x0D, 0x20, 0x85, 0xA0, 0x1680, 0x2028, 0x2029, 0x202F, 0x205F, 0x3000]
+                     + list(range(0x2000, 0x200B)))
+
+
+def load_dictionary(dict_bytes: bytes) -> List[str]:
+    """RecCharacter::new (rec_processor.rs:29-46): String::from_utf8 (strict: Python's utf-8 codec rejects the
+    same overlong / surrogate / > U+10FFFF forms), str::lines (split after "\\n", drop it and one "\\r" before it,
+    no empty last line), str::trim (Unicode White_Space -- NOT Python's str.strip, which also strips U+001C-001F),
+    "blank" first, " " last."""
+    txt = dict_bytes.decode("utf-8")  # raises UnicodeDecodeError where Rust returns Utf8Error
+    lines = txt.split("\n")
+    if lines and lines[-1] == "":
+        lines.pop()
+    out = ["blank"]
+    for ln in lines:
+        a, b = 0, len(ln)
+        while a < b and ord(ln[a]) in _RUST_WS:
+            a += 1
+        while b > a and ord(ln[b - 1]) in _RUST_WS:
+            b -= 1
+        out.append(ln[a:b])
+    return out + [" "]
+
+
 class OracleSession:
     def __init__(self, det_blob: bytes, cls_blob: bytes, rec_blob: bytes, dict_bytes: bytes,
                  max_side_len=2000, min_side_len=30):
@@ -46,8 +71,7 @@ class OracleSession:
         self.wc = nets.read_blob(cls_blob)
         self.wr = nets.read_blob(rec_blob)
         # RecCharacter::new (rec_processor.rs:29-46)
-        lines = [ln.strip() for ln in dict_bytes.decode("utf-8").splitlines()]
-        self.dict = ["blank"] + lines + [" "]
+        self.dict = load_dictionary(dict_bytes)
         self.max_side_len, self.min_side_len = max_side_len, min_side_len
         self.det_worker: Callable = lambda t: nets.det_forward(self.wd, torch.from_numpy(t)).numpy()
         self.cls_worker: Callable = lambda t: nets.cls_forward(self.wc, torch.from_numpy(t)).numpy()

@@ -15,18 +15,32 @@ using namespace rt;
 static thread_local std::string g_create_error;
 const char* rt_results_json_impl(rt_results* r, int page, int stage);
 
+// A call that fails after work was enqueued must not leave kernels or H2D copies in flight: the next
+// begin_call() rewinds the pinned staging and the arenas they read.  Errors of the drain itself are dropped
+// (the first failure is the one reported).
+static void quiesce(rt_session* s) {
+  if (!s) return;
+  (void)hipSetDevice(s->device);
+  if (s->st) (void)hipStreamSynchronize(s->st);
+  for (auto& h : s->helpers)
+    if (h->st) (void)hipStreamSynchronize(h->st);
+  (void)hipGetLastError();
+}
 template <typename F>
 static int guarded(rt_session* s, F&& f) {
   try {
     f();
     return RT_OK;
   } catch (const RtError& e) {
+    quiesce(s);
     if (s) s->last_error = e.what(); else g_create_error = e.what();
     return e.code;
   } catch (const std::bad_alloc&) {
+    quiesce(s);
     if (s) s->last_error = "out of host memory"; else g_create_error = "out of host memory";
     return RT_ERR_BACKEND;
   } catch (const std::exception& e) {
+    quiesce(s);
     if (s) s->last_error = e.what(); else g_create_error = e.what();
     return RT_ERR_BACKEND;
   }
@@ -194,6 +208,33 @@ int rt_decode_image(const void* data, size_t len, uint8_t** rgb, int* h, int* w,
     return RT_ERR_BACKEND;
   }
 }
+int rt_parse_dictionary(const void* data, size_t len, char** out, size_t* out_len, int* n_entries, char* err, size_t err_cap) {
+  if (err && err_cap) err[0] = 0;
+  if ((!data && len) || !out || !out_len || !n_entries) { if (err && err_cap) snprintf(err, err_cap, "rt_parse_dictionary: null argument"); return RT_ERR_INVALID; }
+  *out = nullptr; *out_len = 0; *n_entries = 0;
+  try {
+    std::vector<uint8_t> bytes((const uint8_t*)data, (const uint8_t*)data + len);
+    std::vector<std::string> d = rt::load_dictionary(bytes);
+    std::string j;
+    for (size_t i = 0; i < d.size(); i++) { if (i) j += '\n'; j += d[i]; }
+    char* p = (char*)malloc(j.size() + 1);
+    if (!p) throw RtError(RT_ERR_BACKEND, "out of memory");
+    memcpy(p, j.data(), j.size()); p[j.size()] = 0;
+    *out = p; *out_len = j.size(); *n_entries = (int)d.size();
+    return RT_OK;
+  } catch (const RtError& e) {
+    if (err && err_cap) snprintf(err, err_cap, "%s", e.what());
+    return e.code;
+  } catch (const std::exception& e) {
+    if (err && err_cap) snprintf(err, err_cap, "%s", e.what());
+    return RT_ERR_BACKEND;
+  }
+}
+int rt_format_f32(float v, char* buf, size_t cap) {
+  std::string s = rt_format_f32_impl(v);
+  if (buf && cap) { size_t n = std::min(cap - 1, s.size()); memcpy(buf, s.data(), n); buf[n] = 0; }
+  return (int)s.size();
+}
 // RettoSession::run / run_stream take the encoded bytes (session.rs:108,133): decode on host threads, then the batch path
 int rt_run_encoded_batch(rt_session* s, const void* const* files, const size_t* lens, int n_pages, rt_stage_callback cb,
                          void* user, rt_results** out) {
@@ -320,16 +361,11 @@ size_t rt_model_manifest(int which, char* buf, size_t cap) {
   return s.size() + 1;
 }
 
-// A/B switches for tools/ (not part of the drop-in surface).  `flags` bits:
-//   0  experimental k_dwpw                         1  fused thin blocks (k_lc_thin) OFF
-//   2  k_lc_thin: force the 128-pixel tile         3  depthwise: plain (not XCD-aware) block order
-//   4  depthwise: 32-channel slabs only            5  depthwise: 128- instead of 64-channel wide slabs
-//   6  CTC head on the 128 x 128 wide tile             7  k_lc_thin: producer/consumer wave form
+// A/B switches for tools/ (include/retto_hip.h, diagnostics section)
 RT_API void rt_debug_set_variants(int gemm_variant, int dw_variant, int flags) {
   nn::g_gemm_variant = gemm_variant;
   nn::g_dw_variant = dw_variant;
-  nn::g_fuse_dwpw = flags & 1;
-  nn::g_lc_thin = (flags & 2) ? 0 : ((flags & 4) ? 2 : ((flags & 128) ? 1 : 4));
+  nn::g_lc_thin = (flags & 2) ? 0 : ((flags & 4) ? 2 : 4);
   nn::set_dw_xcd((flags & 8) ? 0 : 1);
   nn::g_dw_wide_slab_min = (flags & 16) ? (1 << 30) : 192;
   nn::g_dw_wide3_min = (flags & 16) ? (1 << 30) : 128;

@@ -53,6 +53,18 @@ struct RtError : std::runtime_error {
                                  std::to_string(__LINE__) + ")");                                \
   } while (0)
 
+// hipLaunchKernelGGL + an immediate hipGetLastError(): a launch the runtime rejects (grid too large, too
+// much LDS, no code object for the device) must surface as RT_ERR_BACKEND, not as RT_OK over garbage.
+#define RT_LAUNCH(kernel, grid, block, shmem, stream, ...)                                                   \
+  do {                                                                                                       \
+    hipLaunchKernelGGL(kernel, grid, block, shmem, stream, __VA_ARGS__);                                     \
+    hipError_t le__ = hipGetLastError();                                                                     \
+    if (le__ != hipSuccess)                                                                                  \
+      throw ::rt::RtError(4, std::string("kernel launch rejected: " #kernel ": ") + hipGetErrorString(le__) + \
+                                 " (" __FILE__ ":" + std::to_string(__LINE__) + ")");                        \
+  } while (0)
+constexpr int RT_MAX_GRID_Y = 65535;  // HIP limit of gridDim.y / gridDim.z
+
 static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 // Channel pitch of an NHWC activation: multiples of 4 (16-byte vectors); wide tensors are padded to
 // 32 channels so that every pixel starts on a 128-byte line (240 -> 256: the depthwise kernels'

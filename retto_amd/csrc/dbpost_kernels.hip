@@ -709,15 +709,15 @@ void db_postprocess_batch(hipStream_t st, int n, const DbPageIn* in, const DbPar
   (void)hipMemcpyAsync(d_desc, h_desc, (size_t)n * sizeof(DbPage), hipMemcpyHostToDevice, st);
   const DbPage* dp = (const DbPage*)d_desc;
   dim3 grid((maxN + 255) / 256, n), blk(256);
-  hipLaunchKernelGGL(k_db_mask, grid, blk, 0, st, dp, p.thresh, p.dilate);
-  hipLaunchKernelGGL(k_ccl_rows, dim3(maxH, n), blk, 0, st, dp);
-  hipLaunchKernelGGL(k_ccl_link, grid, blk, 0, st, dp);
-  hipLaunchKernelGGL(k_ccl_stats, grid, blk, 0, st, dp);
-  hipLaunchKernelGGL(k_contour_alloc, grid, blk, 0, st, dp);
-  hipLaunchKernelGGL(k_row_extents, grid, blk, 0, st, dp);
+  RT_LAUNCH(k_db_mask, grid, blk, 0, st, dp, p.thresh, p.dilate);
+  RT_LAUNCH(k_ccl_rows, dim3(maxH, n), blk, 0, st, dp);
+  RT_LAUNCH(k_ccl_link, grid, blk, 0, st, dp);
+  RT_LAUNCH(k_ccl_stats, grid, blk, 0, st, dp);
+  RT_LAUNCH(k_contour_alloc, grid, blk, 0, st, dp);
+  RT_LAUNCH(k_row_extents, grid, blk, 0, st, dp);
   (void)maxC;
-  hipLaunchKernelGGL(k_contour_boxes, dim3(RT_CONTOUR_WAVES, n), dim3(64), 0, st, dp, p);
-  hipLaunchKernelGGL(k_sort_boxes, dim3(n), dim3(256), 0, st, dp);
+  RT_LAUNCH(k_contour_boxes, dim3(RT_CONTOUR_WAVES, n), dim3(64), 0, st, dp, p);
+  RT_LAUNCH(k_sort_boxes, dim3(n), dim3(256), 0, st, dp);
 }
 
 // Sorted boxes of all pages -> one contiguous list (page order), so that the host fetches them with a single copy.
@@ -734,7 +734,7 @@ __global__ __launch_bounds__(256) void k_pack_boxes(const DbBox* __restrict__ bo
   for (int i = threadIdx.x; i < cnt * WORDS; i += blockDim.x) dst[i] = src[i];
 }
 void pack_boxes(hipStream_t st, int n, const DbBox* boxes, const int* counts, int max_boxes, DbBox* packed) {
-  if (n > 0) hipLaunchKernelGGL(k_pack_boxes, dim3(n), dim3(256), 0, st, boxes, counts, max_boxes, packed);
+  if (n > 0) RT_LAUNCH(k_pack_boxes, dim3(n), dim3(256), 0, st, boxes, counts, max_boxes, packed);
 }
 
 }  // namespace pp

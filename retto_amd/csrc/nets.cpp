@@ -216,14 +216,6 @@ static const float HSIG_LCNET = 0.1666667f;  // paddle nn.Hardsigmoid
 static const float HSIG_MBV3 = 0.2f;         // F.hardsigmoid(slope=0.2, offset=0.5)
 
 static float* run_lc(RunCtx& c, const LcBlock& b, const float* x, const Level& Lin, const Level& Lout) {
-  if (nn::g_fuse_dwpw && !b.se && b.sh == 1 && b.sw == 1 && b.dw.Cp == round_up(b.dw.C, 4)) {
-    int Cpo = chan_pitch(b.cout);
-    float* y2 = c.arena->alloc<float>((size_t)Lout.total * Cpo);
-    ProfScope ps(c.prof, c.st, b.dw.k == 3 ? "dwpw3" : "dwpw5");
-    nn::dwpw(c.st, b.dw.k, x, Lout.d, Lout.n(), Lout.maxH, Lout.maxW, b.dw.Cp, b.dw.w, b.dw.b, b.dw_act, b.dw_lab.has,
-             b.dw_lab.a, b.dw_lab.c, b.pw.w, b.pw.N, b.pw.Npad, y2, Cpo, make_epi(b.pw, ACT_HSWISH, &b.pw_lab));
-    return y2;
-  }
   if (!b.se && nn::lc_thin_supported(b.dw.k, b.sh, b.sw, b.dw.Cp, b.dw.C, b.pw.Npad) && b.pw.K == b.dw.Cp) {
     int Cpo = chan_pitch(b.cout);
     float* y2 = c.arena->alloc<float>((size_t)Lout.total * Cpo);

@@ -45,17 +45,12 @@ int gemm_argmax_tiles(int Npad16);
 void argmax_merge(hipStream_t st, const float* pm, const int* pi, const float* ps, int tiles, long long rows, int* idx,
                   float* prob);
 
-// Fused stride-1 depthwise KxK (+bias, act, LAB) -> 1x1 conv (+epilogue); see k_dwpw.
-void dwpw(hipStream_t st, int K, const float* x, const ImgGeom* geom, int n_img, int maxH, int maxW, int Cp,
-          const float* Wd, const float* bd, int dw_act, int dw_has_lab, float dw_a, float dw_c, const float* Wp, int N,
-          int Npad16, float* y, int ldy, const Epilogue& epi);
 // Fused thin LCNetV3 block (3x3 depthwise -> 1x1 conv, C_in <= 64, no SE): see k_lc_thin.
 extern int g_lc_thin;
 bool lc_thin_supported(int K, int sh, int sw, int Cp, int C, int Npad16);
 void lc_thin(hipStream_t st, int sh, int sw, const float* x, const ImgGeom* gin, const ImgGeom* gout, int n_img, int maxHo,
              int maxWo, int Cp, int C, const float* Wd, const float* bd, int dw_act, int dw_has_lab, float dw_a, float dw_c,
              const float* Wp, int N, int Npad16, float* y, int ldy, const Epilogue& epi);
-extern int g_fuse_dwpw;  // 1 = use the fused kernel where it applies (default)
 
 // 3x3 stride-2 stem on a 3(+1 pad)-channel f32 NHWC input. Ws packed [27][COUT]. COUT in {8,16}.
 // One RGB8 page of a det launch group (device pointer; npix = H*W; out_pix = its pixel offset in the group).

@@ -553,495 +553,6 @@ __global__ __launch_bounds__(64 * WM * WN, (NT > 8 ? 2 : 1)) void k_gemm_wide(co
 }
 
 // ---------------------------------------------------------------------------
-// 32x32x2 variant: block 128 rows x 128 cols, 4 waves as 2x2, each wave 64x64 = 2x2 tiles of
-// v_mfma_f32_32x32x2_f32 (half the operand reads per FLOP of the 16x16x4 form).
-// Lane l: c = l & 31, h = l >> 5; in a 32-deep K slab half h reads k = 16h..16h+15 and feeds
-// element s to step s (same map for both operands).
-// ---------------------------------------------------------------------------
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-__global__ __launch_bounds__(256) void k_gemm_32(const float* __restrict__ A, int lda, long long M, int K,
-                                                 const float* __restrict__ Wp, int N, int Npad, float* __restrict__ C,
-                                                 int ldc, int coff, Epilogue epi) {
-  constexpr int BM = 128, BN = 128, NTHR = 256;
-  __shared__ __attribute__((aligned(16))) float lds[(BM + BN) * LROW];
-  float* xs = lds;
-  float* ws = lds + BM * LROW;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = lane & 31, h = lane >> 5;
-  const int wm = wave >> 1, wn = wave & 1;
-  const long long m0 = (long long)blockIdx.x * BM;
-  const int n0 = blockIdx.y * BN;
-  f32x16 acc[2][2];
-#pragma unroll
-  for (int i = 0; i < 2; i++)
-#pragma unroll
-    for (int j = 0; j < 2; j++)
-#pragma unroll
-      for (int e = 0; e < 16; e++) acc[i][j][e] = 0.f;
-  f32x4 pa[4], pw[4];
-  const int nkc = (K + KC - 1) / KC;
-  auto fetch = [&](int kc) {
-    const int k0 = kc * KC;
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-      int idx = tid + NTHR * i, row = idx >> 3, c4 = idx & 7;
-      long long m = m0 + row;
-      pa[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (m < M && k0 + c4 * 4 < K) pa[i] = *reinterpret_cast<const f32x4*>(A + m * lda + k0 + c4 * 4);
-      pw[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (n0 + row < Npad) pw[i] = *reinterpret_cast<const f32x4*>(Wp + ((long long)kc * Npad + n0 + row) * KC + c4 * 4);
-    }
-  };
-  auto stash = [&]() {
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-      int idx = tid + NTHR * i, row = idx >> 3, c4 = idx & 7;
-      *reinterpret_cast<f32x4*>(xs + row * LROW + c4 * 4) = pa[i];
-      *reinterpret_cast<f32x4*>(ws + row * LROW + c4 * 4) = pw[i];
-    }
-  };
-  fetch(0); stash(); __syncthreads();
-  for (int kc = 0; kc < nkc; kc++) {
-    if (kc + 1 < nkc) fetch(kc + 1);
-    const float* xr = xs + (wm * 64 + c) * LROW + 16 * h;
-    const float* wr = ws + (wn * 64 + c) * LROW + 16 * h;
-#pragma unroll
-    for (int g = 0; g < 4; g++) {
-      f32x4 a0 = *reinterpret_cast<const f32x4*>(xr + g * 4);
-      f32x4 a1 = *reinterpret_cast<const f32x4*>(xr + 32 * LROW + g * 4);
-      f32x4 b0 = *reinterpret_cast<const f32x4*>(wr + g * 4);
-      f32x4 b1 = *reinterpret_cast<const f32x4*>(wr + 32 * LROW + g * 4);
-#pragma unroll
-      for (int s = 0; s < 4; s++) {
-        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(b0[s], a0[s], acc[0][0], 0, 0, 0);
-        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(b1[s], a0[s], acc[0][1], 0, 0, 0);
-        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(b0[s], a1[s], acc[1][0], 0, 0, 0);
-        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(b1[s], a1[s], acc[1][1], 0, 0, 0);
-      }
-    }
-    __syncthreads();
-    if (kc + 1 < nkc) { stash(); __syncthreads(); }
-  }
-  // D: col (pixel) = lane & 31, row (cout) = 8*(reg>>2) + 4*h + (reg&3)
-  const int nstore = (N + 3) & ~3;
-#pragma unroll
-  for (int mt = 0; mt < 2; mt++) {
-    long long m = m0 + wm * 64 + mt * 32 + c;
-    if (m >= M) continue;
-#pragma unroll
-    for (int nt = 0; nt < 2; nt++)
-#pragma unroll
-      for (int gq = 0; gq < 4; gq++) {
-        int col = n0 + wn * 64 + nt * 32 + 8 * gq + 4 * h;
-        if (col >= nstore) continue;
-        f32x4 bias = {0.f, 0.f, 0.f, 0.f};
-        if (epi.bias) bias = *reinterpret_cast<const f32x4*>(epi.bias + col);
-        f32x4 o;
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-          float t = act_apply(acc[mt][nt][gq * 4 + j] + bias[j], epi.act);
-          if (epi.has_lab) t = fmaf(t, epi.lab_a, epi.lab_c);
-          if (epi.residual) t += epi.residual[m * epi.ld_res + col + j];
-          o[j] = (col + j < N) ? t : 0.0f;
-        }
-        *reinterpret_cast<f32x4*>(C + m * ldc + coff + col) = o;
-      }
-  }
-}
-
-// ---------------------------------------------------------------------------
-// Fused LCNetV3 block (stride 1, no SE): y = epi_pw( Wpw . lab(act(dw_KxK(x) + b_dw)) ).
-// The depthwise result only ever exists as the GEMM's A tile in LDS, so the block moves
-// input + output through HBM once instead of twice.
-// One workgroup = 12 waves: 8 consumer waves (4 x 2, each 32 pixels x 16*NT columns of
-// v_mfma_f32_16x16x4_f32) and 4 producer waves (one per SIMD) that compute the next
-// 32-channel depthwise slab (1x4 pixel strips x 4 channels per lane) and stage the next weight
-// slab while the consumers run the MFMAs of the current one; LDS is double buffered and there
-// is one barrier per slab.  VALU/TA work of the producers overlaps the matrix pipe.
-// Output tile: TH x (128/TH) pixels of one image.
-// ---------------------------------------------------------------------------
-template <int K, int NT>
-__global__ __launch_bounds__(768) void k_dwpw(const float* __restrict__ x, const ImgGeom* __restrict__ geom, int Cp,
-                                              const float* __restrict__ Wd, const float* __restrict__ bd, int dw_act,
-                                              int dw_has_lab, float dw_a, float dw_c, const float* __restrict__ Wp,
-                                              int N, int Npad, float* __restrict__ y, int ldy, Epilogue epi, int TH) {
-  constexpr int BN = 32 * NT;  // 2 consumer wave columns x 16*NT
-  __shared__ __attribute__((aligned(16))) float lds[2 * (128 + BN) * LROW];
-  constexpr int BUF = (128 + BN) * LROW;  // one buffer: 128 activation rows then BN weight rows
-  const ImgGeom g = geom[blockIdx.y];
-  const int TW = 128 / TH;
-  const int tiles_x = (g.W + TW - 1) / TW, tiles_y = (g.H + TH - 1) / TH;
-  if ((int)blockIdx.x >= tiles_x * tiles_y) return;
-  const int ty0 = (blockIdx.x / tiles_x) * TH, tx0 = (blockIdx.x % tiles_x) * TW;
-  const int n0 = blockIdx.z * BN;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const bool producer = wave >= 8;
-  const int nkc = (Cp + KC - 1) / KC;
-
-  // ---- producer state: lane -> (strip, channel group)
-  const int pl = (wave - 8) * 64 + lane;            // 0..255 among producer lanes
-  const int c4 = pl & 7, strip = pl >> 3;           // 32 strips of 4 pixels
-  const int sp0 = strip * 4;                        // first tile-local pixel of the strip
-  const int spy = sp0 / TW, spx = sp0 % TW;
-  auto produce = [&](int kc, int buf) {
-    const int ch = kc * KC + c4 * 4;
-    const int oy = ty0 + spy, ox0 = tx0 + spx;
-    f32x4 acc[4];
-    const bool live = ch < Cp && oy < g.H && ox0 < g.W;
-    if (live) {
-      const f32x4 b = *reinterpret_cast<const f32x4*>(bd + ch);
-      acc[0] = b; acc[1] = b; acc[2] = b; acc[3] = b;
-      // one input row at a time: keeps the producer's live set small (the consumer accumulators
-      // occupy the same register file) at the cost of per-row load latency, which the producers
-      // can afford (their slab takes ~1/3 of the consumers' MFMA time)
-#pragma unroll 1
-      for (int dy = 0; dy < K; dy++) {
-        int iy = oy + dy - K / 2;
-        if (iy < 0 || iy >= g.H) continue;
-        const float* row = x + (g.off + (long long)iy * g.W) * Cp + ch;
-        f32x4 v[K + 3];
-#pragma unroll
-        for (int j = 0; j < K + 3; j++) {
-          int ix = ox0 + j - K / 2;
-          v[j] = (ix >= 0 && ix < g.W) ? *reinterpret_cast<const f32x4*>(row + (long long)ix * Cp) : f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-#pragma unroll
-        for (int dx = 0; dx < K; dx++) {
-          f32x4 w = *reinterpret_cast<const f32x4*>(Wd + (dy * K + dx) * Cp + ch);
-#pragma unroll
-          for (int j = 0; j < 4; j++)
-#pragma unroll
-            for (int e = 0; e < 4; e++) acc[j][e] = fmaf(v[j + dx][e], w[e], acc[j][e]);
-        }
-      }
-#pragma unroll
-      for (int j = 0; j < 4; j++)
-#pragma unroll
-        for (int e = 0; e < 4; e++) {
-          float t = act_apply(acc[j][e], dw_act);
-          if (dw_has_lab) t = fmaf(t, dw_a, dw_c);
-          acc[j][e] = t;
-        }
-    } else {
-#pragma unroll
-      for (int j = 0; j < 4; j++) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-#pragma unroll
-    for (int j = 0; j < 4; j++) *reinterpret_cast<f32x4*>(lds + buf * BUF + (sp0 + j) * LROW + c4 * 4) = acc[j];
-    // weight slab: BN rows x 8 float4, 256 producer lanes
-#pragma unroll 2
-    for (int i = 0; i < BN / 32; i++) {
-      int idx = pl + 256 * i, row = idx >> 3, cc = idx & 7;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (n0 + row < Npad) v = *reinterpret_cast<const f32x4*>(Wp + ((long long)kc * Npad + n0 + row) * KC + cc * 4);
-      *reinterpret_cast<f32x4*>(lds + buf * BUF + (128 + row) * LROW + cc * 4) = v;
-    }
-  };
-
-  // ---- consumer state
-  const int r = lane & 15, q = lane >> 4, wm = wave >> 1, wn = wave & 1;
-  f32x4 acc[2][NT];
-#pragma unroll
-  for (int i = 0; i < 2; i++)
-#pragma unroll
-    for (int j = 0; j < NT; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  if (producer) produce(0, 0);
-  __syncthreads();
-  for (int kc = 0; kc < nkc; kc++) {
-    const int buf = kc & 1;
-    if (producer) {
-      if (kc + 1 < nkc) produce(kc + 1, buf ^ 1);
-    } else {
-      const float* xr = lds + buf * BUF + (wm * 32 + r) * LROW;
-      const float* wr = lds + buf * BUF + (128 + wn * NT * 16 + r) * LROW;
-#pragma unroll
-      for (int gi = 0; gi < KC / 16; gi++) {
-        f32x4 a[2], b[NT];
-#pragma unroll
-        for (int mt = 0; mt < 2; mt++) a[mt] = *reinterpret_cast<const f32x4*>(xr + mt * 16 * LROW + gi * 16 + 4 * q);
-#pragma unroll
-        for (int nt = 0; nt < NT; nt++) b[nt] = *reinterpret_cast<const f32x4*>(wr + nt * 16 * LROW + gi * 16 + 4 * q);
-#pragma unroll
-        for (int s = 0; s < 4; s++)
-#pragma unroll
-          for (int nt = 0; nt < NT; nt++)
-#pragma unroll
-            for (int mt = 0; mt < 2; mt++)
-              acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[nt][s], a[mt][s], acc[mt][nt], 0, 0, 0);
-      }
-    }
-    __syncthreads();
-  }
-  if (producer) return;
-  const int nstore = (N + 3) & ~3;
-#pragma unroll
-  for (int mt = 0; mt < 2; mt++) {
-    const int p = wm * 32 + mt * 16 + r;
-    const int oy = ty0 + p / TW, ox = tx0 + p % TW;
-    if (oy >= g.H || ox >= g.W) continue;
-    const long long pix = g.off + (long long)oy * g.W + ox;
-#pragma unroll
-    for (int nt = 0; nt < NT; nt++) {
-      int col = n0 + (wn * NT + nt) * 16 + q * 4;
-      if (col >= nstore) continue;
-      f32x4 bias = {0.f, 0.f, 0.f, 0.f};
-      if (epi.bias) bias = *reinterpret_cast<const f32x4*>(epi.bias + col);
-      f32x4 o;
-#pragma unroll
-      for (int j = 0; j < 4; j++) {
-        float t = act_apply(acc[mt][nt][j] + bias[j], epi.act);
-        if (epi.has_lab) t = fmaf(t, epi.lab_a, epi.lab_c);
-        o[j] = (col + j < N) ? t : 0.0f;
-      }
-      *reinterpret_cast<f32x4*>(y + pix * ldy + col) = o;
-    }
-  }
-}
-
-void dwpw(hipStream_t st, int K, const float* x, const ImgGeom* geom, int n_img, int maxH, int maxW, int Cp,
-          const float* Wd, const float* bd, int dw_act, int dw_has_lab, float dw_a, float dw_c, const float* Wp, int N,
-          int Npad16, float* y, int ldy, const Epilogue& epi) {
-  if (n_img <= 0) return;
-  int TH = 8;
-  while (TH > 1 && TH > maxH) TH >>= 1;
-  if (maxH == 12 || maxH == 6 || maxH == 3) TH = maxH == 3 ? 2 : (maxH == 6 ? 2 : 4);
-  const int TW = 128 / TH;
-  const int tiles = ((maxW + TW - 1) / TW) * ((maxH + TH - 1) / TH);
-  int NT = Npad16 >= 256 ? 8 : (Npad16 > 64 ? 4 : (Npad16 > 32 ? 2 : 1));
-  if (Npad16 > 128 && Npad16 < 256) NT = 8;
-  const int BN = 32 * NT;
-  dim3 grid(tiles, n_img, (Npad16 + BN - 1) / BN);
-#define RT_DWPW(KK, NN) \
-  hipLaunchKernelGGL((k_dwpw<KK, NN>), grid, dim3(768), 0, st, x, geom, Cp, Wd, bd, dw_act, dw_has_lab, dw_a, dw_c, Wp, N, Npad16, y, ldy, epi, TH)
-  if (K == 3) { switch (NT) { case 1: RT_DWPW(3, 1); break; case 2: RT_DWPW(3, 2); break; case 4: RT_DWPW(3, 4); break; default: RT_DWPW(3, 8); } }
-  else if (K == 5) { switch (NT) { case 1: RT_DWPW(5, 1); break; case 2: RT_DWPW(5, 2); break; case 4: RT_DWPW(5, 4); break; default: RT_DWPW(5, 8); } }
-  else throw RtError(8, "dwpw: unsupported kernel size");
-#undef RT_DWPW
-}
-
-// ---------------------------------------------------------------------------
-// Persistent wide GEMM: same tile as k_gemm_wide, but a workgroup walks over several output
-// tiles and the register prefetch runs ACROSS tiles (the first K slab of the next tile is
-// fetched under the last MFMAs of the current one), so the load latency at the start of a
-// tile - a third of a tile's time at K = 240 - is paid once per workgroup instead of per tile.
-// Tiles are numbered row-block major with the column blocks of a row adjacent (shared A rows).
-// ---------------------------------------------------------------------------
-template <int MT, int NT, int WM, int WN>
-__global__ __launch_bounds__(64 * WM * WN) void k_gemm_persist(const float* __restrict__ A, int lda, long long M, int K,
-                                                                const float* __restrict__ Wp, int N, int Npad,
-                                                                float* __restrict__ C, int ldc, int coff, Epilogue epi) {
-  constexpr int NTHR = 64 * WM * WN, BM = 16 * MT * WM, BN = 16 * NT * WN;
-  constexpr int A_LD = (BM * 8 + NTHR - 1) / NTHR, W_LD = (BN * 8 + NTHR - 1) / NTHR;
-  __shared__ __attribute__((aligned(16))) float lds[(BM + BN) * LROW];
-  float* xs = lds;
-  float* ws = lds + BM * LROW;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, q = lane >> 4;
-  const int wm = wave / WN, wn = wave % WN;
-  const int ncol = (Npad + BN - 1) / BN;
-  const long long ntiles = ((M + BM - 1) / BM) * ncol;
-  const int nkc = (K + KC - 1) / KC;
-  const int nstore = (N + 3) & ~3;
-  f32x4 pa[A_LD], pw[W_LD];
-  auto fetch = [&](long long tile, int kc) {
-    const long long m0 = (tile / ncol) * BM;
-    const int n0 = (int)(tile % ncol) * BN, k0 = kc * KC;
-#pragma unroll
-    for (int i = 0; i < A_LD; i++) {
-      int idx = tid + NTHR * i, row = idx >> 3, c4 = idx & 7;
-      long long m = m0 + row;
-      pa[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (row < BM && m < M && k0 + c4 * 4 < K) pa[i] = *reinterpret_cast<const f32x4*>(A + m * lda + k0 + c4 * 4);
-    }
-#pragma unroll
-    for (int i = 0; i < W_LD; i++) {
-      int idx = tid + NTHR * i, row = idx >> 3, c4 = idx & 7;
-      pw[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (row < BN && n0 + row < Npad)
-        pw[i] = *reinterpret_cast<const f32x4*>(Wp + ((long long)kc * Npad + n0 + row) * KC + c4 * 4);
-    }
-  };
-  auto stash = [&]() {
-#pragma unroll
-    for (int i = 0; i < A_LD; i++) {
-      int idx = tid + NTHR * i, row = idx >> 3, c4 = idx & 7;
-      if (row < BM) *reinterpret_cast<f32x4*>(xs + row * LROW + c4 * 4) = pa[i];
-    }
-#pragma unroll
-    for (int i = 0; i < W_LD; i++) {
-      int idx = tid + NTHR * i, row = idx >> 3, c4 = idx & 7;
-      if (row < BN) *reinterpret_cast<f32x4*>(ws + row * LROW + c4 * 4) = pw[i];
-    }
-  };
-  long long tile = blockIdx.x;
-  if (tile >= ntiles) return;
-  fetch(tile, 0);
-  stash();
-  __syncthreads();
-  for (; tile < ntiles; tile += gridDim.x) {
-    f32x4 acc[MT][NT];
-#pragma unroll
-    for (int i = 0; i < MT; i++)
-#pragma unroll
-      for (int j = 0; j < NT; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int kc = 0; kc < nkc; kc++) {
-      const bool more_k = kc + 1 < nkc;
-      const bool more = more_k || tile + gridDim.x < ntiles;
-      if (more_k) fetch(tile, kc + 1);
-      else if (more) fetch(tile + gridDim.x, 0);
-      const float* xr = xs + (wm * MT * 16 + r) * LROW;
-      const float* wr = ws + (wn * NT * 16 + r) * LROW;
-      f32x4 a[KC / 16][MT], b[KC / 16][NT];
-#pragma unroll
-      for (int g = 0; g < KC / 16; g++) {
-#pragma unroll
-        for (int mt = 0; mt < MT; mt++) a[g][mt] = *reinterpret_cast<const f32x4*>(xr + mt * 16 * LROW + g * 16 + 4 * q);
-#pragma unroll
-        for (int nt = 0; nt < NT; nt++) b[g][nt] = *reinterpret_cast<const f32x4*>(wr + nt * 16 * LROW + g * 16 + 4 * q);
-      }
-#pragma unroll
-      for (int g = 0; g < KC / 16; g++)
-#pragma unroll
-        for (int s = 0; s < 4; s++)
-#pragma unroll
-          for (int nt = 0; nt < NT; nt++)
-#pragma unroll
-            for (int mt = 0; mt < MT; mt++)
-              acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[g][nt][s], a[g][mt][s], acc[mt][nt], 0, 0, 0);
-      __syncthreads();
-      if (more) { stash(); __syncthreads(); }
-    }
-    const long long m0 = (tile / ncol) * BM;
-    const int n0 = (int)(tile % ncol) * BN;
-    act_dispatch(epi.act, epi.has_lab, epi.residual != nullptr, [&](auto at, auto lt, auto rt_) {
-      constexpr int AC = decltype(at)::value, L = decltype(lt)::value, RES = decltype(rt_)::value;
-#pragma unroll
-      for (int nt = 0; nt < NT; nt++) {
-        int col = n0 + (wn * NT + nt) * 16 + q * 4;
-        if (col >= nstore) continue;
-        f32x4 bias = {0.f, 0.f, 0.f, 0.f};
-        if (epi.bias) bias = *reinterpret_cast<const f32x4*>(epi.bias + col);
-#pragma unroll
-        for (int mt = 0; mt < MT; mt++) {
-          long long m = m0 + (wm * MT + mt) * 16 + r;
-          if (m >= M) continue;
-          f32x4 o;
-#pragma unroll
-          for (int j = 0; j < 4; j++) {
-            float t = epi_val<AC, L>(acc[mt][nt][j] + bias[j], epi.act, epi.has_lab, epi.lab_a, epi.lab_c);
-            if (RES) t += epi.residual[m * epi.ld_res + col + j];
-            o[j] = (col + j < N) ? t : 0.0f;
-          }
-          *reinterpret_cast<f32x4*>(C + m * ldc + coff + col) = o;
-        }
-      }
-    });
-  }
-}
-
-// ---------------------------------------------------------------------------
-// LDS-DMA GEMM: both operands go HBM/L2 -> LDS with global_load_lds (no VGPR staging, no
-// ds_write pass), NBUF-deep ring of 32-deep K slabs so two slabs stay in flight behind the
-// MFMAs, one raw s_barrier per slab with a counted vmcnt.  LDS rows are unpadded 128 B
-// (the DMA writes lane-linear), bank conflicts are kept 2-way by an XOR swizzle applied to the
-// per-lane SOURCE address and again on the fragment reads.
-// Block: 128 rows x 256 cols, 8 waves as 4 x 2, each 32 x 128 (MT=2, NT=8).
-// ---------------------------------------------------------------------------
-#define RT_GLDS(gp, lp) \
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gp), \
-                                   (__attribute__((address_space(3))) void*)(lp), 16, 0, 0)
-template <int NBUF>
-__global__ __launch_bounds__(512) void k_gemm_dma(const float* __restrict__ A, int lda, long long M, int K,
-                                                  const float* __restrict__ Wp, int N, int Npad, float* __restrict__ C,
-                                                  int ldc, int coff, Epilogue epi, const float* __restrict__ zeros) {
-  constexpr int BM = 128, BN = 256, NT = 8, SLAB = (BM + BN) * KC;  // floats per ring slot
-  __shared__ __attribute__((aligned(16))) float lds[NBUF * SLAB];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, q = lane >> 4;
-  const int wm = wave >> 1, wn = wave & 1;
-  const long long m0 = (long long)blockIdx.x * BM;
-  const int n0 = blockIdx.y * BN;
-  const int nkc = (K + KC - 1) / KC;
-  const int lrow = lane >> 3, pslot = lane & 7;
-  auto issue = [&](int kc, int buf) {
-    float* base = lds + buf * SLAB;
-#pragma unroll
-    for (int i = 0; i < 2; i++) {  // activations: 16 groups of 8 rows, 2 per wave
-      const int rg = wave * 2 + i, row = rg * 8 + lrow;
-      const int k = kc * KC + ((pslot ^ (row & 7)) << 2);
-      const long long m = m0 + row;
-      const float* src = (m < M && k < K) ? A + m * lda + k : zeros;
-      RT_GLDS(src, base + rg * 8 * KC);
-    }
-#pragma unroll
-    for (int i = 0; i < 4; i++) {  // weights: 32 groups of 8 rows, 4 per wave
-      const int rg = wave * 4 + i, row = rg * 8 + lrow;
-      const int n = n0 + row;
-      const float* src = n < Npad ? Wp + ((long long)kc * Npad + n) * KC + ((pslot ^ (row & 7)) << 2) : zeros;
-      RT_GLDS(src, base + BM * KC + rg * 8 * KC);
-    }
-  };
-  f32x4 acc[2][NT];
-#pragma unroll
-  for (int i = 0; i < 2; i++)
-#pragma unroll
-    for (int j = 0; j < NT; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  issue(0, 0);
-  if (nkc > 1) issue(1, 1);
-  for (int kc = 0; kc < nkc; kc++) {
-    // slab kc has landed once at most the 6 DMAs of slab kc+1 are still outstanding
-    if (kc + 1 < nkc) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    if (kc + 2 < nkc) issue(kc + 2, (kc + 2) % NBUF);
-    const float* xb = lds + (kc % NBUF) * SLAB;
-    const float* wb = xb + BM * KC;
-#pragma unroll
-    for (int gi = 0; gi < KC / 16; gi++) {
-      f32x4 a[2], b[NT];
-#pragma unroll
-      for (int mt = 0; mt < 2; mt++) {
-        const int row = wm * 32 + mt * 16 + r;
-        a[mt] = *reinterpret_cast<const f32x4*>(xb + row * KC + (((gi * 4 + q) ^ (row & 7)) << 2));
-      }
-#pragma unroll
-      for (int nt = 0; nt < NT; nt++) {
-        const int row = wn * 128 + nt * 16 + r;
-        b[nt] = *reinterpret_cast<const f32x4*>(wb + row * KC + (((gi * 4 + q) ^ (row & 7)) << 2));
-      }
-#pragma unroll
-      for (int s = 0; s < 4; s++)
-#pragma unroll
-        for (int nt = 0; nt < NT; nt++)
-#pragma unroll
-          for (int mt = 0; mt < 2; mt++)
-            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[nt][s], a[mt][s], acc[mt][nt], 0, 0, 0);
-    }
-    asm volatile("" ::: "memory");
-  }
-  const int nstore = (N + 3) & ~3;
-#pragma unroll
-  for (int nt = 0; nt < NT; nt++) {
-    int col = n0 + (wn * NT + nt) * 16 + q * 4;
-    if (col >= nstore) continue;
-    f32x4 bias = {0.f, 0.f, 0.f, 0.f};
-    if (epi.bias) bias = *reinterpret_cast<const f32x4*>(epi.bias + col);
-#pragma unroll
-    for (int mt = 0; mt < 2; mt++) {
-      long long m = m0 + wm * 32 + mt * 16 + r;
-      if (m >= M) continue;
-      f32x4 o;
-#pragma unroll
-      for (int j = 0; j < 4; j++) {
-        float t = act_apply(acc[mt][nt][j] + bias[j], epi.act);
-        if (epi.has_lab) t = fmaf(t, epi.lab_a, epi.lab_c);
-        if (epi.residual) t += epi.residual[m * epi.ld_res + col + j];
-        o[j] = (col + j < N) ? t : 0.0f;
-      }
-      *reinterpret_cast<f32x4*>(C + m * ldc + coff + col) = o;
-    }
-  }
-}
-// ---------------------------------------------------------------------------
 // Fused thin LCNetV3 block (3x3 depthwise, strides (1,1) / (2,1) / (2,2), no SE, C_in <= 64, N <= 128):
 //   y = epi_pw( W_pw . lab(act(dw3x3(x) + b_dw)) )
 // These layers are HBM bound (a few channels per pixel): run separately they move 3*C_in + C_out floats per
@@ -1167,138 +678,7 @@ __global__ __launch_bounds__(64 * TH) void k_lc_thin(const float* __restrict__ x
   }
 }
 
-// Producer / consumer form of k_lc_thin (64-pixel tiles): waves 0-3 load the patch of tile t+1 and run its
-// depthwise stage into the second A buffer while waves 4-7 multiply tile t and store it, so the MFMA pipe no
-// longer waits through the load / depthwise phases of its own tile.  Two block-wide barriers per tile.
-template <int C4, int NT, int SH, int SW>
-__global__ __launch_bounds__(512) void k_lc_thin_pc(const float* __restrict__ x, const ImgGeom* __restrict__ gin,
-                                                    const ImgGeom* __restrict__ gout, int C, const float* __restrict__ Wd,
-                                                    const float* __restrict__ bd, int dw_act, int dw_has_lab, float dw_a,
-                                                    float dw_c, const float* __restrict__ Wp, int N, int Npad,
-                                                    float* __restrict__ y, int ldy, Epilogue epi, int tiles_per_block) {
-  constexpr int CP = C4 * 4, TH = 4, TW = 16, ROWS = TH * TW, NPROD = 256, PPITCH = CP + 4;
-  constexpr int PH = (TH - 1) * SH + 3, PW = (TW - 1) * SW + 3;
-  constexpr int NKC = (CP + KC - 1) / KC, NCOL = 32 * NT;
-  constexpr int NPF = (PH * PW * C4 + NPROD - 1) / NPROD;
-  constexpr int SL = C4 >= 12 ? 4 : (C4 == 8 ? 2 : 1), ITEMS = (ROWS / SL) * C4;
-  static_assert(ITEMS <= NPROD, "one depthwise item per producer thread");
-  __shared__ __attribute__((aligned(16))) float patch[PH * PW * PPITCH];
-  __shared__ __attribute__((aligned(16))) float at[2 * NKC * ROWS * LROW];
-  __shared__ __attribute__((aligned(16))) float wt[NKC * NCOL * LROW];
-  const ImgGeom g = gout[blockIdx.y], gi = gin[blockIdx.y];
-  const int tiles_x = (g.W + TW - 1) / TW, n_tiles = tiles_x * ((g.H + TH - 1) / TH);
-  const int tile0 = blockIdx.x * tiles_per_block;
-  if (tile0 >= n_tiles) return;
-  const int tile_end = min(n_tiles, tile0 + tiles_per_block);
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, q = lane >> 4;
-  const bool producer = wave < 4;
-  for (int idx = tid; idx < NKC * NCOL * 8; idx += 512) {
-    const int c4i = idx & 7, row = (idx >> 3) % NCOL, kc = (idx >> 3) / NCOL;
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (row < Npad) v = *reinterpret_cast<const f32x4*>(Wp + ((long long)kc * Npad + row) * KC + c4i * 4);
-    *reinterpret_cast<f32x4*>(wt + (kc * NCOL + row) * LROW + c4i * 4) = v;
-  }
-  for (int idx = tid; idx < 2 * NKC * ROWS * LROW / 4; idx += 512) *reinterpret_cast<f32x4*>(at + idx * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
-  // ---- producer state
-  const int ic4 = tid % C4, ip0 = (tid / C4) * SL, ipy = ip0 / TW, ipx = ip0 % TW;
-  f32x4 dww[9], dwb, pf[NPF];
-  if (producer) {
-#pragma unroll
-    for (int t = 0; t < 9; t++) dww[t] = *reinterpret_cast<const f32x4*>(Wd + t * CP + ic4 * 4);
-    dwb = *reinterpret_cast<const f32x4*>(bd + ic4 * 4);
-  }
-  auto fetch = [&](int t) {
-    const int ty0 = (t / tiles_x) * TH, tx0 = (t % tiles_x) * TW;
-#pragma unroll
-    for (int i = 0; i < NPF; i++) {
-      const int e = tid + NPROD * i;
-      pf[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (e < PH * PW * C4) {
-        const int c4i = e % C4, px = e / C4, iy = ty0 * SH - 1 + px / PW, ix = tx0 * SW - 1 + px % PW;
-        if (iy >= 0 && iy < gi.H && ix >= 0 && ix < gi.W)
-          pf[i] = *reinterpret_cast<const f32x4*>(x + (gi.off + (long long)iy * gi.W + ix) * CP + c4i * 4);
-      }
-    }
-  };
-  auto stash = [&]() {
-#pragma unroll
-    for (int i = 0; i < NPF; i++) {
-      const int e = tid + NPROD * i;
-      if (e < PH * PW * C4) *reinterpret_cast<f32x4*>(patch + (e / C4) * PPITCH + (e % C4) * 4) = pf[i];
-    }
-  };
-  auto depthwise = [&](int buf) {
-    float* ab = at + buf * NKC * ROWS * LROW;
-    act_dispatch(dw_act, dw_has_lab, false, [&](auto atag, auto ltag, auto) {
-      constexpr int A = decltype(atag)::value, L = decltype(ltag)::value;
-      if (tid < ITEMS) {
-        f32x4 acc[SL];
-#pragma unroll
-        for (int j = 0; j < SL; j++) acc[j] = dwb;
-#pragma unroll
-        for (int dy = 0; dy < 3; dy++) {
-          constexpr int NVW = (SL - 1) * SW + 3;
-          f32x4 v[NVW];
-#pragma unroll
-          for (int j = 0; j < NVW; j++)
-            v[j] = *reinterpret_cast<const f32x4*>(patch + ((ipy * SH + dy) * PW + ipx * SW + j) * PPITCH + ic4 * 4);
-#pragma unroll
-          for (int dx = 0; dx < 3; dx++)
-#pragma unroll
-            for (int j = 0; j < SL; j++)
-#pragma unroll
-              for (int e = 0; e < 4; e++) acc[j][e] = fmaf(v[j * SW + dx][e], dww[dy * 3 + dx][e], acc[j][e]);
-        }
-#pragma unroll
-        for (int j = 0; j < SL; j++) {
-          f32x4 o;
-#pragma unroll
-          for (int e = 0; e < 4; e++) o[e] = (ic4 * 4 + e < C) ? epi_val<A, L>(acc[j][e], dw_act, dw_has_lab, dw_a, dw_c) : 0.f;
-          *reinterpret_cast<f32x4*>(ab + (((ic4 * 4) / KC) * ROWS + ip0 + j) * LROW + (ic4 * 4) % KC) = o;
-        }
-      }
-    });
-  };
-  // ---- consumer state
-  const int cw = wave - 4, wm = cw >> 1, wn = cw & 1;
-  const int nt_valid = max(0, min(NT, Npad / 16 - wn * NT));
-  const int nstore = (N + 3) & ~3;
-
-  // prologue: tile0 through the producers alone
-  if (producer) { fetch(tile0); stash(); }
-  __syncthreads();
-  if (producer) { if (tile0 + 1 < tile_end) fetch(tile0 + 1); depthwise(0); }
-  __syncthreads();
-  for (int tile = tile0; tile < tile_end; tile++) {
-    const int buf = (tile - tile0) & 1;
-    if (producer && tile + 1 < tile_end) stash();  // patch of tile+1 (requested one phase ago)
-    __syncthreads();
-    if (producer) {
-      if (tile + 2 < tile_end) fetch(tile + 2);
-      if (tile + 1 < tile_end) depthwise(buf ^ 1);
-    } else {
-      const float* ab = at + buf * NKC * ROWS * LROW;
-      f32x4 acc[2][NT];
-#pragma unroll
-      for (int i = 0; i < 2; i++)
-#pragma unroll
-        for (int j = 0; j < NT; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int kc = 0; kc < NKC; kc++)
-        mma_chunk<NT>(ab + (kc * ROWS + wm * 32 + r) * LROW, ab + (kc * ROWS + wm * 32 + 16 + r) * LROW,
-                      wt + (kc * NCOL + wn * NT * 16) * LROW, nt_valid, acc, r, q);
-      const int oy0 = (tile / tiles_x) * TH, ox0 = (tile % tiles_x) * TW;
-      const int p0 = wm * 32 + r, p1 = p0 + 16;
-      const int oya = oy0 + p0 / TW, oxa = ox0 + p0 % TW, oyb = oy0 + p1 / TW, oxb = ox0 + p1 % TW;
-      const long long pa = g.off + (long long)oya * g.W + oxa, pb = g.off + (long long)oyb * g.W + oxb;
-      epilogue_store<NT>(acc, nt_valid, epi, wn * NT * 16, N, nstore, y + pa * ldy, y + pb * ldy, oya < g.H && oxa < g.W,
-                         oyb < g.H && oxb < g.W, nullptr, nullptr, q);
-    }
-    __syncthreads();
-  }
-}
-
-int g_lc_thin = 4;  // 4 = fused thin blocks (default); 2 / 3 = force the 128- / 64-pixel tile; 1 = producer/consumer form (measured slower: 1.36 vs 0.99 ms at 64 -> 64); 0 = separate depthwise + GEMM kernels (A/B)
+int g_lc_thin = 4;  // 4 = fused thin blocks (default); 2 / 3 = force the 128- / 64-pixel tile; 0 = separate depthwise + GEMM kernels (A/B)
 static int lc_thin_code(int sh, int sw, int Cp, int Npad16) {  // instantiated (stride, C_in/4, column tiles) combinations
   const int c4 = Cp / 4, nt = (Npad16 + 31) / 32;
   if (sh == 1 && sw == 1) {
@@ -1325,23 +705,8 @@ void lc_thin(hipStream_t st, int sh, int sw, const float* x, const ImgGeom* gin,
   const int TH = code >= 6 ? 4 : (g_lc_thin == 2 ? 8 : (g_lc_thin == 3 ? 4 : (Cp >= 48 ? 4 : 8)));  // 2 / 3 force a variant (A/B)
   const int tiles = ((maxWo + 15) / 16) * ((maxHo + TH - 1) / TH), tpb = 8;
   dim3 grid((tiles + tpb - 1) / tpb, n_img);
-#define RT_LCT_T(CC, NN, TT, S1, S2) hipLaunchKernelGGL((k_lc_thin<CC, NN, TT, S1, S2>), grid, dim3(64 * TT), 0, st, x, gin, gout, C, Wd, bd, dw_act, dw_has_lab, dw_a, dw_c, Wp, N, Npad16, y, ldy, epi, tpb)
+#define RT_LCT_T(CC, NN, TT, S1, S2) RT_LAUNCH((k_lc_thin<CC, NN, TT, S1, S2>), grid, dim3(64 * TT), 0, st, x, gin, gout, C, Wd, bd, dw_act, dw_has_lab, dw_a, dw_c, Wp, N, Npad16, y, ldy, epi, tpb)
 #define RT_LCT(CC, NN) do { if (TH == 4) RT_LCT_T(CC, NN, 4, 1, 1); else RT_LCT_T(CC, NN, 8, 1, 1); } while (0)
-  if (g_lc_thin == 1) {  // producer / consumer waves on 64-pixel tiles
-    const int tiles4 = ((maxWo + 15) / 16) * ((maxHo + 3) / 4);
-    dim3 gridp((tiles4 + tpb - 1) / tpb, n_img);
-#define RT_LCP(CC, NN, S1, S2) hipLaunchKernelGGL((k_lc_thin_pc<CC, NN, S1, S2>), gridp, dim3(512), 0, st, x, gin, gout, C, Wd, bd, dw_act, dw_has_lab, dw_a, dw_c, Wp, N, Npad16, y, ldy, epi, tpb)
-    switch (code) {
-      case 1: RT_LCP(4, 1, 1, 1); return;
-      case 2: RT_LCP(8, 2, 1, 1); return;
-      case 3: RT_LCP(12, 2, 1, 1); return;
-      case 4: RT_LCP(16, 2, 1, 1); return;
-      case 6: RT_LCP(8, 2, 2, 2); return;
-      case 7: RT_LCP(12, 3, 2, 2); return;
-      default: break;
-    }
-#undef RT_LCP
-  }
   switch (code) {
     case 1: RT_LCT(4, 1); break;
     case 2: RT_LCT(8, 2); break;
@@ -1353,15 +718,6 @@ void lc_thin(hipStream_t st, int sh, int sw, const float* x, const ImgGeom* gin,
   }
 #undef RT_LCT
 #undef RT_LCT_T
-}
-
-static const float* zero_page() {
-  static float* z = nullptr;
-  if (!z) {
-    RT_HIP_CHECK(hipMalloc((void**)&z, 4096));
-    RT_HIP_CHECK(hipMemset(z, 0, 4096));
-  }
-  return z;
 }
 
 int g_gemm_variant = 0;  // 0 = production choice; others are forced by the kernel micro-benchmark
@@ -1409,7 +765,7 @@ __global__ __launch_bounds__(256) void k_argmax_merge(const float* __restrict__ 
 void argmax_merge(hipStream_t st, const float* pm, const int* pi, const float* ps, int tiles, long long rows, int* idx,
                   float* prob) {
   if (rows <= 0) return;
-  hipLaunchKernelGGL(k_argmax_merge, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, pm, pi, ps, tiles, rows, idx, prob);
+  RT_LAUNCH(k_argmax_merge, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, pm, pi, ps, tiles, rows, idx, prob);
 }
 
 int gemm_tile_rows(long long M, int Npad16) {
@@ -1427,13 +783,13 @@ void gemm(hipStream_t st, const float* A, int lda, long long M, int K, const flo
     if (epi.am_tiles != gemm_argmax_tiles(Npad16)) throw RtError(8, "gemm: am_tiles must be gemm_argmax_tiles(Npad16)");
     if (g_argmax_wide == 1) {
       dim3 grid((unsigned)((M + 255) / 256), (unsigned)((Npad16 + 239) / 240));
-      hipLaunchKernelGGL((k_gemm_wide<4, 5, 4, 3, 0, 0, 0, 1>), grid, dim3(768), 0, st, A, lda, M, K, Wp, N, Npad16, C, ldc, coff, epi);
+      RT_LAUNCH((k_gemm_wide<4, 5, 4, 3, 0, 0, 0, 1>), grid, dim3(768), 0, st, A, lda, M, K, Wp, N, Npad16, C, ldc, coff, epi);
     } else if (g_argmax_wide == 2) {
       dim3 grid((unsigned)((M + 127) / 128), (unsigned)((Npad16 + 127) / 128));
-      hipLaunchKernelGGL((k_gemm_wide<2, 4, 4, 2, 0, 0, 0, 1>), grid, dim3(512), 0, st, A, lda, M, K, Wp, N, Npad16, C, ldc, coff, epi);
+      RT_LAUNCH((k_gemm_wide<2, 4, 4, 2, 0, 0, 0, 1>), grid, dim3(512), 0, st, A, lda, M, K, Wp, N, Npad16, C, ldc, coff, epi);
     } else {  // narrow kernel, 128-column blocks
       dim3 grid((unsigned)((M + 127) / 128), (unsigned)((Npad16 + 127) / 128));
-      hipLaunchKernelGGL((k_gemm<8, 1>), grid, dim3(256), 0, st, A, lda, M, K, Wp, N, Npad16, C, ldc, coff, epi);
+      RT_LAUNCH((k_gemm<8, 1>), grid, dim3(256), 0, st, A, lda, M, K, Wp, N, Npad16, C, ldc, coff, epi);
     }
     return;
   }
@@ -1443,61 +799,25 @@ void gemm(hipStream_t st, const float* A, int lda, long long M, int K, const flo
     if (v == 0 && Npad16 >= 128) v = 8;
     if (v == 10) {
       dim3 grid((unsigned)((M + 127) / 128), (unsigned)((Npad16 + 239) / 240));
-      hipLaunchKernelGGL((k_gemm_wide<2, 5, 4, 3, 0, 0, 1>), grid, dim3(768), 0, st, A, lda, M, K, Wp, N, Npad16, C, ldc, coff, epi);
+      RT_LAUNCH((k_gemm_wide<2, 5, 4, 3, 0, 0, 1>), grid, dim3(768), 0, st, A, lda, M, K, Wp, N, Npad16, C, ldc, coff, epi);
     } else if (v == 8) {
       dim3 grid((unsigned)((M + 127) / 128), (unsigned)((Npad16 + 127) / 128));
-      hipLaunchKernelGGL((k_gemm_wide<2, 4, 4, 2, 0, 0, 1>), grid, dim3(512), 0, st, A, lda, M, K, Wp, N, Npad16, C, ldc, coff, epi);
+      RT_LAUNCH((k_gemm_wide<2, 4, 4, 2, 0, 0, 1>), grid, dim3(512), 0, st, A, lda, M, K, Wp, N, Npad16, C, ldc, coff, epi);
     } else {
       throw RtError(8, "gemm: a_scale is only implemented for the wide tiles");
     }
     return;
   }
-  if (v == 19) {  // A/B only: the 256 x 240 tile walked persistently needs > 168 VGPRs (171 spilled): 58 vs 93 TFLOP/s
-    long long nt = ((M + 255) / 256) * ((Npad16 + 239) / 240);
-    hipLaunchKernelGGL((k_gemm_persist<4, 5, 4, 3>), dim3((unsigned)std::min<long long>(nt, 256)), dim3(768), 0, st, A, lda, M, K, Wp, N, Npad16, C, ldc, coff, epi);
-    return;
-  }
-  if (v == 13 || v == 14) {
-    if (v == 13) {
-      long long nt = ((M + 127) / 128) * ((Npad16 + 239) / 240);
-      hipLaunchKernelGGL((k_gemm_persist<2, 5, 4, 3>), dim3((unsigned)std::min<long long>(nt, 256)), dim3(768), 0, st, A, lda, M, K, Wp, N, Npad16, C, ldc, coff, epi);
-    } else {
-      long long nt = ((M + 127) / 128) * ((Npad16 + 127) / 128);
-      hipLaunchKernelGGL((k_gemm_persist<2, 4, 4, 2>), dim3((unsigned)std::min<long long>(nt, 512)), dim3(512), 0, st, A, lda, M, K, Wp, N, Npad16, C, ldc, coff, epi);
-    }
-    return;
-  }
-  if (v == 12) {
-    dim3 grid((unsigned)((M + 127) / 128), (unsigned)((Npad16 + 255) / 256));
-    hipLaunchKernelGGL((k_gemm_dma<3>), grid, dim3(512), 0, st, A, lda, M, K, Wp, N, Npad16, C, ldc, coff, epi, zero_page());
-    return;
-  }
-  if (v == 4) {
-    dim3 grid((unsigned)((M + 127) / 128), (unsigned)((Npad16 + 127) / 128));
-    hipLaunchKernelGGL(k_gemm_32, grid, dim3(256), 0, st, A, lda, M, K, Wp, N, Npad16, C, ldc, coff, epi);
-    return;
-  }
-  if (v == 3) {
-    dim3 grid((unsigned)((M + 127) / 128), (unsigned)((Npad16 + 127) / 128));
-    hipLaunchKernelGGL((k_gemm_wide<4, 4, 2, 2>), grid, dim3(256), 0, st, A, lda, M, K, Wp, N, Npad16, C, ldc, coff, epi);
-    return;
-  }
-  if (v == 6 || v == 7) {
-    dim3 grid((unsigned)((M + 127) / 128), (unsigned)((Npad16 + 127) / 128));
-    if (v == 6) hipLaunchKernelGGL((k_gemm_wide<4, 4, 2, 2, 0, 1>), grid, dim3(256), 0, st, A, lda, M, K, Wp, N, Npad16, C, ldc, coff, epi);
-    else hipLaunchKernelGGL((k_gemm_wide<4, 4, 2, 2, 0, 2>), grid, dim3(256), 0, st, A, lda, M, K, Wp, N, Npad16, C, ldc, coff, epi);
-    return;
-  }
   if (v == 8) {
     dim3 grid((unsigned)((M + 127) / 128), (unsigned)((Npad16 + 127) / 128));
-    hipLaunchKernelGGL((k_gemm_wide<2, 4, 4, 2>), grid, dim3(512), 0, st, A, lda, M, K, Wp, N, Npad16, C, ldc, coff, epi);
+    RT_LAUNCH((k_gemm_wide<2, 4, 4, 2>), grid, dim3(512), 0, st, A, lda, M, K, Wp, N, Npad16, C, ldc, coff, epi);
     return;
   }
   if ((v == 20 && Npad16 <= 128 && K <= 128) || (v == 0 && !g_gemm_variant && Npad16 <= 64 && K <= 64 && M >= 65536)) {  // streaming kernel for the thin layers
     const int ntl = Npad16 / 16, kg = (K + 15) / 16;
     const long long tiles = (M + 31) / 32;
     const unsigned blocks = (unsigned)std::min<long long>((tiles + 3) / 4, 256 * 8);
-#define RT_GS(NTV, KGV) hipLaunchKernelGGL((k_gemm_stream<NTV, KGV>), dim3(blocks), dim3(256), 0, st, A, lda, M, K, Wp, N, Npad16, C, ldc, coff, epi)
+#define RT_GS(NTV, KGV) RT_LAUNCH((k_gemm_stream<NTV, KGV>), dim3(blocks), dim3(256), 0, st, A, lda, M, K, Wp, N, Npad16, C, ldc, coff, epi)
 #define RT_GS_K(NTV) do { if (kg <= 1) RT_GS(NTV, 1); else if (kg <= 2) RT_GS(NTV, 2); else if (kg <= 4) RT_GS(NTV, 4); else if (kg <= 6) RT_GS(NTV, 6); else RT_GS(NTV, 8); } while (0)
     if (ntl <= 1) RT_GS_K(1); else if (ntl <= 2) RT_GS_K(2); else if (ntl <= 3) RT_GS_K(3); else if (ntl <= 4) RT_GS_K(4);
     else if (ntl <= 6) RT_GS_K(6); else RT_GS_K(8);
@@ -1505,52 +825,14 @@ void gemm(hipStream_t st, const float* A, int lda, long long M, int K, const flo
 #undef RT_GS
     return;
   }
-  if (v == 18) {  // 2 workgroups per CU x 4 fat waves (32 rows x 240 columns each)
-    dim3 grid((unsigned)((M + 127) / 128), (unsigned)((Npad16 + 239) / 240));
-    hipLaunchKernelGGL((k_gemm_wide<2, 15, 4, 1>), grid, dim3(256), 0, st, A, lda, M, K, Wp, N, Npad16, C, ldc, coff, epi);
-    return;
-  }
-  if (v == 16 || v == 17) {
-    dim3 grid((unsigned)((M + (v == 16 ? 255 : 127)) / (v == 16 ? 256 : 128)), (unsigned)((Npad16 + 239) / 240));
-    if (v == 16) hipLaunchKernelGGL((k_gemm_wide<4, 5, 4, 3, 0, 0, 0, 0, 1>), grid, dim3(768), 0, st, A, lda, M, K, Wp, N, Npad16, C, ldc, coff, epi);
-    else hipLaunchKernelGGL((k_gemm_wide<2, 5, 4, 3, 0, 0, 0, 0, 1>), grid, dim3(768), 0, st, A, lda, M, K, Wp, N, Npad16, C, ldc, coff, epi);
-    return;
-  }
   if (v == 15) {
     dim3 grid((unsigned)((M + 255) / 256), (unsigned)((Npad16 + 239) / 240));
-    hipLaunchKernelGGL((k_gemm_wide<4, 5, 4, 3>), grid, dim3(768), 0, st, A, lda, M, K, Wp, N, Npad16, C, ldc, coff, epi);
+    RT_LAUNCH((k_gemm_wide<4, 5, 4, 3>), grid, dim3(768), 0, st, A, lda, M, K, Wp, N, Npad16, C, ldc, coff, epi);
     return;
   }
   if (v == 10) {
     dim3 grid((unsigned)((M + 127) / 128), (unsigned)((Npad16 + 239) / 240));
-    hipLaunchKernelGGL((k_gemm_wide<2, 5, 4, 3>), grid, dim3(768), 0, st, A, lda, M, K, Wp, N, Npad16, C, ldc, coff, epi);
-    return;
-  }
-  if (v == 11) {
-    dim3 grid((unsigned)((M + 63) / 64), (unsigned)((Npad16 + 239) / 240));
-    hipLaunchKernelGGL((k_gemm_wide<2, 5, 2, 3>), grid, dim3(384), 0, st, A, lda, M, K, Wp, N, Npad16, C, ldc, coff, epi);
-    return;
-  }
-  if (v == 9) {
-    dim3 grid((unsigned)((M + 63) / 64), (unsigned)((Npad16 + 127) / 128));
-    hipLaunchKernelGGL((k_gemm_wide<2, 4, 2, 2>), grid, dim3(256), 0, st, A, lda, M, K, Wp, N, Npad16, C, ldc, coff, epi);
-    return;
-  }
-  if (v == 5) {
-    long long mblocks = (M + 127) / 128; int ncol = (Npad16 + 127) / 128;
-    dim3 grid((unsigned)(((mblocks + 7) / 8) * 8 * ncol));
-    hipLaunchKernelGGL((k_gemm_wide<4, 4, 2, 2, 1>), grid, dim3(256), 0, st, A, lda, M, K, Wp, N, Npad16, C, ldc, coff, epi);
-    return;
-  }
-  if (v == 2) {
-    int waste240 = round_up(Npad16, 240) - Npad16, waste192 = round_up(Npad16, 192) - Npad16;
-    if (waste240 <= waste192) {
-      dim3 grid((unsigned)((M + 127) / 128), (unsigned)((Npad16 + 239) / 240));
-      hipLaunchKernelGGL((k_gemm_wide<4, 5, 2, 3>), grid, dim3(384), 0, st, A, lda, M, K, Wp, N, Npad16, C, ldc, coff, epi);
-    } else {
-      dim3 grid((unsigned)((M + 127) / 128), (unsigned)((Npad16 + 191) / 192));
-      hipLaunchKernelGGL((k_gemm_wide<4, 4, 2, 3>), grid, dim3(384), 0, st, A, lda, M, K, Wp, N, Npad16, C, ldc, coff, epi);
-    }
+    RT_LAUNCH((k_gemm_wide<2, 5, 4, 3>), grid, dim3(768), 0, st, A, lda, M, K, Wp, N, Npad16, C, ldc, coff, epi);
     return;
   }
   int ntiles = Npad16 / 16;
@@ -1565,7 +847,7 @@ void gemm(hipStream_t st, const float* A, int lda, long long M, int K, const flo
   }
   dim3 grid((unsigned)((M + 127) / 128), (unsigned)((ntiles + NT - 1) / NT));
 #define RT_GEMM_CASE(n) \
-  case n: hipLaunchKernelGGL(k_gemm<n>, grid, dim3(256), 0, st, A, lda, M, K, Wp, N, Npad16, C, ldc, coff, epi); break;
+  case n: RT_LAUNCH(k_gemm<n>, grid, dim3(256), 0, st, A, lda, M, K, Wp, N, Npad16, C, ldc, coff, epi); break;
   switch (NT) {
     RT_GEMM_CASE(1) RT_GEMM_CASE(2) RT_GEMM_CASE(3) RT_GEMM_CASE(4) RT_GEMM_CASE(5) RT_GEMM_CASE(6) RT_GEMM_CASE(7)
     RT_GEMM_CASE(8)
@@ -1675,17 +957,17 @@ void conv_sp(hipStream_t st, int KH, int KW, const float* x, int ldx, const ImgG
     int NT = ntiles >= 2 ? 2 : 1;
     dim3 grid(((maxW + 15) / 16) * ((maxH + 7) / 8), n_img, (ntiles + NT - 1) / NT);
     if (NT == 2)
-      hipLaunchKernelGGL((k_conv_sp<3, 3, 8, 16, 2>), grid, dim3(256), 0, st, x, ldx, geom, Cin, Wp, N, Npad16, y, ldy,
+      RT_LAUNCH((k_conv_sp<3, 3, 8, 16, 2>), grid, dim3(256), 0, st, x, ldx, geom, Cin, Wp, N, Npad16, y, ldy,
                          epi);
     else
-      hipLaunchKernelGGL((k_conv_sp<3, 3, 8, 16, 1>), grid, dim3(256), 0, st, x, ldx, geom, Cin, Wp, N, Npad16, y, ldy,
+      RT_LAUNCH((k_conv_sp<3, 3, 8, 16, 1>), grid, dim3(256), 0, st, x, ldx, geom, Cin, Wp, N, Npad16, y, ldy,
                          epi);
   } else if (KH == 1 && KW == 3) {
     int NT = ntiles >= 4 ? 4 : ntiles;
     dim3 grid(((maxW + 127) / 128) * maxH, n_img, (ntiles + NT - 1) / NT);
 #define RT_C13(n)                                                                                                   \
   case n:                                                                                                           \
-    hipLaunchKernelGGL((k_conv_sp<1, 3, 1, 128, n>), grid, dim3(256), 0, st, x, ldx, geom, Cin, Wp, N, Npad16, y, ldy, \
+    RT_LAUNCH((k_conv_sp<1, 3, 1, 128, n>), grid, dim3(256), 0, st, x, ldx, geom, Cin, Wp, N, Npad16, y, ldy, \
                        epi);                                                                                        \
     break;
     switch (NT) { RT_C13(1) RT_C13(2) RT_C13(3) RT_C13(4) }
@@ -1696,158 +978,6 @@ void conv_sp(hipStream_t st, int KH, int KW, const float* x, int ldx, const ImgG
 }
 
 // ---------------------------------------------------------------------------
-// Depthwise conv: HBM/L2 bound. Thread = (output pixel, 4 channels).
-// ---------------------------------------------------------------------------
-template <int K>
-__global__ __launch_bounds__(256) void k_dwconv(int sh, int sw, const float* __restrict__ x,
-                                                const ImgGeom* __restrict__ gin, const ImgGeom* __restrict__ gout,
-                                                int Cp, const float* __restrict__ Wd, const float* __restrict__ bias,
-                                                int act, int has_lab, float lab_a, float lab_c, float* __restrict__ y) {
-  const ImgGeom gi = gin[blockIdx.y], go = gout[blockIdx.y];
-  const int C4 = Cp >> 2;
-  long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
-  long long total = (long long)go.H * go.W * C4;
-  if (idx >= total) return;
-  int c4 = (int)(idx % C4);
-  long long p = idx / C4;
-  int oy = (int)(p / go.W), ox = (int)(p % go.W);
-  f32x4 acc = *reinterpret_cast<const f32x4*>(bias + c4 * 4);
-  const int iy0 = oy * sh - K / 2, ix0 = ox * sw - K / 2;
-#pragma unroll
-  for (int dy = 0; dy < K; dy++) {
-    int iy = iy0 + dy;
-    if (iy < 0 || iy >= gi.H) continue;
-#pragma unroll
-    for (int dx = 0; dx < K; dx++) {
-      int ix = ix0 + dx;
-      if (ix < 0 || ix >= gi.W) continue;
-      f32x4 v = *reinterpret_cast<const f32x4*>(x + (gi.off + (long long)iy * gi.W + ix) * Cp + c4 * 4);
-      f32x4 w = *reinterpret_cast<const f32x4*>(Wd + (dy * K + dx) * Cp + c4 * 4);
-#pragma unroll
-      for (int j = 0; j < 4; j++) acc[j] = fmaf(v[j], w[j], acc[j]);
-    }
-  }
-  f32x4 o;
-#pragma unroll
-  for (int j = 0; j < 4; j++) {
-    float t = act_apply(acc[j], act);
-    if (has_lab) t = fmaf(t, lab_a, lab_c);
-    o[j] = t;
-  }
-  *reinterpret_cast<f32x4*>(y + (go.off + p) * Cp + c4 * 4) = o;
-}
-
-// Stride-1 variant: a thread produces a strip of 4 consecutive output pixels (x 4 channels),
-// sliding the K x (K+3) input window through registers: K*(K+3) 16-byte loads per 4 outputs
-// instead of 4*K*K.
-template <int K>
-__global__ __launch_bounds__(256) void k_dwconv_s1(const float* __restrict__ x, const ImgGeom* __restrict__ geom, int Cp,
-                                                   const float* __restrict__ Wd, const float* __restrict__ bias, int act,
-                                                   int has_lab, float lab_a, float lab_c, float* __restrict__ y) {
-  const ImgGeom g = geom[blockIdx.y];
-  const int C4 = Cp >> 2, strips = (g.W + 3) >> 2;
-  long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= (long long)g.H * strips * C4) return;
-  int c4 = (int)(idx % C4);
-  long long s = idx / C4;
-  int oy = (int)(s / strips), ox0 = (int)(s % strips) * 4;
-  const f32x4 b = *reinterpret_cast<const f32x4*>(bias + c4 * 4);
-  f32x4 acc[4] = {b, b, b, b};
-#pragma unroll
-  for (int dy = 0; dy < K; dy++) {
-    int iy = oy + dy - K / 2;
-    if (iy < 0 || iy >= g.H) continue;
-    const float* row = x + (g.off + (long long)iy * g.W) * Cp + c4 * 4;
-    f32x4 v[K + 3];
-#pragma unroll
-    for (int j = 0; j < K + 3; j++) {
-      int ix = ox0 + j - K / 2;
-      v[j] = (ix >= 0 && ix < g.W) ? *reinterpret_cast<const f32x4*>(row + (long long)ix * Cp) : f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-#pragma unroll
-    for (int dx = 0; dx < K; dx++) {
-      f32x4 w = *reinterpret_cast<const f32x4*>(Wd + (dy * K + dx) * Cp + c4 * 4);
-#pragma unroll
-      for (int j = 0; j < 4; j++)
-#pragma unroll
-        for (int e = 0; e < 4; e++) acc[j][e] = fmaf(v[j + dx][e], w[e], acc[j][e]);
-    }
-  }
-#pragma unroll
-  for (int j = 0; j < 4; j++) {
-    if (ox0 + j >= g.W) break;
-    f32x4 o;
-#pragma unroll
-    for (int e = 0; e < 4; e++) {
-      float t = act_apply(acc[j][e], act);
-      if (has_lab) t = fmaf(t, lab_a, lab_c);
-      o[e] = t;
-    }
-    *reinterpret_cast<f32x4*>(y + (g.off + (long long)oy * g.W + ox0 + j) * Cp + c4 * 4) = o;
-  }
-}
-
-// Stride-1, LDS-tiled variant: a block stages the halo tile of a 32-channel slab once in LDS
-// (each input element leaves L2 ~(TH+K-1)(TW+K-1)/(TH*TW) times instead of K*(K+3)/4 times),
-// then every thread produces a 1x4 output strip x 4 channels from LDS.
-// Block = 256 threads = CG channel groups x 8 strips x TH rows, tile TH x 32 pixels.
-template <int K, int CG>
-__global__ __launch_bounds__(256) void k_dwconv_lds(const float* __restrict__ x, const ImgGeom* __restrict__ geom, int Cp,
-                                                    const float* __restrict__ Wd, const float* __restrict__ bias, int act,
-                                                    int has_lab, float lab_a, float lab_c, float* __restrict__ y) {
-  constexpr int TH = 256 / (CG * 8), TW = 32, HH = TH + K - 1, HW = TW + K - 1, PS = CG * 4 + 4;  // padded pixel stride
-  __shared__ __attribute__((aligned(16))) float tile[HH * HW * PS];
-  const ImgGeom g = geom[blockIdx.y];
-  const int tiles_x = (g.W + TW - 1) / TW, tiles_y = (g.H + TH - 1) / TH;
-  if ((int)blockIdx.x >= tiles_x * tiles_y) return;
-  const int ty0 = (blockIdx.x / tiles_x) * TH, tx0 = (blockIdx.x % tiles_x) * TW;
-  const int cbase = blockIdx.z * CG * 4;  // first channel of this slab
-  const int tid = threadIdx.x;
-  for (int idx = tid; idx < HH * HW * CG; idx += 256) {
-    int hp = idx / CG, c4 = idx % CG;
-    int gy = ty0 + hp / HW - K / 2, gx = tx0 + hp % HW - K / 2;
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (gy >= 0 && gy < g.H && gx >= 0 && gx < g.W && cbase + c4 * 4 < Cp)
-      v = *reinterpret_cast<const f32x4*>(x + (g.off + (long long)gy * g.W + gx) * Cp + cbase + c4 * 4);
-    *reinterpret_cast<f32x4*>(tile + hp * PS + c4 * 4) = v;
-  }
-  __syncthreads();
-  const int c4 = tid % CG, sx = (tid / CG) % 8, ty = tid / (CG * 8);
-  const int ch = cbase + c4 * 4;
-  if (ch >= Cp) return;
-  const int oy = ty0 + ty, ox0 = tx0 + sx * 4;
-  if (oy >= g.H || ox0 >= g.W) return;
-  const f32x4 b = *reinterpret_cast<const f32x4*>(bias + ch);
-  f32x4 acc[4] = {b, b, b, b};
-#pragma unroll
-  for (int dy = 0; dy < K; dy++) {
-    const float* row = tile + ((ty + dy) * HW + sx * 4) * PS + c4 * 4;
-    f32x4 v[K + 3];
-#pragma unroll
-    for (int j = 0; j < K + 3; j++) v[j] = *reinterpret_cast<const f32x4*>(row + j * PS);
-#pragma unroll
-    for (int dx = 0; dx < K; dx++) {
-      f32x4 w = *reinterpret_cast<const f32x4*>(Wd + (dy * K + dx) * Cp + ch);
-#pragma unroll
-      for (int j = 0; j < 4; j++)
-#pragma unroll
-        for (int e = 0; e < 4; e++) acc[j][e] = fmaf(v[j + dx][e], w[e], acc[j][e]);
-    }
-  }
-#pragma unroll
-  for (int j = 0; j < 4; j++) {
-    if (ox0 + j >= g.W) break;
-    f32x4 o;
-#pragma unroll
-    for (int e = 0; e < 4; e++) {
-      float t = act_apply(acc[j][e], act);
-      if (has_lab) t = fmaf(t, lab_a, lab_c);
-      o[e] = t;
-    }
-    *reinterpret_cast<f32x4*>(y + (g.off + (long long)oy * g.W + ox0 + j) * Cp + ch) = o;
-  }
-}
-
 // Row-streaming depthwise conv, strides (SH, SW) in {1,2}: a thread owns an R-row x 4-pixel output
 // patch of 4 channels and streams the (R-1)*SH+K input rows through registers once (K=5, R=4,
 // stride 1: 4 16-byte loads per output instead of 25), with the KxK weights of the block's
@@ -1990,14 +1120,13 @@ static int dw_strip_rows(int sh, int maxHo) {
   if (g_dw_variant == 4) return 2;
   if (maxHo == 6 || (maxHo == 3 && sh == 1)) return 3;  // (stride 2 onto 3 rows: 2-row strips measured faster)
   return sh == 1 ? 4 : 2;
-}  // 0 = production; 1 = generic; 2 = register strip; 3 = LDS tile; 4 = row streaming
-int g_fuse_dwpw = 0;  // experimental: correct, but producer-latency bound; off by default
+}
 
 void dwconv(hipStream_t st, int K, int sh, int sw, const float* x, const ImgGeom* gin, const ImgGeom* gout, int n_img,
             int maxHo, int maxWo, int Cp, int C, const float* Wd, const float* bias, int act, int has_lab, float lab_a,
             float lab_c, float* y, float* pool) {
   if (n_img <= 0) return;
-  if ((K == 3 || K == 5) && sh >= 1 && sh <= 2 && sw >= 1 && sw <= 2 && (g_dw_variant == 0 || g_dw_variant == 4)) {
+  if ((K == 3 || K == 5) && sh >= 1 && sh <= 2 && sw >= 1 && sw <= 2 && (g_dw_variant == 0 || g_dw_variant == 4)) {  // 4 = 2-row strips (A/B)
     const int R = dw_strip_rows(sh, maxHo);  // input rows streamed: stride 1 -> R+K-1, stride 2 -> 2R+K-2
     long long strips = (long long)((maxWo + 3) / 4) * ((maxHo + R - 1) / R);
     // 64- / 128-channel slabs (256 / 512 contiguous bytes per pixel and load) for wide tensors: the 5x5 kernel on
@@ -2008,8 +1137,8 @@ void dwconv(hipStream_t st, int K, int sh, int sw, const float* x, const ImgGeom
       dim3 gridw((unsigned)((strips + spb - 1) / spb), n_img, (Cp + lp * 4 - 1) / (lp * 4));
 #define RT_DWW(KK, RR, SH_, SW_, LL)                                                                                         \
   do {                                                                                                                       \
-    if (pool) hipLaunchKernelGGL((k_dwconv_rows<KK, RR, SH_, SW_, 1, LL>), gridw, dim3(256), 0, st, x, gin, gout, Cp, C, Wd, bias, act, has_lab, lab_a, lab_c, y, pool); \
-    else hipLaunchKernelGGL((k_dwconv_rows<KK, RR, SH_, SW_, 0, LL>), gridw, dim3(256), 0, st, x, gin, gout, Cp, C, Wd, bias, act, has_lab, lab_a, lab_c, y, pool); \
+    if (pool) RT_LAUNCH((k_dwconv_rows<KK, RR, SH_, SW_, 1, LL>), gridw, dim3(256), 0, st, x, gin, gout, Cp, C, Wd, bias, act, has_lab, lab_a, lab_c, y, pool); \
+    else RT_LAUNCH((k_dwconv_rows<KK, RR, SH_, SW_, 0, LL>), gridw, dim3(256), 0, st, x, gin, gout, Cp, C, Wd, bias, act, has_lab, lab_a, lab_c, y, pool); \
   } while (0)
 #define RT_DWW_L(KK, RR, SH_, SW_) do { if (lp == 16) RT_DWW(KK, RR, SH_, SW_, 16); else RT_DWW(KK, RR, SH_, SW_, 32); } while (0)
       if (K == 5 && sh == 1 && sw == 1 && R == 4) { RT_DWW_L(5, 4, 1, 1); return; }
@@ -2026,8 +1155,8 @@ void dwconv(hipStream_t st, int K, int sh, int sw, const float* x, const ImgGeom
     dim3 grid((unsigned)((strips + 31) / 32), n_img, (Cp + 31) / 32);
 #define RT_DWR(KK, RR, SH_, SW_)                                                                                              \
   do {                                                                                                                       \
-    if (pool) hipLaunchKernelGGL((k_dwconv_rows<KK, RR, SH_, SW_, 1>), grid, dim3(256), 0, st, x, gin, gout, Cp, C, Wd, bias, act, has_lab, lab_a, lab_c, y, pool); \
-    else hipLaunchKernelGGL((k_dwconv_rows<KK, RR, SH_, SW_, 0>), grid, dim3(256), 0, st, x, gin, gout, Cp, C, Wd, bias, act, has_lab, lab_a, lab_c, y, pool); \
+    if (pool) RT_LAUNCH((k_dwconv_rows<KK, RR, SH_, SW_, 1>), grid, dim3(256), 0, st, x, gin, gout, Cp, C, Wd, bias, act, has_lab, lab_a, lab_c, y, pool); \
+    else RT_LAUNCH((k_dwconv_rows<KK, RR, SH_, SW_, 0>), grid, dim3(256), 0, st, x, gin, gout, Cp, C, Wd, bias, act, has_lab, lab_a, lab_c, y, pool); \
   } while (0)
     const int code = (K == 5 ? 4 : 0) + (sh == 2 ? 2 : 0) + (sw == 2 ? 1 : 0);
 #define RT_DWR_R(KK, SH_, SW_, RBIG) \
@@ -2042,36 +1171,7 @@ void dwconv(hipStream_t st, int K, int sh, int sw, const float* x, const ImgGeom
 #undef RT_DWR
     return;
   }
-  if (Cp - C >= 4 || pool) throw RtError(8, "dwconv: only the row-streaming kernel supports padded channel pitches / fused pooling");
-  if (sh == 1 && sw == 1 && (K == 3 || K == 5) && g_dw_variant == 3 && Cp >= 16) {  // measured slower than the register strip (tools/), kept for A/B
-    const bool c8 = Cp >= 32;
-    const int TH = c8 ? 4 : 8, CB = c8 ? 32 : 16;
-    dim3 grid(((maxWo + 31) / 32) * ((maxHo + TH - 1) / TH), n_img, (Cp + CB - 1) / CB);
-#define RT_DWL(KK, CG) hipLaunchKernelGGL((k_dwconv_lds<KK, CG>), grid, dim3(256), 0, st, x, gout, Cp, Wd, bias, act, has_lab, lab_a, lab_c, y)
-    if (K == 3) { if (c8) RT_DWL(3, 8); else RT_DWL(3, 4); }
-    else { if (c8) RT_DWL(5, 8); else RT_DWL(5, 4); }
-#undef RT_DWL
-    return;
-  }
-  if (sh == 1 && sw == 1 && (K == 3 || K == 5) && g_dw_variant != 1) {
-    long long total = (long long)maxHo * ((maxWo + 3) / 4) * (Cp / 4);
-    dim3 grid((unsigned)((total + 255) / 256), n_img);
-    if (K == 3)
-      hipLaunchKernelGGL(k_dwconv_s1<3>, grid, dim3(256), 0, st, x, gout, Cp, Wd, bias, act, has_lab, lab_a, lab_c, y);
-    else
-      hipLaunchKernelGGL(k_dwconv_s1<5>, grid, dim3(256), 0, st, x, gout, Cp, Wd, bias, act, has_lab, lab_a, lab_c, y);
-    return;
-  }
-  long long total = (long long)maxHo * maxWo * (Cp / 4);
-  dim3 grid((unsigned)((total + 255) / 256), n_img);
-  if (K == 3)
-    hipLaunchKernelGGL(k_dwconv<3>, grid, dim3(256), 0, st, sh, sw, x, gin, gout, Cp, Wd, bias, act, has_lab, lab_a,
-                       lab_c, y);
-  else if (K == 5)
-    hipLaunchKernelGGL(k_dwconv<5>, grid, dim3(256), 0, st, sh, sw, x, gin, gout, Cp, Wd, bias, act, has_lab, lab_a,
-                       lab_c, y);
-  else
-    throw RtError(8, "dwconv: unsupported kernel size");
+  throw RtError(8, "dwconv: unsupported kernel size / stride");
 }
 
 // ---------------------------------------------------------------------------
@@ -2180,7 +1280,7 @@ void stem_conv_u8(hipStream_t st, const U8Page* pages, float scale, const float*
   if (n_img <= 0) return;
   if (COUT != 16) throw RtError(8, "stem_conv_u8: unsupported COUT");
   dim3 grid((unsigned)(((long long)maxHo * maxWo + 255) / 256), n_img);
-  hipLaunchKernelGGL(k_stem_u8<16>, grid, dim3(256), 0, st, pages, scale, mean3[0], mean3[1], mean3[2], std3[0], std3[1],
+  RT_LAUNCH(k_stem_u8<16>, grid, dim3(256), 0, st, pages, scale, mean3[0], mean3[1], mean3[2], std3[0], std3[1],
                      std3[2], gin, gout, Ws, bias, act, y);
 }
 
@@ -2188,8 +1288,8 @@ void stem_conv(hipStream_t st, const float* x, const ImgGeom* gin, const ImgGeom
                int COUT, const float* Ws, const float* bias, int act, float* y) {
   if (n_img <= 0) return;
   dim3 grid((unsigned)(((long long)maxHo * maxWo + 255) / 256), n_img);
-  if (COUT == 16) hipLaunchKernelGGL(k_stem<16>, grid, dim3(256), 0, st, x, gin, gout, Ws, bias, act, y);
-  else if (COUT == 8) hipLaunchKernelGGL(k_stem<8>, grid, dim3(256), 0, st, x, gin, gout, Ws, bias, act, y);
+  if (COUT == 16) RT_LAUNCH(k_stem<16>, grid, dim3(256), 0, st, x, gin, gout, Ws, bias, act, y);
+  else if (COUT == 8) RT_LAUNCH(k_stem<8>, grid, dim3(256), 0, st, x, gin, gout, Ws, bias, act, y);
   else throw RtError(8, "stem_conv: unsupported COUT");
 }
 
@@ -2205,7 +1305,7 @@ __global__ void k_nchw3_to_nhwc4(const float* __restrict__ in, int n, int H, int
 void nchw3_to_nhwc4(hipStream_t st, const float* in, int n, int H, int W, float* out) {
   long long total = (long long)n * H * W;
   if (total <= 0) return;
-  hipLaunchKernelGGL(k_nchw3_to_nhwc4, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, in, n, H, W, out);
+  RT_LAUNCH(k_nchw3_to_nhwc4, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, in, n, H, W, out);
 }
 
 // ---------------------------------------------------------------------------
@@ -2314,8 +1414,8 @@ void se_scale(hipStream_t st, const float* x, const ImgGeom* geom, int n_img, lo
               float* partial, float* scale) {
   if (n_img <= 0) return;
   int chunks = pool_chunks(max_pix);
-  hipLaunchKernelGGL(k_pool_partial, dim3(chunks, n_img), dim3(256), 0, st, x, geom, Cp, chunks, partial);
-  hipLaunchKernelGGL(k_se_fc, dim3(n_img), dim3(256), (Cp + Cr + 4) * sizeof(float), st, partial, geom, chunks, C, Cp,
+  RT_LAUNCH(k_pool_partial, dim3(chunks, n_img), dim3(256), 0, st, x, geom, Cp, chunks, partial);
+  RT_LAUNCH(k_se_fc, dim3(n_img), dim3(256), (Cp + Cr + 4) * sizeof(float), st, partial, geom, chunks, C, Cp,
                      w1, b1, w2, b2, Cr, slope, residual, scale, 0, 32, (const float*)nullptr, 0, 0);
 }
 void se_scale_projected(hipStream_t st, const float* x_in, const ImgGeom* geom, int n_img, long long max_pix, int Cin,
@@ -2323,8 +1423,8 @@ void se_scale_projected(hipStream_t st, const float* x_in, const ImgGeom* geom, 
                         const float* b2, int Cr, float slope, int residual, float* partial, float* scale) {
   if (n_img <= 0) return;
   int chunks = pool_chunks(max_pix);
-  hipLaunchKernelGGL(k_pool_partial, dim3(chunks, n_img), dim3(256), 0, st, x_in, geom, Cin_p, chunks, partial);
-  hipLaunchKernelGGL(k_se_fc, dim3(n_img), dim3(256), (Cp + Cr + 4 + Cin_p + 4) * sizeof(float), st, partial, geom, chunks, C, Cp,
+  RT_LAUNCH(k_pool_partial, dim3(chunks, n_img), dim3(256), 0, st, x_in, geom, Cin_p, chunks, partial);
+  RT_LAUNCH(k_se_fc, dim3(n_img), dim3(256), (Cp + Cr + 4 + Cin_p + 4) * sizeof(float), st, partial, geom, chunks, C, Cp,
                      w1, b1, w2, b2, Cr, slope, residual, scale, 0, 32, Wlin, Cin, Cin_p);
 }
 // Lanes side by side on a pixel in k_dwconv_rows for this layer: 16 / 32 (64- / 128-channel slabs) where the tensor is
@@ -2350,15 +1450,15 @@ void se_fc_from_dw(hipStream_t st, const float* partial, const ImgGeom* geom, in
                    int strips_per_block, int C, int Cp, const float* w1, const float* b1, const float* w2, const float* b2,
                    int Cr, float slope, int residual, float* scale) {
   if (n_img <= 0) return;
-  hipLaunchKernelGGL(k_se_fc, dim3(n_img), dim3(256), (Cp + Cr + 4) * sizeof(float), st, partial, geom, chunks, C, Cp,
+  RT_LAUNCH(k_se_fc, dim3(n_img), dim3(256), (Cp + Cr + 4) * sizeof(float), st, partial, geom, chunks, C, Cp,
                      w1, b1, w2, b2, Cr, slope, residual, scale, strip_R, strips_per_block, (const float*)nullptr, 0, 0);
 }
 void global_mean(hipStream_t st, const float* x, const ImgGeom* geom, int n_img, long long max_pix, int Cp,
                  float* partial, float* out) {
   if (n_img <= 0) return;
   int chunks = pool_chunks(max_pix);
-  hipLaunchKernelGGL(k_pool_partial, dim3(chunks, n_img), dim3(256), 0, st, x, geom, Cp, chunks, partial);
-  hipLaunchKernelGGL(k_se_fc, dim3(n_img), dim3(256), (Cp + 4) * sizeof(float), st, partial, geom, chunks, Cp, Cp,
+  RT_LAUNCH(k_pool_partial, dim3(chunks, n_img), dim3(256), 0, st, x, geom, Cp, chunks, partial);
+  RT_LAUNCH(k_se_fc, dim3(n_img), dim3(256), (Cp + 4) * sizeof(float), st, partial, geom, chunks, Cp, Cp,
                      (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, 0,
                      0.f, 0, out, 0, 32, (const float*)nullptr, 0, 0);
 }
@@ -2380,7 +1480,7 @@ void scale_channels(hipStream_t st, float* x, const ImgGeom* geom, int n_img, lo
                     const float* scale) {
   if (n_img <= 0) return;
   long long total = max_pix * (Cp / 4);
-  hipLaunchKernelGGL(k_scale_channels, dim3((unsigned)((total + 255) / 256), n_img), dim3(256), 0, st, x, geom, Cp,
+  RT_LAUNCH(k_scale_channels, dim3((unsigned)((total + 255) / 256), n_img), dim3(256), 0, st, x, geom, Cp,
                      scale);
 }
 
@@ -2443,7 +1543,7 @@ void lateral_add(hipStream_t st, const float* x, int Cin, int Cin_p, const float
                  const float* b, const ImgGeom* ga, const ImgGeom* gb, int n_img, long long max_pix, float* out) {
   if (n_img <= 0) return;
   long long total = ((max_pix + 3) / 4) * (C / 4);  // 4 pixels per thread
-  hipLaunchKernelGGL(k_lateral_add, dim3((unsigned)((total + 255) / 256), n_img), dim3(256), (size_t)Cin * C * sizeof(float), st,
+  RT_LAUNCH(k_lateral_add, dim3((unsigned)((total + 255) / 256), n_img), dim3(256), (size_t)Cin * C * sizeof(float), st,
                      x, Cin, Cin_p, Wlin, C, scale, b, ga, gb, out);
 }
 
@@ -2469,7 +1569,7 @@ void upsample_add(hipStream_t st, const float* a, const float* b, const ImgGeom*
                   long long max_pix, int Cp, float* out, const float* scale_a) {
   if (n_img <= 0) return;
   long long total = max_pix * (Cp / 4);
-  hipLaunchKernelGGL(k_upsample_add, dim3((unsigned)((total + 255) / 256), n_img), dim3(256), 0, st, a, b, ga, gb, Cp,
+  RT_LAUNCH(k_upsample_add, dim3((unsigned)((total + 255) / 256), n_img), dim3(256), 0, st, a, b, ga, gb, Cp,
                      out, scale_a);
 }
 
@@ -2507,7 +1607,7 @@ void fpn_concat(hipStream_t st, const float* p5, const float* p4, const float* p
   if (n_img <= 0) return;
   long long total = max_pix * Cq;  // 4 levels * Cq/4 groups
   const float* nul = nullptr;
-  hipLaunchKernelGGL(k_fpn_concat, dim3((unsigned)((total + 255) / 256), n_img), dim3(256), 0, st, p5, p4, p3, p2, g5,
+  RT_LAUNCH(k_fpn_concat, dim3((unsigned)((total + 255) / 256), n_img), dim3(256), 0, st, p5, p4, p3, p2, g5,
                      g4, g3, g2, Cq, out, scales ? scales[0] : nul, scales ? scales[1] : nul, scales ? scales[2] : nul,
                      scales ? scales[3] : nul);
 }
@@ -2564,7 +1664,7 @@ __global__ __launch_bounds__(256) void k_db_head_tail(const float* __restrict__ 
 void db_head_tail(hipStream_t st, const float* x, const ImgGeom* gin, const ImgGeom* gout, int n_img, long long max_pix,
                   const float* w1, const float* b1, const float* w2, const float* b2, float* out) {
   if (n_img <= 0) return;
-  hipLaunchKernelGGL(k_db_head_tail, dim3((unsigned)((max_pix + 255) / 256), n_img), dim3(256), 0, st, x, gin, gout, w1,
+  RT_LAUNCH(k_db_head_tail, dim3((unsigned)((max_pix + 255) / 256), n_img), dim3(256), 0, st, x, gin, gout, w1,
                      b1, w2, b2, out);
 }
 
@@ -2594,7 +1694,7 @@ void avgpool_3x2(hipStream_t st, const float* x, const ImgGeom* gin, const ImgGe
                  int Cp, float* y, int ldy) {
   if (n_img <= 0) return;
   long long total = max_pix * (Cp / 4);
-  hipLaunchKernelGGL(k_avgpool_3x2, dim3((unsigned)((total + 255) / 256), n_img), dim3(256), 0, st, x, gin, gout, Cp, y,
+  RT_LAUNCH(k_avgpool_3x2, dim3((unsigned)((total + 255) / 256), n_img), dim3(256), 0, st, x, gin, gout, Cp, y,
                      ldy);
 }
 __global__ __launch_bounds__(256) void k_maxpool_2x2(const float* __restrict__ x, const ImgGeom* __restrict__ gin,
@@ -2622,7 +1722,7 @@ void maxpool_2x2(hipStream_t st, const float* x, const ImgGeom* gin, const ImgGe
                  int Cp, float* y) {
   if (n_img <= 0) return;
   long long total = max_pix * (Cp / 4);
-  hipLaunchKernelGGL(k_maxpool_2x2, dim3((unsigned)((total + 255) / 256), n_img), dim3(256), 0, st, x, gin, gout, Cp, y);
+  RT_LAUNCH(k_maxpool_2x2, dim3((unsigned)((total + 255) / 256), n_img), dim3(256), 0, st, x, gin, gout, Cp, y);
 }
 
 // ---------------------------------------------------------------------------
@@ -2662,7 +1762,7 @@ void add_layernorm(hipStream_t st, const float* x, const float* r, long long row
                    const float* beta, float eps, float* y) {
   if (rows <= 0) return;
   if (C > 256) throw RtError(8, "add_layernorm: C > 256");
-  hipLaunchKernelGGL(k_add_layernorm, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, x, r, rows, C, g, beta, eps, y);
+  RT_LAUNCH(k_add_layernorm, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, x, r, rows, C, g, beta, eps, y);
 }
 
 // block = (query chunk of 64, head, image); K/V of the head streamed through LDS in tiles of 64 keys
@@ -2714,7 +1814,7 @@ void attention(hipStream_t st, const float* qkv, const ImgGeom* geom, int n_img,
                float* out) {
   if (n_img <= 0) return;
   if (hd != 15) throw RtError(8, "attention: head dim must be 15");
-  hipLaunchKernelGGL(k_attention<15>, dim3((maxT + 63) / 64, heads, n_img), dim3(64), 0, st, qkv, geom, heads, out);
+  RT_LAUNCH(k_attention<15>, dim3((maxT + 63) / 64, heads, n_img), dim3(64), 0, st, qkv, geom, heads, out);
 }
 
 __global__ __launch_bounds__(256) void k_copy_channels(const float* __restrict__ src, int lds, long long rows, int C4,
@@ -2728,7 +1828,7 @@ __global__ __launch_bounds__(256) void k_copy_channels(const float* __restrict__
 void copy_channels(hipStream_t st, const float* src, int lds, long long rows, int C, float* dst, int ldd, int coff) {
   if (rows <= 0) return;
   long long total = rows * (C / 4);
-  hipLaunchKernelGGL(k_copy_channels, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, src, lds, rows, C / 4, dst,
+  RT_LAUNCH(k_copy_channels, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, src, lds, rows, C / 4, dst,
                      ldd, coff);
 }
 
@@ -2784,18 +1884,18 @@ __global__ __launch_bounds__(256) void k_softmax_rows(const float* __restrict__ 
 }
 void softmax_rows(hipStream_t st, const float* in, int ld, long long rows, int C, float* out) {
   if (rows <= 0) return;
-  hipLaunchKernelGGL(k_softmax_rows<0>, dim3((unsigned)rows), dim3(256), 0, st, in, ld, rows, C, out, (int*)nullptr,
+  RT_LAUNCH(k_softmax_rows<0>, dim3((unsigned)rows), dim3(256), 0, st, in, ld, rows, C, out, (int*)nullptr,
                      (float*)nullptr);
 }
 void argmax_prob_rows(hipStream_t st, const float* in, int ld, long long rows, int C, int* idx, float* prob) {
   if (rows <= 0) return;
-  hipLaunchKernelGGL(k_softmax_rows<1>, dim3((unsigned)rows), dim3(256), 0, st, in, ld, rows, C, (float*)nullptr, idx,
+  RT_LAUNCH(k_softmax_rows<1>, dim3((unsigned)rows), dim3(256), 0, st, in, ld, rows, C, (float*)nullptr, idx,
                      prob);
 }
 
 void argmax_rows(hipStream_t st, const float* in, int ld, long long rows, int C, int* idx, float* maxval) {
   if (rows <= 0) return;
-  hipLaunchKernelGGL(k_softmax_rows<2>, dim3((unsigned)rows), dim3(256), 0, st, in, ld, rows, C, (float*)nullptr, idx,
+  RT_LAUNCH(k_softmax_rows<2>, dim3((unsigned)rows), dim3(256), 0, st, in, ld, rows, C, (float*)nullptr, idx,
                      maxval);
 }
 

@@ -103,7 +103,7 @@ void thumbnail_rgb8(hipStream_t st, const uint8_t* src, int h, int w, uint8_t* d
     (void)hipMemcpyAsync(dst, src, (size_t)total * 3, hipMemcpyDeviceToDevice, st);
     return;
   }
-  hipLaunchKernelGGL(k_thumbnail, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, ThumbSrc{src, h, w}, dst, nh, nw,
+  RT_LAUNCH(k_thumbnail, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, ThumbSrc{src, h, w}, dst, nh, nw,
                      err_flag);
 }
 
@@ -146,7 +146,7 @@ void det_normalize_batch(hipStream_t st, const NormDesc* d_descs, int n, long lo
   if (n <= 0 || max_pix <= 0) return;
   Norm3 nm; nm.scale = scale;
   for (int i = 0; i < 3; i++) { nm.mean[i] = mean3[i]; nm.stdv[i] = std3[i]; }
-  hipLaunchKernelGGL(k_det_normalize_batch, dim3((unsigned)((max_pix + 255) / 256), n), dim3(256), 0, st, d_descs, nm, out);
+  RT_LAUNCH(k_det_normalize_batch, dim3((unsigned)((max_pix + 255) / 256), n), dim3(256), 0, st, d_descs, nm, out);
 }
 void det_normalize(hipStream_t st, const uint8_t* rgb, int h, int w, float scale, const float* mean3,
                    const float* std3, int layout, float* out) {
@@ -154,7 +154,7 @@ void det_normalize(hipStream_t st, const uint8_t* rgb, int h, int w, float scale
   if (npix <= 0) return;
   Norm3 nm; nm.scale = scale;
   for (int i = 0; i < 3; i++) { nm.mean[i] = mean3[i]; nm.stdv[i] = std3[i]; }
-  hipLaunchKernelGGL(k_det_normalize, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, st, rgb, npix, nm, layout, out);
+  RT_LAUNCH(k_det_normalize, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, st, rgb, npix, nm, layout, out);
 }
 
 
@@ -202,7 +202,8 @@ __global__ __launch_bounds__(256) void k_warp_crops(const CropDesc* __restrict__
 }
 void warp_crops(hipStream_t st, const CropDesc* descs, int n, int max_pix, uint8_t* pool) {
   if (n <= 0 || max_pix <= 0) return;
-  hipLaunchKernelGGL(k_warp_crops, dim3((max_pix + 255) / 256, n), dim3(256), 0, st, descs, pool);
+  for (int y0 = 0; y0 < n; y0 += RT_MAX_GRID_Y)  // one grid row per crop: chunked to the gridDim.y limit
+    RT_LAUNCH(k_warp_crops, dim3((max_pix + 255) / 256, std::min(n - y0, RT_MAX_GRID_Y)), dim3(256), 0, st, descs + y0, pool);
 }
 
 // cls_processor.rs:108-121 (first-max argmax) + :163-166 rotate_180_in_place
@@ -231,8 +232,9 @@ void cls_post_rotate(hipStream_t st, const float* probs, const int* crop_of_row,
                      const CropRef* crops, uint8_t* pool, int max_pix, int* label_idx, float* score) {
   if (rows <= 0) return;
   int bx = std::max(1, (max_pix / 2 + 255) / 256);
-  hipLaunchKernelGGL(k_cls_post_rotate, dim3(bx, rows), dim3(256), 0, st, probs, crop_of_row, thresh, crops, pool, label_idx,
-                     score);
+  for (int y0 = 0; y0 < rows; y0 += RT_MAX_GRID_Y)
+    RT_LAUNCH(k_cls_post_rotate, dim3(bx, std::min(rows - y0, RT_MAX_GRID_Y)), dim3(256), 0, st, probs + 2 * (size_t)y0,
+              crop_of_row + y0, thresh, crops, pool, label_idx, score);
 }
 
 // image_helper.rs:176-209
@@ -263,8 +265,9 @@ void resize_norm(hipStream_t st, const LineDesc* lines, int n, int img_h, int ma
                  float* out, int* err_flag) {
   if (n <= 0 || max_W <= 0) return;
   long long total = (long long)img_h * max_W;
-  hipLaunchKernelGGL(k_resize_norm, dim3((unsigned)((total + 255) / 256), n), dim3(256), 0, st, lines, img_h, pool, layout,
-                     out, err_flag);
+  for (int y0 = 0; y0 < n; y0 += RT_MAX_GRID_Y)
+    RT_LAUNCH(k_resize_norm, dim3((unsigned)((total + 255) / 256), std::min(n - y0, RT_MAX_GRID_Y)), dim3(256), 0, st,
+              lines + y0, img_h, pool, layout, out, err_flag);
 }
 
 // rec_processor.rs:48-97
@@ -288,7 +291,7 @@ __global__ __launch_bounds__(64) void k_ctc_decode(const int* __restrict__ idx, 
 void ctc_decode(hipStream_t st, const int* idx, const float* prob, const ImgGeom* lines, int n, int* tokens,
                 int* n_tokens, float* score) {
   if (n <= 0) return;
-  hipLaunchKernelGGL(k_ctc_decode, dim3((n + 63) / 64), dim3(64), 0, st, idx, prob, lines, n, tokens, n_tokens, score);
+  RT_LAUNCH(k_ctc_decode, dim3((n + 63) / 64), dim3(64), 0, st, idx, prob, lines, n, tokens, n_tokens, score);
 }
 
 // ===========================================================================
@@ -305,7 +308,7 @@ __global__ __launch_bounds__(256) void k_sum_partial(const float* __restrict__ x
 }
 void sum_partial(hipStream_t st, const float* x, long long n, double* partials) {
   if (n <= 0) return;
-  hipLaunchKernelGGL(k_sum_partial, dim3(sum_blocks(n)), dim3(256), 0, st, x, n, partials);
+  RT_LAUNCH(k_sum_partial, dim3(sum_blocks(n)), dim3(256), 0, st, x, n, partials);
 }
 
 }  // namespace pp

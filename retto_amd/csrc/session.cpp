@@ -28,6 +28,72 @@ struct HostTick {
 };
 
 // ---------------------------------------------------------------------------
+// RecCharacter::new (rec_processor.rs:29-46): String::from_utf8(bytes)? -> lines().map(|l| l.trim()) -> push " "
+// -> insert "blank" at 0.  Rust semantics, restated exactly:
+//  * String::from_utf8 is strict: overlong forms, surrogates (U+D800-DFFF) and code points above U+10FFFF
+//    are errors (Utf8Error);
+//  * str::lines splits after every '\n', drops that '\n' and one '\r' in front of it; a trailing '\n' does not
+//    open a last empty line;
+//  * str::trim strips every char with the Unicode White_Space property (char::is_whitespace): U+0009-000D,
+//    U+0020, U+0085, U+00A0, U+1680, U+2000-200A, U+2028, U+2029, U+202F, U+205F, U+3000 -- a dictionary line
+//    that holds only U+3000 becomes the empty string.
+// ---------------------------------------------------------------------------
+namespace rt {
+static int utf8_decode_strict(const unsigned char* p, size_t n, uint32_t* cp) {  // bytes consumed, 0 = invalid
+  if (n == 0) return 0;
+  const unsigned char c = p[0];
+  if (c < 0x80) { *cp = c; return 1; }
+  auto cont = [&](size_t i) { return i < n && (p[i] & 0xC0) == 0x80; };
+  if (c >= 0xC2 && c <= 0xDF) { if (!cont(1)) return 0; *cp = ((c & 0x1F) << 6) | (p[1] & 0x3F); return 2; }
+  if (c >= 0xE0 && c <= 0xEF) {
+    if (!cont(1) || !cont(2)) return 0;
+    if (c == 0xE0 && p[1] < 0xA0) return 0;   // overlong
+    if (c == 0xED && p[1] >= 0xA0) return 0;  // surrogate
+    *cp = ((c & 0x0F) << 12) | ((p[1] & 0x3F) << 6) | (p[2] & 0x3F); return 3;
+  }
+  if (c >= 0xF0 && c <= 0xF4) {
+    if (!cont(1) || !cont(2) || !cont(3)) return 0;
+    if (c == 0xF0 && p[1] < 0x90) return 0;   // overlong
+    if (c == 0xF4 && p[1] >= 0x90) return 0;  // above U+10FFFF
+    *cp = ((c & 0x07) << 18) | ((p[1] & 0x3F) << 12) | ((p[2] & 0x3F) << 6) | (p[3] & 0x3F); return 4;
+  }
+  return 0;  // 0x80-0xC1 (continuation / overlong lead), 0xF5-0xFF
+}
+static bool is_rust_whitespace(uint32_t c) {
+  return (c >= 0x09 && c <= 0x0D) || c == 0x20 || c == 0x85 || c == 0xA0 || c == 0x1680 || (c >= 0x2000 && c <= 0x200A) ||
+         c == 0x2028 || c == 0x2029 || c == 0x202F || c == 0x205F || c == 0x3000;
+}
+std::vector<std::string> load_dictionary(const std::vector<uint8_t>& bytes) {
+  const unsigned char* p = bytes.data();
+  const size_t n = bytes.size();
+  std::vector<std::string> dict;
+  dict.push_back("blank");
+  size_t pos = 0;
+  while (pos < n) {
+    // one line: [pos, e) without its terminator
+    size_t e = pos;
+    while (e < n && p[e] != '\n') e++;
+    size_t le = e;
+    if (e < n && le > pos && p[le - 1] == '\r') le--;
+    // trim: first / last non-whitespace char, validating as we decode
+    size_t first = std::string::npos, last_end = 0;
+    for (size_t i = pos; i < le;) {
+      uint32_t cp;
+      int k = utf8_decode_strict(p + i, le - i, &cp);
+      if (k == 0) throw RtError(RT_ERR_UTF8, "dictionary is not valid UTF-8 (byte offset " + std::to_string(i) + ")");
+      if (!is_rust_whitespace(cp)) { if (first == std::string::npos) first = i; last_end = i + (size_t)k; }
+      i += (size_t)k;
+    }
+    dict.push_back(first == std::string::npos ? std::string() : std::string((const char*)p + first, last_end - first));
+    if (e >= n) break;
+    pos = e + 1;
+  }
+  dict.push_back(" ");
+  return dict;
+}
+}  // namespace rt
+
+// ---------------------------------------------------------------------------
 // construction (RettoSession::new, session.rs:62-73; RettoWorker::new, worker.rs:91-98)
 // ---------------------------------------------------------------------------
 rt_session* rt_session_create(const rt_config* cfg) {
@@ -53,31 +119,7 @@ rt_session* rt_session_create(const rt_config* cfg) {
   s->det.reset(new DetNet(bd));
   s->cls.reset(new ClsNet(bc));
   s->rec.reset(new RecNet(br));
-  // RecCharacter::new: lines().map(trim), push " ", insert "blank" at 0
-  {
-    std::string txt((const char*)dict.data(), dict.size());
-    // String::from_utf8 validation (error.rs Utf8Error)
-    for (size_t i = 0; i < txt.size();) {
-      unsigned char c = (unsigned char)txt[i];
-      int len = c < 0x80 ? 1 : (c >> 5) == 6 ? 2 : (c >> 4) == 14 ? 3 : (c >> 3) == 30 ? 4 : 0;
-      if (len == 0 || i + len > txt.size()) throw RtError(RT_ERR_UTF8, "dictionary is not valid UTF-8");
-      for (int k = 1; k < len; k++)
-        if (((unsigned char)txt[i + k] >> 6) != 2) throw RtError(RT_ERR_UTF8, "dictionary is not valid UTF-8");
-      i += len;
-    }
-    s->dict.push_back("blank");
-    size_t pos = 0;
-    while (pos < txt.size()) {
-      size_t e = txt.find('\n', pos);
-      std::string line = txt.substr(pos, e == std::string::npos ? std::string::npos : e - pos);
-      if (!line.empty() && line.back() == '\r') line.pop_back();
-      size_t a = line.find_first_not_of(" \t\r\n\v\f"), b = line.find_last_not_of(" \t\r\n\v\f");
-      s->dict.push_back(a == std::string::npos ? std::string() : line.substr(a, b - a + 1));
-      if (e == std::string::npos) break;
-      pos = e + 1;
-    }
-    s->dict.push_back(" ");
-  }
+  s->dict = rt::load_dictionary(dict);
   if ((int)s->dict.size() != s->rec->classes())
     throw RtError(RT_ERR_SHAPE, "dictionary has " + std::to_string(s->dict.size()) + " entries but the rec head has " +
                                     std::to_string(s->rec->classes()) + " classes");
@@ -362,19 +404,45 @@ std::string json_escape(const std::string& s) {
   }
   return o;
 }
+// serde_json writes a finite f32 through ryu: the shortest decimal string that parses back to the same f32
+// (0.9f -> "0.9", not "0.899999976"), laid out by ryu's f32 rules -- plain decimals while the decimal point
+// position kk is in (-6, 13] ("123.0", "0.00001234"), otherwise d[.ddd]e[-]x ("1e30", "1.234e-7").
 std::string fnum(float v) {
-  if (v != v) return "null";  // serde_json writes non-finite f32 as null
-  if (std::isinf(v)) return "null";
-  char b[32]; snprintf(b, sizeof b, "%.9g", (double)v);
-  std::string s(b);
-  if (s.find_first_of(".eEn") == std::string::npos) s += ".0";
-  return s;
+  if (v != v || std::isinf(v)) return "null";  // serde_json writes non-finite floats as null
+  if (v == 0.0f) return std::signbit(v) ? "-0.0" : "0.0";
+  char b[40];
+  int prec = 0;
+  for (; prec < 9; prec++) {  // shortest digit string that round-trips
+    snprintf(b, sizeof b, "%.*e", prec, (double)v);
+    if (strtof(b, nullptr) == v) break;
+  }
+  std::string digits; int exp10 = 0; bool neg = false;
+  {
+    const char* p = b;
+    if (*p == '-') { neg = true; p++; }
+    for (; *p && *p != 'e'; p++) if (*p != '.') digits += *p;
+    exp10 = atoi(p + 1);
+  }
+  while (digits.size() > 1 && digits.back() == '0') digits.pop_back();
+  const int len = (int)digits.size();
+  const int k = exp10 - (len - 1);  // value = digits * 10^k
+  const int kk = len + k;           // position of the decimal point
+  std::string o = neg ? "-" : "";
+  if (0 <= k && kk <= 13) { o += digits; o.append((size_t)k, '0'); o += ".0"; }
+  else if (0 < kk && kk <= 13) { o += digits.substr(0, (size_t)kk); o += '.'; o += digits.substr((size_t)kk); }
+  else if (-6 < kk && kk <= 0) { o += "0."; o.append((size_t)(-kk), '0'); o += digits; }
+  else {
+    o += digits[0];
+    if (len > 1) { o += '.'; o += digits.substr(1); }
+    o += 'e'; o += std::to_string(kk - 1);
+  }
+  return o;
 }
 }  // namespace
+std::string rt_format_f32_impl(float v) { return fnum(v); }
 
 rt_results* rt_session::run_pages(const uint8_t* const* rgb, const int* hs, const int* ws, int n_pages, int mem,
                                   const float* const* det_map_override) {
-  static std::chrono::steady_clock::time_point last_exit = std::chrono::steady_clock::now();
   if (g_trace) fprintf(stderr, "[rt host] %-28s %8.3f ms\n", "between calls", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - last_exit).count());
   HostTick tick0;
   begin_call();
@@ -711,7 +779,7 @@ rt_results* rt_session::run_pages(const uint8_t* const* rgb, const int* hs, cons
   if (stage_cb)
     for (int i = 0; i < n_pages; i++) { emit_stage(i, 1, res->pages[i]); emit_stage(i, 2, res->pages[i]); }
   tick.lap("results");
-  last_exit = std::chrono::steady_clock::now();
+  if (g_trace) last_exit = std::chrono::steady_clock::now();
   return res.release();
 }
 

@@ -2,6 +2,7 @@
 // (/root/reference/retto-core/src/session.rs:75-106) over a batch of pages, plus the
 // tensor-level worker entry points (worker.rs:69-73) and the stage functions.
 #pragma once
+#include <chrono>
 #include <memory>
 #include <mutex>
 #include <string>
@@ -52,6 +53,7 @@ struct rt_session {
   void* stage_user = nullptr;
   std::mutex* stage_mu = nullptr;  // callbacks of concurrent lanes are serialised
   int page_base = 0;               // global index of this lane's first page
+  std::chrono::steady_clock::time_point last_exit = std::chrono::steady_clock::now();  // RT_TRACE only
   void emit_stage(int page, int stage, const rt_results::Page& P);
 
   rt::RunCtx ctx(rt::Arena* a) { return rt::RunCtx{st, a, &pinned, &prof}; }
@@ -81,3 +83,8 @@ struct rt_session {
 };
 
 rt_session* rt_session_create(const rt_config* cfg);
+std::string rt_format_f32_impl(float v);  // serde_json / ryu form of an f32
+namespace rt {
+// RecCharacter::new (rec_processor.rs:29-46) with Rust's from_utf8 / lines / trim semantics
+std::vector<std::string> load_dictionary(const std::vector<uint8_t>& bytes);
+}

@@ -146,3 +146,79 @@ def test_integration_doc_config_matches_header():
     assert rs_fields == fields
     from retto_amd._lib import Config
     assert [f[0] for f in Config._fields_] == fields
+
+
+def _parse_dict(data: bytes):
+    lib = _lib.load()
+    lib.rt_parse_dictionary.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t),
+                                        C.POINTER(C.c_int), C.c_char_p, C.c_size_t]
+    out, ln, n = C.c_void_p(), C.c_size_t(), C.c_int()
+    err = C.create_string_buffer(256)
+    rc = lib.rt_parse_dictionary(data, len(data), C.byref(out), C.byref(ln), C.byref(n), err, 256)
+    if rc != 0:
+        return rc, err.value.decode()
+    joined = C.string_at(out, ln.value).decode("utf-8")
+    lib.rt_buffer_free.argtypes = [C.c_void_p]
+    lib.rt_buffer_free(out)
+    ents = joined.split("\n")
+    assert len(ents) == n.value
+    return 0, ents
+
+
+def test_dictionary_follows_rust_from_utf8_lines_trim():
+    """RecCharacter::new (rec_processor.rs:29-46): strict UTF-8, str::lines, str::trim over the Unicode
+    White_Space set -- both the product loader and the oracle's."""
+    from oracle.pipeline import load_dictionary
+    raw = ("a\r\n" "　\n" "  b \t \n" "\n" "c\n" "一　二\n" "\x1cfs\n" "​zw\n" "last").encode("utf-8")
+    want = ["blank", "a", "", "b", "", "c", "一　二", "\x1cfs", "​zw", "last", " "]
+    # U+3000-only line -> "", inner U+3000 kept, U+001C is NOT White_Space (Python's strip() would remove it),
+    # U+200B (zero width space) is not White_Space either; no empty entry after a trailing newline
+    rc, ents = _parse_dict(raw)
+    assert rc == 0 and ents == want
+    assert load_dictionary(raw) == want
+    rc, ents = _parse_dict(raw + b"\n")
+    assert rc == 0 and ents == want and load_dictionary(raw + b"\n") == want
+    assert _parse_dict(b"")[1] == ["blank", " "] == load_dictionary(b"")
+    for bad in (b"ok\n\xc0\xaf\n",          # overlong '/'
+                b"\xe0\x80\xaf",            # overlong 3-byte
+                b"\xed\xa0\x80",            # surrogate U+D800
+                b"\xf4\x90\x80\x80",        # > U+10FFFF
+                b"\xf8\x88\x80\x80\x80",    # 5-byte form
+                b"abc\xe4\xb8",             # truncated
+                b"\x80"):                   # stray continuation
+        rc, msg = _parse_dict(bad)
+        assert rc == 5 and "UTF-8" in msg, bad   # RT_ERR_UTF8 <-> RettoError::Utf8Error
+        with pytest.raises(UnicodeDecodeError):
+            load_dictionary(bad)
+    # the synthetic 6623-line stand-in still gives 6625 classes
+    rc, ents = _parse_dict(synth.synth_dict())
+    assert rc == 0 and len(ents) == 6625 and ents[0] == "blank" and ents[-1] == " "
+
+
+def test_json_numbers_are_shortest_round_trip_like_serde_json():
+    """serde_json writes f32 through ryu: shortest digits that parse back to the same f32."""
+    lib = _lib.load()
+    lib.rt_format_f32.argtypes = [C.c_float, C.c_char_p, C.c_size_t]
+
+    def fmt(v):
+        b = C.create_string_buffer(64)
+        lib.rt_format_f32(float(v), b, 64)
+        return b.value.decode()
+
+    known = {0.9: "0.9", 1.0: "1.0", 123.0: "123.0", 0.5: "0.5", 1e-7: "1e-7", 1.234e-7: "1.234e-7", 3.4e38: "3.4e38",
+             0.00001234: "0.00001234", 1e13: "1e13", 1e12: "1000000000000.0", 16777216.0: "16777216.0", -2.5: "-2.5",
+             1.0 / 3.0: "0.33333334", 0.0: "0.0", 959.0: "959.0"}
+    for v, s in known.items():
+        assert fmt(v) == s, (v, fmt(v), s)
+    assert fmt(float("nan")) == "null" and fmt(float("inf")) == "null"
+    rng = np.random.default_rng(0)
+    vals = np.concatenate([rng.random(2000, dtype=np.float32), (rng.standard_normal(2000) * 1e3).astype(np.float32),
+                           rng.integers(0, 4000, 500).astype(np.float32),
+                           np.exp(rng.uniform(-80, 80, 2000)).astype(np.float32)])
+    for v in vals:
+        s = fmt(v)
+        assert np.float32(float(s)) == v, (v, s)                      # round trip
+        digits = s.replace("-", "").split("e")[0].replace(".", "").strip("0")
+        assert len(digits) <= 9
+        if len(digits) > 1:                                           # no shorter digit string round-trips
+            assert np.float32(float("%.*e" % (len(digits) - 2, float(v)))) != v, (v, s)
