@@ -100,7 +100,11 @@ typedef struct rt_config {
   int32_t max_boxes_per_page; /* capacity of the per-page box list; 0 = default 4096 */
   int32_t det_sub_batch;      /* pages per det launch group; 0 = default */
   int32_t lanes;              /* concurrent page streams inside rt_run_batch (1..4); 0 = default 3 */
+  int32_t dtype;              /* rt_dtype: arithmetic of the three networks.  RT_DTYPE_F32 (default) = what the reference's
+                                 ort-CPU path computes in; RT_DTYPE_F16 = fp16 storage / MFMA, fp32 accumulation
+                                 (BASELINE.json config 5).  The PP-OCRv4 server graphs are built in fp16 only. */
 } rt_config;
+typedef enum rt_dtype { RT_DTYPE_F32 = 0, RT_DTYPE_F16 = 1 } rt_dtype;
 
 typedef struct rt_session rt_session;
 typedef struct rt_results rt_results;
@@ -120,6 +124,9 @@ RT_API int rt_cls(rt_session* s, const float* nchw, int n, int c, int h, int w, 
  * query T only. */
 RT_API int rt_rec(rt_session* s, const float* nchw, int n, int c, int h, int w, float* out, int* t_out);
 RT_API int rt_rec_classes(const rt_session* s);
+/* "<det arch>/<det dtype> <cls dtype> <rec arch>/<rec dtype>", e.g. "mobile/f32 f32 mobile/f32" or "server/f16 f16 server/f16":
+ * which graphs the model sources held and the arithmetic they run in (library-owned string) */
+RT_API const char* rt_model_info(const rt_session* s);
 
 /* ---- stage functions (host buffers; computed on the GPU) ------------------------- */
 RT_API int rt_resize_both_dims(const rt_session* s, int h, int w, int* out_h, int* out_w);
@@ -239,6 +246,10 @@ RT_API size_t rt_model_manifest(int which, char* buf, size_t cap);
  * only, 5 128- instead of 64-channel wide slabs, 6 CTC head on the 128x128 wide tile.
  * Process-wide; every setting computes bit-identical results. */
 RT_API void rt_debug_set_variants(int gemm_variant, int dw_variant, int flags);
+/* one launch of the fp16 implicit-GEMM conv kernel on host tensors: x [n, cin, h, w], wt [cout, cin, kh, kw], bias [cout] or
+ * NULL, "same" padding k/2, stride (sh, sw), act = 0 none / 1 relu / 2 hardswish / 3 swish / 4 sigmoid -> out [n, cout, ho, wo] */
+RT_API int rt_debug_conv16(rt_session* s, const float* x, int n, int cin, int h, int w, const float* wt, int cout, int kh, int kw,
+                           int sh, int sw, const float* bias, int act, float* out);
 /* times nn::gemm (M x K x N, random data) over `iters` launches on the session's stream and
  * returns the average ms and the max |diff| against variant 0 */
 RT_API int rt_bench_gemm(rt_session* s, long long M, int K, int N, int variant, int iters, float* ms_out, float* maxdiff_out);

@@ -149,14 +149,20 @@ def rec_forward(w: Dict[str, torch.Tensor], x: torch.Tensor) -> torch.Tensor:
     for name, k, _cin, _cout, stride, se in REC_BLOCKS:
         x = _lcnet_block(w, "rec." + name, x, k, stride, se, dw_act=True)
     x = F.avg_pool2d(x, (3, 2))
+    return _svtr_ctc(w, "rec", x)
+
+
+def _svtr_ctc(w, prefix, x):
+    """EncoderWithSVTR (dims 120, depth 2, 8 heads, kernel [1,3], use_guide) + CTC head on the pooled backbone
+    feature x [B, C, 1, T]; tensors named <prefix>.neck.* / <prefix>.head.fc."""
     h = x
-    z = swish(_conv(w, "rec.neck.conv1", x, pad=(0, 1)))
-    z = swish(_conv(w, "rec.neck.conv2", z))
+    z = swish(_conv(w, prefix + ".neck.conv1", x, pad=(0, 1)))
+    z = swish(_conv(w, prefix + ".neck.conv2", z))
     B, C, H, W = z.shape
     z = z.flatten(2).transpose(1, 2)  # [B, T, C]
     nh, hd = 8, C // 8
     for i in range(2):
-        p = f"rec.neck.blk{i}"
+        p = f"{prefix}.neck.blk{i}"
         qkv = (z @ w[p + ".qkv.w"] + w[p + ".qkv.b"]).reshape(B, -1, 3, nh, hd).permute(2, 0, 3, 1, 4)
         q, k_, v = qkv[0] * (hd ** -0.5), qkv[1], qkv[2]
         attn = torch.softmax(q @ k_.transpose(-2, -1), dim=-1)
@@ -165,14 +171,14 @@ def rec_forward(w: Dict[str, torch.Tensor], x: torch.Tensor) -> torch.Tensor:
         z = _ln(w, p + ".norm1", z + a, 1e-5)
         m = swish(z @ w[p + ".fc1.w"] + w[p + ".fc1.b"]) @ w[p + ".fc2.w"] + w[p + ".fc2.b"]
         z = _ln(w, p + ".norm2", z + m, 1e-5)
-    z = _ln(w, "rec.neck.norm", z, 1e-6)
+    z = _ln(w, prefix + ".neck.norm", z, 1e-6)
     z = z.reshape(B, H, W, C).permute(0, 3, 1, 2)
-    z = swish(_conv(w, "rec.neck.conv3", z))
+    z = swish(_conv(w, prefix + ".neck.conv3", z))
     z = torch.cat([h, z], dim=1)
-    z = swish(_conv(w, "rec.neck.conv4", z, pad=(0, 1)))
-    z = swish(_conv(w, "rec.neck.conv1x1", z))
+    z = swish(_conv(w, prefix + ".neck.conv4", z, pad=(0, 1)))
+    z = swish(_conv(w, prefix + ".neck.conv1x1", z))
     z = z.squeeze(2).transpose(1, 2)  # Im2Seq: [B, T, 120]
-    logits = z @ w["rec.head.fc.w"] + w["rec.head.fc.b"]
+    logits = z @ w[prefix + ".head.fc.w"] + w[prefix + ".head.fc.b"]
     return torch.softmax(logits, dim=2)
 
 
@@ -194,3 +200,86 @@ def cls_forward(w: Dict[str, torch.Tensor], x: torch.Tensor) -> torch.Tensor:
     x = F.max_pool2d(x, 2, 2)
     x = x.mean(dim=(2, 3))
     return torch.softmax(x @ w["cls.head.fc.w"] + w["cls.head.fc.b"], dim=1)
+
+
+# ---------------------------------------------------------------------------
+# PP-OCRv4 server graphs (BASELINE.json config 5; not named by the reference, SURVEY.md Appendix C "Server"):
+# PPHGNet_small backbone (ppocr/modeling/backbones/rec_hgnet.py), LKPAN(256, large, intracl) neck and PFHeadLocal head
+# for detection; the mobile model's SVTR neck / CTC head on 1024 channels for recognition.  Parameter counts
+# reproduce the published inference models (det ~113 MB, rec ~90 MB fp32).  PARITY UNPINNED (as above).
+# ---------------------------------------------------------------------------
+HG_STEM = 3
+HG_LAYERS = 6
+HG_STAGES_DET = [("st1", 1, False, (2, 2)), ("st2", 1, True, (2, 2)), ("st3", 2, True, (2, 2)), ("st4", 1, True, (2, 2))]
+HG_STAGES_REC = [("st1", 1, True, (2, 1)), ("st2", 1, True, (1, 2)), ("st3", 2, True, (2, 1)), ("st4", 1, True, (2, 1))]
+
+
+def _hg_block(w, p, x, identity):
+    outs = [x]
+    t = x
+    for l in range(HG_LAYERS):
+        t = F.relu(_conv(w, f"{p}.l{l}", t, pad=(1, 1)))
+        outs.append(t)
+    t = F.relu(_conv(w, p + ".agg", torch.cat(outs, dim=1)))
+    gate = torch.sigmoid(_conv(w, p + ".ese", t.mean(dim=(2, 3), keepdim=True)))   # ESEModule
+    t = t * gate
+    return t + x if identity else t
+
+
+def _hgnet(w, prefix, x, stages, det):
+    for i in range(HG_STEM):
+        x = F.relu(_conv(w, f"{prefix}.stem{i}", x, stride=(2, 2) if i == 0 else (1, 1), pad=(1, 1)))
+    if det:
+        x = F.max_pool2d(x, 3, 2, 1)
+    feats = []
+    for name, blocks, down, stride in stages:
+        p = f"{prefix}.{name}"
+        if down:
+            x = _conv(w, p + ".ds", x, stride=stride, pad=(1, 1), groups=x.shape[1])
+        for b in range(blocks):
+            x = _hg_block(w, f"{p}.b{b}", x, identity=b > 0)
+        feats.append(x)
+    return feats
+
+
+def _intracl(w, p, x):
+    t = _conv(w, p + ".reduce", x)
+    for k in (7, 5, 3):
+        t = (_conv(w, f"{p}.c{k}", t, pad=(k // 2, k // 2)) + _conv(w, f"{p}.v{k}", t, pad=(k // 2, 0))
+             + _conv(w, f"{p}.q{k}", t, pad=(0, k // 2)))
+    return x + F.relu(_conv(w, p + ".ret", t))
+
+
+@torch.no_grad()
+def sdet_forward(w: Dict[str, torch.Tensor], x: torch.Tensor) -> torch.Tensor:
+    """x [N,3,H,W] (BGR, normalised; H, W multiples of 32) -> probability map [N,1,H,W] = 0.5 * (shrink + cbn)."""
+    c2, c3, c4, c5 = _hgnet(w, "sdet", x, HG_STAGES_DET, det=True)
+    up = lambda t, s: F.interpolate(t, scale_factor=s, mode="nearest")
+    n = "sdet.neck"
+    in5 = _conv(w, n + ".ins3", c5); in4 = _conv(w, n + ".ins2", c4)
+    in3 = _conv(w, n + ".ins1", c3); in2 = _conv(w, n + ".ins0", c2)
+    out4 = in4 + up(in5, 2); out3 = in3 + up(out4, 2); out2 = in2 + up(out3, 2)
+    f5 = _conv(w, n + ".inp3", in5, pad=(4, 4)); f4 = _conv(w, n + ".inp2", out4, pad=(4, 4))
+    f3 = _conv(w, n + ".inp1", out3, pad=(4, 4)); f2 = _conv(w, n + ".inp0", out2, pad=(4, 4))
+    pan3 = f3 + _conv(w, n + ".panhead0", f2, stride=(2, 2), pad=(1, 1))
+    pan4 = f4 + _conv(w, n + ".panhead1", pan3, stride=(2, 2), pad=(1, 1))
+    pan5 = f5 + _conv(w, n + ".panhead2", pan4, stride=(2, 2), pad=(1, 1))
+    p2 = _conv(w, n + ".panlat0", f2, pad=(4, 4)); p3 = _conv(w, n + ".panlat1", pan3, pad=(4, 4))
+    p4 = _conv(w, n + ".panlat2", pan4, pad=(4, 4)); p5 = _conv(w, n + ".panlat3", pan5, pad=(4, 4))
+    p5 = _intracl(w, n + ".incl4", p5); p4 = _intracl(w, n + ".incl3", p4)
+    p3 = _intracl(w, n + ".incl2", p3); p2 = _intracl(w, n + ".incl1", p2)
+    fuse = torch.cat([up(p5, 8), up(p4, 4), up(p3, 2), p2], dim=1)
+    y = F.relu(_conv(w, "sdet.head.conv1", fuse, pad=(1, 1)))
+    f = F.relu(F.conv_transpose2d(y, w["sdet.head.deconv1.w"], w["sdet.head.deconv1.b"], stride=2))
+    base = torch.sigmoid(F.conv_transpose2d(f, w["sdet.head.deconv2.w"], w["sdet.head.deconv2.b"], stride=2))
+    loc = F.relu(_conv(w, "sdet.head.local3", torch.cat([base, up(f, 2)], dim=1), pad=(1, 1)))   # LocalModule
+    cbn = torch.sigmoid(_conv(w, "sdet.head.local1", loc))
+    return 0.5 * (base + cbn)
+
+
+@torch.no_grad()
+def srec_forward(w: Dict[str, torch.Tensor], x: torch.Tensor) -> torch.Tensor:
+    """x [n,3,48,W] -> softmax probs [n,T,classes], T = W/8."""
+    x = _hgnet(w, "srec", x, HG_STAGES_REC, det=False)[-1]
+    x = F.avg_pool2d(x, (3, 2))
+    return _svtr_ctc(w, "srec", x)

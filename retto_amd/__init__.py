@@ -116,6 +116,7 @@ class RettoSessionConfig:  # session.rs:17-40
     max_boxes_per_page: int = 0
     det_sub_batch: int = 0
     lanes: int = 0
+    dtype: str = "f32"   # "f32" (the reference's arithmetic) or "f16" (fp16 storage / MFMA, fp32 accumulation)
 
 
 # ---- result types (points.rs, processor/*.rs) ---------------------------------------------
@@ -225,6 +226,9 @@ class _Handle:
         if tuple(cl.label) != (0, 180):
             raise InvalidArgument("cls label set other than [0, 180] is not supported")
         c.max_boxes_per_page = cfg.max_boxes_per_page; c.det_sub_batch = cfg.det_sub_batch; c.lanes = cfg.lanes
+        if cfg.dtype not in ("f32", "f16"):
+            raise InvalidArgument("dtype must be 'f32' or 'f16'")
+        c.dtype = 1 if cfg.dtype == "f16" else 0
         h = C.c_void_p()
         _check(lib.rt_create(C.byref(c), C.byref(h)), None)
         self.lib, self.h = lib, h
@@ -509,10 +513,11 @@ def model_manifest(which: int) -> str:
     return buf.value.decode()
 
 
-def synthetic_session_config(seed: int = 0, device: int = 0, **kw) -> RettoSessionConfig:
-    """Session config over seeded synthetic PP-OCRv4-shaped weights (see retto_amd.synth)."""
+def synthetic_session_config(seed: int = 0, device: int = 0, server: bool = False, **kw) -> RettoSessionConfig:
+    """Session config over seeded synthetic PP-OCRv4-shaped weights (see retto_amd.synth): the mobile graphs, or with
+    ``server=True`` the PP-OCRv4 server det / rec graphs (fp16 only: pass ``dtype="f16"``)."""
     from . import synth
-    det, cls, rec, dic = synth.synth_models(seed)
+    det, cls, rec, dic = synth.synth_server_models(seed) if server else synth.synth_models(seed)
     cfg = RettoSessionConfig(**kw)
     cfg.worker_config = RettoHipWorkerConfig(device=device, models=RettoWorkerModelProvider(
         det=RettoWorkerModelSource.Blob(det), rec=RettoWorkerModelSource.Blob(rec), cls=RettoWorkerModelSource.Blob(cls)))

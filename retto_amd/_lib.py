@@ -14,6 +14,7 @@ LIB_PATH = os.path.join(_HERE, "libretto_hip.so")
 
 RT_OK = 0
 RT_MEM_HOST, RT_MEM_DEVICE = 0, 1
+RT_DTYPE_F32, RT_DTYPE_F16 = 0, 1
 STATUS_NAMES = {0: "OK", 1: "IOError", 2: "ImageError", 3: "ShapeError", 4: "BackendError", 5: "Utf8Error",
                 7: "ModelNotFoundError", 8: "InvalidArgument", 9: "CapacityError"}
 
@@ -33,14 +34,14 @@ class Config(C.Structure):
         ("det_min_mini_box_size", C.c_int32), ("det_dilation", C.c_int32),
         ("cls_image_shape", C.c_int32 * 3), ("cls_batch_num", C.c_int32), ("cls_thresh", C.c_float),
         ("rec_image_shape", C.c_int32 * 3), ("rec_batch_num", C.c_int32),
-        ("max_boxes_per_page", C.c_int32), ("det_sub_batch", C.c_int32), ("lanes", C.c_int32),
+        ("max_boxes_per_page", C.c_int32), ("det_sub_batch", C.c_int32), ("lanes", C.c_int32), ("dtype", C.c_int32),
     ]
 
 
 # every symbol include/retto_hip.h declares (tests check that each is exported)
 EXPORTS = [
     "rt_config_default", "rt_create", "rt_destroy", "rt_last_error", "rt_version",
-    "rt_det", "rt_cls", "rt_rec", "rt_rec_classes",
+    "rt_det", "rt_cls", "rt_rec", "rt_rec_classes", "rt_model_info",
     "rt_resize_both_dims", "rt_resize_both", "rt_det_input_dims", "rt_det_preprocess", "rt_det_postprocess",
     "rt_crop_dims", "rt_crop_images", "rt_scale_and_clip", "rt_resize_norm_width", "rt_resize_norm_image",
     "rt_ctc_decode",
@@ -50,7 +51,7 @@ EXPORTS = [
     "rt_device_malloc", "rt_device_free", "rt_memcpy_h2d", "rt_memcpy_d2h", "rt_synchronize",
     "rt_set_lanes", "rt_profile_enable", "rt_profile_get",
     "rt_onnx_to_rtwb", "rt_buffer_free", "rt_model_manifest", "rt_decode_image", "rt_run_encoded_batch",
-    "rt_debug_set_variants", "rt_bench_gemm", "rt_parse_dictionary", "rt_format_f32",
+    "rt_debug_set_variants", "rt_bench_gemm", "rt_debug_conv16", "rt_parse_dictionary", "rt_format_f32",
 ]
 
 STAGE_CALLBACK = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.c_int, C.c_char_p)  # rt_stage_callback

@@ -69,7 +69,7 @@ void rt_config_default(rt_config* c) {
   c->cls_batch_num = 6; c->cls_thresh = 0.9f;
   c->rec_image_shape[0] = 3; c->rec_image_shape[1] = 48; c->rec_image_shape[2] = 320;
   c->rec_batch_num = 6;
-  c->max_boxes_per_page = 0; c->det_sub_batch = 0; c->lanes = 0;
+  c->max_boxes_per_page = 0; c->det_sub_batch = 0; c->lanes = 0; c->dtype = RT_DTYPE_F32;
 }
 
 int rt_create(const rt_config* cfg, rt_session** out) {
@@ -80,6 +80,7 @@ int rt_create(const rt_config* cfg, rt_session** out) {
                  cfg->cls_image_shape[1] == 48 && cfg->cls_image_shape[2] == 192,
              (rt_session*)nullptr, "unsupported cls/rec image_shape for the PP-OCRv4 mobile graphs");
   RT_REQUIRE(cfg->lanes >= 0 && cfg->lanes <= 4, (rt_session*)nullptr, "lanes must be in [0, 4]");
+  RT_REQUIRE(cfg->dtype == RT_DTYPE_F32 || cfg->dtype == RT_DTYPE_F16, (rt_session*)nullptr, "dtype must be RT_DTYPE_F32 or RT_DTYPE_F16");
   RT_REQUIRE(cfg->max_boxes_per_page >= 0 && cfg->max_boxes_per_page <= 4096, (rt_session*)nullptr,
              "max_boxes_per_page must be in [0, 4096]");
   return guarded(nullptr, [&] { *out = rt_session_create(cfg); });
@@ -119,6 +120,7 @@ int rt_rec(rt_session* s, const float* nchw, int n, int c, int h, int w, float* 
   return guarded(s, [&] { s->rec_forward(nchw, n, h, w, out, t_out); });
 }
 int rt_rec_classes(const rt_session* s) { return s ? s->rec->classes() : 0; }
+const char* rt_model_info(const rt_session* s) { return s ? s->model_info.c_str() : ""; }
 
 int rt_resize_both_dims(const rt_session* s, int h, int w, int* out_h, int* out_w) {
   if (!s || !out_h || !out_w) return RT_ERR_INVALID;
@@ -371,6 +373,44 @@ RT_API void rt_debug_set_variants(int gemm_variant, int dw_variant, int flags) {
   nn::g_dw_wide3_min = (flags & 16) ? (1 << 30) : 128;
   nn::g_dw_wide_lp = (flags & 32) ? 32 : 16;
   nn::g_argmax_wide = (flags & 64) ? 2 : 0;
+}
+// Runs one nh::conv16 launch on host tensors (diagnostics: the numerics tests compare it with torch conv2d).
+// x [n, cin, h, w] f32, w [cout, cin, kh, kw] f32, bias [cout] or null, "same" padding k/2, stride (sh, sw); out [n, cout, ho, wo] f32.
+RT_API int rt_debug_conv16(rt_session* s, const float* x, int n, int cin, int h, int w, const float* wt, int cout, int kh, int kw,
+                           int sh, int sw, const float* bias, int act, float* out) {
+  RT_REQUIRE(s && x && wt && out && n > 0 && cin > 0 && h > 0 && w > 0 && cout > 0, s, "rt_debug_conv16: bad argument");
+  return guarded(s, [&] {
+    using nh::half_t;
+    s->begin_call();
+    const int cp = nh::pitch8(cin), op = nh::pitch8(cout), npad = round_up(cout, 32), nslab = (cp + 31) / 32;
+    const int ho = (h - 1) / sh + 1, wo = (w - 1) / sw + 1;
+    std::vector<half_t> hx((size_t)n * h * w * cp, (half_t)0.f), hw((size_t)nslab * kh * kw * npad * 32, (half_t)0.f);
+    for (int i = 0; i < n; i++)
+      for (int c = 0; c < cin; c++)
+        for (int p = 0; p < h * w; p++) hx[((size_t)i * h * w + p) * cp + c] = (half_t)x[((size_t)i * cin + c) * h * w + p];
+    for (int o = 0; o < cout; o++)
+      for (int c = 0; c < cin; c++)
+        for (int t = 0; t < kh * kw; t++)
+          hw[((((size_t)(c / 32) * kh + t / kw) * kw + t % kw) * npad + o) * 32 + c % 32] = (half_t)wt[((size_t)o * cin + c) * kh * kw + t];
+    std::vector<float> hb(npad, 0.f);
+    if (bias) memcpy(hb.data(), bias, (size_t)cout * sizeof(float));
+    half_t* dx = s->arena.alloc<half_t>(hx.size()); half_t* dw = s->arena.alloc<half_t>(hw.size());
+    float* db = s->arena.alloc<float>(hb.size()); half_t* dy = s->arena.alloc<half_t>((size_t)n * ho * wo * op);
+    RT_HIP_CHECK(hipMemcpyAsync(dx, hx.data(), hx.size() * 2, hipMemcpyHostToDevice, s->st));
+    RT_HIP_CHECK(hipMemcpyAsync(dw, hw.data(), hw.size() * 2, hipMemcpyHostToDevice, s->st));
+    RT_HIP_CHECK(hipMemcpyAsync(db, hb.data(), hb.size() * 4, hipMemcpyHostToDevice, s->st));
+    Level Li = make_level(std::vector<std::pair<int, int>>((size_t)n, {h, w})), Lo = make_level(std::vector<std::pair<int, int>>((size_t)n, {ho, wo}));
+    RunCtx c = s->ctx(&s->arena);
+    upload_levels(c, {&Li, &Lo});
+    nh::Epi16 e; e.bias = db; e.act = act;
+    nh::conv16(s->st, dx, cp, Li.d, Lo.d, n, Lo.maxH, Lo.maxW, cp, kh, kw, sh, sw, kh / 2, kw / 2, dw, cout, npad, dy, op, 0, e);
+    std::vector<half_t> hy((size_t)n * ho * wo * op);
+    RT_HIP_CHECK(hipMemcpyAsync(hy.data(), dy, hy.size() * 2, hipMemcpyDeviceToHost, s->st));
+    s->sync();
+    for (int i = 0; i < n; i++)
+      for (int o = 0; o < cout; o++)
+        for (int p = 0; p < ho * wo; p++) out[((size_t)i * cout + o) * ho * wo + p] = (float)hy[((size_t)i * ho * wo + p) * op + o];
+  });
 }
 // Kernel micro-benchmark (not part of the drop-in surface): times nn::gemm on random data.
 RT_API int rt_bench_gemm(rt_session* s, long long M, int K, int N, int variant, int iters, float* ms_out, float* maxdiff_out) {

@@ -33,6 +33,10 @@ Level down_level(const Level& in, int sh, int sw) {
   finish_level(L);
   return L;
 }
+Level flat_level(const Level& in) {
+  if (in.total > 0x7fffffffLL) throw RtError(3, "level too large for a flat view");
+  return make_level({{1, (int)in.total}});
+}
 Level pool_level(const Level& in, int kh, int kw) {
   Level L;
   for (auto& g : in.h) L.h.push_back(ImgGeom{0, g.H >= kh ? (g.H - kh) / kh + 1 : 0, g.W >= kw ? (g.W - kw) / kw + 1 : 0, 0});
@@ -58,6 +62,14 @@ void upload_levels(RunCtx& c, std::vector<Level*> levels) {
 // weights
 // ---------------------------------------------------------------------------
 WeightStore::~WeightStore() { for (void* p : bufs_) (void)hipFree(p); }
+void* WeightStore::upload_bytes(const void* host, size_t bytes) {
+  void* p = nullptr;
+  size_t cap = std::max<size_t>(bytes, 16);
+  RT_HIP_CHECK(hipMalloc(&p, cap));
+  RT_HIP_CHECK(hipMemcpy(p, host, bytes, hipMemcpyHostToDevice));
+  bufs_.push_back(p); total_ += cap;
+  return p;
+}
 float* WeightStore::upload(const std::vector<float>& host) {
   void* p = nullptr;
   size_t bytes = std::max<size_t>(host.size(), 4) * sizeof(float);
@@ -72,7 +84,7 @@ static void expect_dims(const BlobTensor& t, std::initializer_list<int> d, const
 }
 
 // conv weight [cout, cin, kh, kw] -> [nkc][taps][Npad][KC]
-static PackedDense pack_conv(WeightStore& ws, const Blob& b, const std::string& name, int cout, int cin, int kh, int kw) {
+PackedDense pack_conv(WeightStore& ws, const Blob& b, const std::string& name, int cout, int cin, int kh, int kw) {
   const BlobTensor& w = b.get(name + ".w");
   expect_dims(w, {cout, cin, kh, kw}, name + ".w");
   PackedDense p;
@@ -96,7 +108,7 @@ static PackedDense pack_conv(WeightStore& ws, const Blob& b, const std::string& 
   return p;
 }
 // linear weight [in, out]
-static PackedDense pack_linear(WeightStore& ws, const Blob& b, const std::string& name, int cin, int cout) {
+PackedDense pack_linear(WeightStore& ws, const Blob& b, const std::string& name, int cin, int cout) {
   const BlobTensor& w = b.get(name + ".w");
   expect_dims(w, {cin, cout}, name + ".w");
   PackedDense p;
@@ -144,7 +156,7 @@ static Lab get_lab(const Blob& b, const std::string& name) {
   if (b.has(name + ".a")) { l.has = 1; l.a = b.get(name + ".a").data[0]; l.c = b.get(name + ".c").data[0]; }
   return l;
 }
-static float* upload_raw(WeightStore& ws, const Blob& b, const std::string& name, size_t expect_numel) {
+float* upload_raw(WeightStore& ws, const Blob& b, const std::string& name, size_t expect_numel) {
   const BlobTensor& t = b.get(name);
   if (t.numel() != expect_numel) throw RtError(3, "RTWB: unexpected size for " + name);
   return ws.upload(std::vector<float>(t.data, t.data + t.numel()));
@@ -184,8 +196,7 @@ static LcBlock build_lc(WeightStore& ws, const Blob& b, const std::string& prefi
   return blk;
 }
 
-static Epilogue make_epi(const PackedDense& p, int act, const Lab* lab = nullptr, const float* residual = nullptr,
-                         int ld_res = 0) {
+Epilogue make_epi(const PackedDense& p, int act, const Lab* lab, const float* residual, int ld_res) {
   Epilogue e;
   e.bias = p.b; e.act = act;
   e.has_lab = lab ? lab->has : 0; e.lab_a = lab ? lab->a : 1.f; e.lab_c = lab ? lab->c : 0.f;
@@ -392,23 +403,10 @@ RecNet::RecNet(const Blob& b) {
   const int C = 480, D = 120;
   conv1_ = pack_conv(ws_, b, "rec.neck.conv1", C / 8, C, 1, 3);
   conv2_ = pack_conv(ws_, b, "rec.neck.conv2", D, C / 8, 1, 1);
-  for (int i = 0; i < 2; i++) {
-    std::string p = "rec.neck.blk" + std::to_string(i);
-    blk_[i].qkv = pack_linear(ws_, b, p + ".qkv", D, 3 * D);
-    blk_[i].proj = pack_linear(ws_, b, p + ".proj", D, D);
-    blk_[i].fc1 = pack_linear(ws_, b, p + ".fc1", D, 2 * D);
-    blk_[i].fc2 = pack_linear(ws_, b, p + ".fc2", 2 * D, D);
-    blk_[i].n1g = upload_raw(ws_, b, p + ".norm1.g", D); blk_[i].n1b = upload_raw(ws_, b, p + ".norm1.beta", D);
-    blk_[i].n2g = upload_raw(ws_, b, p + ".norm2.g", D); blk_[i].n2b = upload_raw(ws_, b, p + ".norm2.beta", D);
-  }
-  ng_ = upload_raw(ws_, b, "rec.neck.norm.g", D); nb_ = upload_raw(ws_, b, "rec.neck.norm.beta", D);
   conv3_ = pack_conv(ws_, b, "rec.neck.conv3", C, D, 1, 1);
   conv4_ = pack_conv(ws_, b, "rec.neck.conv4", C / 8, 2 * C, 1, 3);
   conv1x1_ = pack_conv(ws_, b, "rec.neck.conv1x1", D, C / 8, 1, 1);
-  const BlobTensor& fw = b.get("rec.head.fc.w");
-  if (fw.dims.size() != 2 || fw.dims[0] != D) throw RtError(3, "RTWB: unexpected shape for rec.head.fc.w");
-  classes_ = fw.dims[1];
-  fc_ = pack_linear(ws_, b, "rec.head.fc", D, classes_);
+  core_.load(ws_, b, "rec");
 }
 
 int RecNet::tokens_for_width(int w) {
@@ -443,12 +441,47 @@ float* RecNet::run(RunCtx& c, const float* x, Level& L0, Level& Lt, int* idx_out
   float* z = c.arena->alloc<float>((size_t)rows * D);
   { ProfScope ps(c.prof, c.st, "gemm_neck");
     nn::gemm(c.st, z1, 60, rows, conv2_.K, conv2_.w, D, conv2_.Npad, z, D, 0, make_epi(conv2_, ACT_SWISH)); }
+  float* zf = core_.mixer(c, z, Lt);
+  { ProfScope ps(c.prof, c.st, "gemm_neck");
+    nn::gemm(c.st, zf, D, rows, conv3_.K, conv3_.w, C, conv3_.Npad, cat, 2 * C, C, make_epi(conv3_, ACT_SWISH)); }
+  float* z4 = c.arena->alloc<float>((size_t)rows * 60);
+  { ProfScope ps(c.prof, c.st, "conv1x3");
+    nn::conv_sp(c.st, 1, 3, cat, 2 * C, Lt.d, Lt.n(), Lt.maxH, Lt.maxW, 2 * C, conv4_.w, 60, conv4_.Npad, z4, 60,
+                make_epi(conv4_, ACT_SWISH)); }
+  float* z5 = c.arena->alloc<float>((size_t)rows * D);
+  { ProfScope ps(c.prof, c.st, "gemm_neck");
+    nn::gemm(c.st, z4, 60, rows, conv1x1_.K, conv1x1_.w, D, conv1x1_.Npad, z5, D, 0, make_epi(conv1x1_, ACT_SWISH)); }
+  return core_.head(c, z5, rows, idx_out, prob_out);
+}
+
+// ---------------------------------------------------------------------------
+// SvtrCore: EncoderWithSVTR's mixing blocks (post-norm: x = LN(x + MHA(x)); x = LN(x + MLP(x))), final LN, CTC FC
+// ---------------------------------------------------------------------------
+void SvtrCore::load(WeightStore& ws, const Blob& b, const std::string& prefix) {
+  for (int i = 0; i < 2; i++) {
+    std::string p = prefix + ".neck.blk" + std::to_string(i);
+    blk[i].qkv = pack_linear(ws, b, p + ".qkv", D, 3 * D);
+    blk[i].proj = pack_linear(ws, b, p + ".proj", D, D);
+    blk[i].fc1 = pack_linear(ws, b, p + ".fc1", D, 2 * D);
+    blk[i].fc2 = pack_linear(ws, b, p + ".fc2", 2 * D, D);
+    blk[i].n1g = upload_raw(ws, b, p + ".norm1.g", D); blk[i].n1b = upload_raw(ws, b, p + ".norm1.beta", D);
+    blk[i].n2g = upload_raw(ws, b, p + ".norm2.g", D); blk[i].n2b = upload_raw(ws, b, p + ".norm2.beta", D);
+  }
+  ng = upload_raw(ws, b, prefix + ".neck.norm.g", D); nb = upload_raw(ws, b, prefix + ".neck.norm.beta", D);
+  const BlobTensor& fw = b.get(prefix + ".head.fc.w");
+  if (fw.dims.size() != 2 || fw.dims[0] != D) throw RtError(3, "RTWB: unexpected shape for " + prefix + ".head.fc.w");
+  classes = fw.dims[1];
+  fc = pack_linear(ws, b, prefix + ".head.fc", D, classes);
+}
+
+float* SvtrCore::mixer(RunCtx& c, float* z, const Level& Lt) const {
+  const long long rows = Lt.total;
   float* qkv = c.arena->alloc<float>((size_t)rows * 3 * D);
   float* a = c.arena->alloc<float>((size_t)rows * D);
   float* a2 = c.arena->alloc<float>((size_t)rows * D);
   float* m = c.arena->alloc<float>((size_t)rows * 2 * D);
   for (int i = 0; i < 2; i++) {
-    const Blk& k = blk_[i];
+    const Blk& k = blk[i];
     { ProfScope ps(c.prof, c.st, "gemm_neck");
       nn::gemm(c.st, z, D, rows, k.qkv.K, k.qkv.w, 3 * D, k.qkv.Npad, qkv, 3 * D, 0, make_epi(k.qkv, ACT_NONE)); }
     { ProfScope ps(c.prof, c.st, "attention");
@@ -468,33 +501,28 @@ float* RecNet::run(RunCtx& c, const float* x, Level& L0, Level& Lt, int* idx_out
   }
   float* zf = c.arena->alloc<float>((size_t)rows * D);
   { ProfScope ps(c.prof, c.st, "layernorm");
-    nn::add_layernorm(c.st, z, nullptr, rows, D, ng_, nb_, 1e-6f, zf); }
-  { ProfScope ps(c.prof, c.st, "gemm_neck");
-    nn::gemm(c.st, zf, D, rows, conv3_.K, conv3_.w, C, conv3_.Npad, cat, 2 * C, C, make_epi(conv3_, ACT_SWISH)); }
-  float* z4 = c.arena->alloc<float>((size_t)rows * 60);
-  { ProfScope ps(c.prof, c.st, "conv1x3");
-    nn::conv_sp(c.st, 1, 3, cat, 2 * C, Lt.d, Lt.n(), Lt.maxH, Lt.maxW, 2 * C, conv4_.w, 60, conv4_.Npad, z4, 60,
-                make_epi(conv4_, ACT_SWISH)); }
-  float* z5 = c.arena->alloc<float>((size_t)rows * D);
-  { ProfScope ps(c.prof, c.st, "gemm_neck");
-    nn::gemm(c.st, z4, 60, rows, conv1x1_.K, conv1x1_.w, D, conv1x1_.Npad, z5, D, 0, make_epi(conv1x1_, ACT_SWISH)); }
+    nn::add_layernorm(c.st, z, nullptr, rows, D, ng, nb, 1e-6f, zf); }
+  return zf;
+}
+
+float* SvtrCore::head(RunCtx& c, const float* z5, long long rows, int* idx_out, float* prob_out) const {
   if (idx_out) {
-    const int tiles = nn::gemm_argmax_tiles(fc_.Npad);
-    Epilogue e = make_epi(fc_, ACT_NONE);
+    const int tiles = nn::gemm_argmax_tiles(fc.Npad);
+    Epilogue e = make_epi(fc, ACT_NONE);
     e.am_max = c.arena->alloc<float>((size_t)rows * tiles);
     e.am_sum = c.arena->alloc<float>((size_t)rows * tiles);
     e.am_idx = c.arena->alloc<int>((size_t)rows * tiles);
     e.am_tiles = tiles;
-    { ProfScope ps(c.prof, c.st, "gemm_ctc_fc", shape_str(rows, fc_.K, classes_, 1));
-      nn::gemm(c.st, z5, D, rows, fc_.K, fc_.w, classes_, fc_.Npad, nullptr, 0, 0, e); }
+    { ProfScope ps(c.prof, c.st, "gemm_ctc_fc", shape_str(rows, fc.K, classes, 1));
+      nn::gemm(c.st, z5, D, rows, fc.K, fc.w, classes, fc.Npad, nullptr, 0, 0, e); }
     { ProfScope ps(c.prof, c.st, "ctc_argmax");
       nn::argmax_merge(c.st, e.am_max, e.am_idx, e.am_sum, tiles, rows, idx_out, prob_out); }
     return nullptr;
   }
-  const int ld = logits_ld();
+  const int ld = round_up(classes, 4);
   float* logits = c.arena->alloc<float>((size_t)rows * ld);
-  { ProfScope ps(c.prof, c.st, "gemm_ctc_fc", shape_str(rows, fc_.K, classes_, 0));
-    nn::gemm(c.st, z5, D, rows, fc_.K, fc_.w, classes_, fc_.Npad, logits, ld, 0, make_epi(fc_, ACT_NONE)); }
+  { ProfScope ps(c.prof, c.st, "gemm_ctc_fc", shape_str(rows, fc.K, classes, 0));
+    nn::gemm(c.st, z5, D, rows, fc.K, fc.w, classes, fc.Npad, logits, ld, 0, make_epi(fc, ACT_NONE)); }
   return logits;
 }
 

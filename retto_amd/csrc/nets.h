@@ -35,6 +35,7 @@ struct RunCtx {
 };
 
 Level make_level(const std::vector<std::pair<int, int>>& hw);
+Level flat_level(const Level& in);                             // one "image" of 1 x total pixels: a 1x1 conv as a GEMM over rows
 Level down_level(const Level& in, int sh, int sw);             // conv k odd, pad k/2
 Level pool_level(const Level& in, int kh, int kw);             // stride = kernel, no pad
 void upload_levels(RunCtx& c, std::vector<Level*> levels);     // one H2D copy for all tables
@@ -51,11 +52,17 @@ class WeightStore {  // owns one device allocation per network
  public:
   ~WeightStore();
   float* upload(const std::vector<float>& host);
+  void* upload_bytes(const void* host, size_t bytes);
   size_t bytes() const { return total_; }
  private:
   std::vector<void*> bufs_;
   size_t total_ = 0;
 };
+
+PackedDense pack_conv(WeightStore& ws, const Blob& b, const std::string& name, int cout, int cin, int kh, int kw);
+PackedDense pack_linear(WeightStore& ws, const Blob& b, const std::string& name, int cin, int cout);
+float* upload_raw(WeightStore& ws, const Blob& b, const std::string& name, size_t expect_numel);
+Epilogue make_epi(const PackedDense& p, int act, const Lab* lab = nullptr, const float* residual = nullptr, int ld_res = 0);
 
 struct LcBlock {
   PackedDw dw; Lab dw_lab; int dw_act = 0;
@@ -64,17 +71,66 @@ struct LcBlock {
   int sh = 1, sw = 1, cin = 0, cout = 0;
 };
 
-class DetNet {
+// The three worker functions as interfaces (RettoInnerWorker::{det,cls,rec}, worker.rs:69-73): the fp32 mobile
+// networks below and the fp16 mobile / server networks of nets_f16.h implement them; the session only sees these.
+class DetModel {
  public:
-  explicit DetNet(const Blob& b);
+  virtual ~DetModel() {}
   // x: f32 NHWC pitch-4 (B,G,R,0) at level L0 (every H,W a multiple of 32).
   // Returns the probability maps, one float per L0 pixel (arena memory).
-  float* run(RunCtx& c, const float* x, Level& L0) { return run(c, x, L0, nullptr, 0.f, nullptr, nullptr); }
+  virtual float* run(RunCtx& c, const float* x, Level& L0) = 0;
   // Same from the RGB8 pages themselves (device descriptors, one per image of L0): the normalisation of
-  // DetProcessor::preprocess is folded into the stem, the f32 input tensor is never built.
-  float* run_u8(RunCtx& c, const nn::U8Page* pages, float scale, const float* mean3, const float* std3, Level& L0) {
+  // DetProcessor::preprocess is folded into the first kernel, the f32 input tensor is never built.
+  virtual float* run_u8(RunCtx& c, const nn::U8Page* pages, float scale, const float* mean3, const float* std3, Level& L0) = 0;
+  virtual const char* arch() const = 0;   // "mobile" / "server"
+  virtual const char* dtype() const = 0;  // "f32" / "f16"
+  virtual size_t weight_bytes() const = 0;
+};
+class ClsModel {
+ public:
+  virtual ~ClsModel() {}
+  // x: f32 NHWC pitch-4, n images of 48 x 192. Returns softmax probs [n,2] (arena).
+  virtual float* run(RunCtx& c, const float* x, Level& L0) = 0;
+  virtual const char* dtype() const = 0;
+};
+class RecModel {
+ public:
+  virtual ~RecModel() {}
+  virtual int classes() const = 0;
+  int logits_ld() const { return round_up(classes(), 4); }
+  // x: f32 NHWC pitch-4 (R,G,B,0), level L0 = lines of height 48; Lt (out) is the token level (H=1, W=T_i).
+  // Returns the logits [Lt.total, logits_ld()], or -- with idx_out / prob_out (Lt.total each) -- runs the fused
+  // CTC head (argmax + softmax probability of the argmax per time step, no logits in HBM) and returns nullptr.
+  virtual float* run(RunCtx& c, const float* x, Level& L0, Level& Lt, int* idx_out = nullptr, float* prob_out = nullptr) = 0;
+  virtual const char* arch() const = 0;
+  virtual const char* dtype() const = 0;
+  virtual size_t weight_bytes() const = 0;
+};
+
+// The part of the recognition head that is the same in every variant (mobile / server, fp32 / fp16): the two
+// SVTR mixing blocks + final norm on D = 120 channels, and the CTC FC with its fused argmax epilogue.  fp32.
+struct SvtrCore {
+  struct Blk { PackedDense qkv, proj, fc1, fc2; float *n1g, *n1b, *n2g, *n2b; } blk[2];
+  float *ng = nullptr, *nb = nullptr;
+  PackedDense fc;
+  int classes = 0, D = 120;
+  void load(WeightStore& ws, const Blob& b, const std::string& prefix);  // <prefix>.neck.blk*, .neck.norm, .head.fc
+  // z [rows, D] -> LN(blocks(z)) [rows, D]
+  float* mixer(RunCtx& c, float* z, const Level& Lt) const;
+  // z5 [rows, D] -> fused argmax (idx_out / prob_out) and nullptr, or the logits [rows, round_up(classes, 4)]
+  float* head(RunCtx& c, const float* z5, long long rows, int* idx_out, float* prob_out) const;
+};
+
+class DetNet : public DetModel {
+ public:
+  explicit DetNet(const Blob& b);
+  float* run(RunCtx& c, const float* x, Level& L0) override { return run(c, x, L0, nullptr, 0.f, nullptr, nullptr); }
+  float* run_u8(RunCtx& c, const nn::U8Page* pages, float scale, const float* mean3, const float* std3, Level& L0) override {
     return run(c, nullptr, L0, pages, scale, mean3, std3);
   }
+  const char* arch() const override { return "mobile"; }
+  const char* dtype() const override { return "f32"; }
+  size_t weight_bytes() const override { return ws_.bytes(); }
  private:
   float* run(RunCtx& c, const float* x, Level& L0, const nn::U8Page* pages, float scale, const float* mean3, const float* std3);
   WeightStore ws_;
@@ -88,32 +144,29 @@ class DetNet {
   float *dc1_w_, *dc1_b_, *dc2_w_, *dc2_b_;
 };
 
-class RecNet {
+class RecNet : public RecModel {
  public:
   explicit RecNet(const Blob& b);
-  int classes() const { return classes_; }
-  int logits_ld() const { return round_up(classes_, 4); }
-  // x: f32 NHWC pitch-4 (R,G,B,0), level L0 = lines of height 48. Returns logits
-  // [rows, logits_ld()] with rows = sum of T_i; Lt (out) is the token level (H=1, W=T_i).
-  // Returns the logits [Lt.total, logits_ld()], or -- with idx_out / prob_out (Lt.total each) -- runs the fused
-  // CTC head (argmax + softmax probability of the argmax per time step, no logits in HBM) and returns nullptr.
-  float* run(RunCtx& c, const float* x, Level& L0, Level& Lt, int* idx_out = nullptr, float* prob_out = nullptr);
+  int classes() const override { return core_.classes; }
+  float* run(RunCtx& c, const float* x, Level& L0, Level& Lt, int* idx_out = nullptr, float* prob_out = nullptr) override;
+  const char* arch() const override { return "mobile"; }
+  const char* dtype() const override { return "f32"; }
+  size_t weight_bytes() const override { return ws_.bytes(); }
+  // time steps of a line of width w (stem stride 2, one (1,2) stage, avg-pool 2): the same for the mobile and server graphs
   static int tokens_for_width(int w);
  private:
   WeightStore ws_;
   float* stem_w_; float* stem_b_;
   std::vector<LcBlock> blocks_;
-  PackedDense conv1_, conv2_, conv3_, conv4_, conv1x1_, fc_;
-  struct Blk { PackedDense qkv, proj, fc1, fc2; float *n1g, *n1b, *n2g, *n2b; } blk_[2];
-  float *ng_, *nb_;
-  int classes_ = 0;
+  PackedDense conv1_, conv2_, conv3_, conv4_, conv1x1_;
+  SvtrCore core_;
 };
 
-class ClsNet {
+class ClsNet : public ClsModel {
  public:
   explicit ClsNet(const Blob& b);
-  // x: f32 NHWC pitch-4, n images of 48 x 192. Returns softmax probs [n,2] (arena).
-  float* run(RunCtx& c, const float* x, Level& L0);
+  float* run(RunCtx& c, const float* x, Level& L0) override;
+  const char* dtype() const override { return "f32"; }
  private:
   struct B { PackedDense expand, linear; PackedDw dw; bool se; SeW sew; int act, sh, sw; bool shortcut; };
   WeightStore ws_;

@@ -116,9 +116,15 @@ rt_session* rt_session_create(const rt_config* cfg) {
   std::vector<uint8_t> dict = read_source_bytes(cfg->dict.path, cfg->dict.data, cfg->dict.len, "dict");
   s->cfg.det = s->cfg.cls = s->cfg.rec = s->cfg.dict = rt_model_source{nullptr, nullptr, 0};
   RT_HIP_CHECK(hipStreamCreateWithFlags(&s->st, hipStreamNonBlocking));
-  s->det.reset(new DetNet(bd));
-  s->cls.reset(new ClsNet(bc));
-  s->rec.reset(new RecNet(br));
+  // which graph a source holds is read off its tensor names; rt_config.dtype picks the arithmetic
+  const bool f16 = cfg->dtype == RT_DTYPE_F16;
+  const bool sdet = blob_is_server_det(bd), srec = blob_is_server_rec(br);
+  if ((sdet || srec) && !f16)
+    throw RtError(RT_ERR_INVALID, "the PP-OCRv4 server graphs are built in fp16 only: set rt_config.dtype = RT_DTYPE_F16");
+  if (sdet) s->det.reset(new DetServerH(bd)); else if (f16) s->det.reset(new DetNetH(bd)); else s->det.reset(new DetNet(bd));
+  if (f16) s->cls.reset(new ClsNetH(bc)); else s->cls.reset(new ClsNet(bc));
+  if (srec) s->rec.reset(new RecServerH(br)); else if (f16) s->rec.reset(new RecNetH(br)); else s->rec.reset(new RecNet(br));
+  s->model_info = std::string(s->det->arch()) + "/" + s->det->dtype() + " " + s->cls->dtype() + " " + s->rec->arch() + "/" + s->rec->dtype();
   s->dict = rt::load_dictionary(dict);
   if ((int)s->dict.size() != s->rec->classes())
     throw RtError(RT_ERR_SHAPE, "dictionary has " + std::to_string(s->dict.size()) + " entries but the rec head has " +
@@ -129,7 +135,7 @@ rt_session* rt_session_create(const rt_config* cfg) {
   for (int l = 1; l < lanes; l++) {
     std::unique_ptr<rt_session> h(new rt_session());
     h->cfg = s->cfg; h->device = s->device;
-    h->det = s->det; h->cls = s->cls; h->rec = s->rec; h->dict = s->dict;
+    h->det = s->det; h->cls = s->cls; h->rec = s->rec; h->dict = s->dict; h->model_info = s->model_info;
     RT_HIP_CHECK(hipStreamCreateWithFlags(&h->st, hipStreamNonBlocking));
     RT_HIP_CHECK(hipMalloc((void**)&h->d_flags, 64));
     RT_HIP_CHECK(hipMemset(h->d_flags, 0, 64));

@@ -10,6 +10,7 @@
 
 #include "../../include/retto_hip.h"
 #include "nets.h"
+#include "nets_f16.h"
 #include "prepost.h"
 #include "runtime.h"
 
@@ -37,9 +38,10 @@ struct rt_session {
   rt::Arena dbws;       // DB post-processing workspace (stream-ordered reuse across pages)
   rt::Pinned pinned;
   rt::Profiler prof;
-  std::shared_ptr<rt::DetNet> det;   // weights are shared with the helper lanes
-  std::shared_ptr<rt::ClsNet> cls;
-  std::shared_ptr<rt::RecNet> rec;
+  std::shared_ptr<rt::DetModel> det;   // weights are shared with the helper lanes
+  std::shared_ptr<rt::ClsModel> cls;
+  std::shared_ptr<rt::RecModel> rec;
+  std::string model_info;
   // extra lanes: same networks and config, own stream / arenas; rt_run_batch splits the pages
   // over the lanes and runs them on concurrent host threads
   std::vector<std::unique_ptr<rt_session>> helpers;

@@ -185,6 +185,95 @@ def cls_tensors(seed: int = 3) -> Dict[str, np.ndarray]:
     return g.t
 
 
+# ---------------------------------------------------------------------------
+# PP-OCRv4 *server* graphs (BASELINE.json config 5; SURVEY.md Appendix C "Server"): PPHGNet_small backbones
+# (ppocr/modeling/backbones/rec_hgnet.py), det neck LKPAN(256, large, intracl) + head PFHeadLocal(k=50, large),
+# rec neck / head as the mobile model (EncoderWithSVTR on 1024 channels + CTC).  Inference form: every
+# ConvBNAct is one conv with bias (BN folded).
+# ---------------------------------------------------------------------------
+HG_STEM = [64, 64, 128]
+HG_LAYERS = 6
+# name, in, mid, out, blocks, downsample
+HG_STAGES_DET = [("st1", 128, 128, 256, 1, False), ("st2", 256, 160, 512, 1, True),
+                 ("st3", 512, 192, 768, 2, True), ("st4", 768, 224, 1024, 1, True)]
+HG_STAGES_REC = [("st1", 128, 128, 256, 1, True), ("st2", 256, 160, 512, 1, True),
+                 ("st3", 512, 192, 768, 2, True), ("st4", 768, 224, 1024, 1, True)]
+HG_STRIDES_DET = [(2, 2)] * 4
+HG_STRIDES_REC = [(2, 1), (1, 2), (2, 1), (2, 1)]
+LKPAN_CH = 256
+SREC_NECK_IN = 1024
+
+
+def _hgnet(g: _Gen, prefix: str, stages):
+    cin = 3
+    for i, c in enumerate(HG_STEM):
+        g.conv(f"{prefix}.stem{i}", c, cin, 3, 3, gain=1.7 if i == 0 else 1.0)
+        cin = c
+    for name, cin, mid, cout, blocks, down in stages:
+        p = f"{prefix}.{name}"
+        if down:
+            g.conv(p + ".ds", cin, 1, 3, 3, act=False)      # depthwise ConvBNAct(use_act=False)
+        for b in range(blocks):
+            bin_ = cin if b == 0 else cout
+            c = bin_
+            for l in range(HG_LAYERS):
+                g.conv(f"{p}.b{b}.l{l}", mid, c, 3, 3, gain=0.92)
+                c = mid
+            g.conv(f"{p}.b{b}.agg", cout, bin_ + HG_LAYERS * mid, 1, 1, gain=1.25)   # ESE gate ~0.5 follows
+            g.conv(f"{p}.b{b}.ese", cout, cout, 1, 1, act=False, gain=0.5)
+
+
+def sdet_tensors(seed: int = 4) -> Dict[str, np.ndarray]:
+    g = _Gen(seed)
+    _hgnet(g, "sdet", HG_STAGES_DET)
+    C, Q = LKPAN_CH, LKPAN_CH // 4
+    for i, (_, _, _, cout, _, _) in enumerate(HG_STAGES_DET):
+        g.conv(f"sdet.neck.ins{i}", C, cout, 1, 1, act=False, bias=False)
+        g.conv(f"sdet.neck.inp{i}", Q, C, 9, 9, act=False, bias=False)
+        g.conv(f"sdet.neck.panlat{i}", Q, Q, 9, 9, act=False, bias=False)
+        if i > 0:
+            g.conv(f"sdet.neck.panhead{i - 1}", Q, Q, 3, 3, act=False, bias=False)
+    for i in range(1, 5):                       # IntraCLBlock(64, reduce_factor=2)
+        p = f"sdet.neck.incl{i}"
+        R = Q // 2
+        g.conv(p + ".reduce", R, Q, 1, 1, act=False)
+        for k in (7, 5, 3):
+            g.conv(f"{p}.c{k}", R, R, k, k, act=False, gain=0.6)
+            g.conv(f"{p}.v{k}", R, R, k, 1, act=False, gain=0.6)
+            g.conv(f"{p}.q{k}", R, R, 1, k, act=False, gain=0.6)
+        g.conv(p + ".ret", Q, R, 1, 1)
+    g.conv("sdet.head.conv1", Q, C, 3, 3)
+    g.t["sdet.head.deconv1.w"] = (g.rng.standard_normal((Q, Q, 2, 2)) * np.sqrt(2.0 / Q)).astype(np.float32)
+    g.t["sdet.head.deconv1.b"] = (g.rng.standard_normal(Q) * 0.05).astype(np.float32)
+    g.t["sdet.head.deconv2.w"] = (g.rng.standard_normal((Q, 1, 2, 2)) * 0.3 * np.sqrt(1.0 / Q)).astype(np.float32)
+    g.t["sdet.head.deconv2.b"] = (g.rng.standard_normal(1) * 0.05).astype(np.float32)
+    g.conv("sdet.head.local3", Q, Q + 1, 3, 3)
+    g.conv("sdet.head.local1", 1, Q, 1, 1, act=False, gain=0.3)
+    return g.t
+
+
+def srec_tensors(seed: int = 5) -> Dict[str, np.ndarray]:
+    g = _Gen(seed)
+    _hgnet(g, "srec", HG_STAGES_REC)
+    C, D = SREC_NECK_IN, REC_NECK_DIM
+    g.conv("srec.neck.conv1", C // 8, C, 1, 3)
+    g.conv("srec.neck.conv2", D, C // 8, 1, 1)
+    for i in range(2):
+        p = f"srec.neck.blk{i}"
+        g.linear(p + ".qkv", D, 3 * D)
+        g.linear(p + ".proj", D, D)
+        g.ln(p + ".norm1", D)
+        g.linear(p + ".fc1", D, 2 * D, gain=np.sqrt(2.0))
+        g.linear(p + ".fc2", 2 * D, D)
+        g.ln(p + ".norm2", D)
+    g.ln("srec.neck.norm", D)
+    g.conv("srec.neck.conv3", C, D, 1, 1)
+    g.conv("srec.neck.conv4", C // 8, 2 * C, 1, 3)
+    g.conv("srec.neck.conv1x1", D, C // 8, 1, 1)
+    g.linear("srec.head.fc", D, REC_CLASSES, gain=8.0)   # peaked like the mobile head (max prob ~0.5): token ids are decisive
+    return g.t
+
+
 def pack_blob(tensors: Dict[str, np.ndarray]) -> bytes:
     names = list(tensors.keys())
     table = bytearray()
@@ -244,3 +333,10 @@ def synth_models(seed: int = 0):
     """Returns (det_blob, cls_blob, rec_blob, dict_bytes)."""
     return (pack_blob(det_tensors(seed * 10 + 1)), pack_blob(cls_tensors(seed * 10 + 3)),
             pack_blob(rec_tensors(seed * 10 + 2)), synth_dict())
+
+
+def synth_server_models(seed: int = 0):
+    """PP-OCRv4 server det / rec (the angle classifier stays the mobile one, as in PaddleOCR's server pipeline).
+    Returns (det_blob, cls_blob, rec_blob, dict_bytes)."""
+    return (pack_blob(sdet_tensors(seed * 10 + 4)), pack_blob(cls_tensors(seed * 10 + 3)),
+            pack_blob(srec_tensors(seed * 10 + 5)), synth_dict())

@@ -1,0 +1,206 @@
+"""GPU tests of the half-precision path (rt_config.dtype = RT_DTYPE_F16): the fp16 kernel family against torch,
+the PP-OCRv4 mobile networks in fp16 and the PP-OCRv4 server networks (BASELINE.json config 5) against the fp32
+torch-CPU oracle.  Tolerances are stated at each test: fp16 storage rounds every activation to 11 significant
+bits, so the bar is a tolerance on the probabilities plus exact token ids / labels wherever the fp32 oracle's
+decision margin exceeds that tolerance."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import nets_torch as N
+from oracle import ref_lib as R
+import retto_amd
+from retto_amd import synth, workload
+
+pytestmark = pytest.mark.gpu
+
+# Stated fp16 tolerances (absolute, on probabilities in [0, 1])
+DET_ATOL_F16 = 4e-2       # DB probability map, mobile and server: max over the map; the mean error must stay below DET_MEAN_F16
+DET_MEAN_F16 = 3e-3
+CLS_ATOL_F16 = 2e-2
+REC_ATOL_F16 = 3e-2       # per-class softmax probabilities
+REC_MARGIN_F16 = 6e-2     # token ids must agree wherever the fp32 top-2 margin exceeds this
+
+
+@pytest.fixture(scope="module")
+def hip16():
+    s = retto_amd.RettoSession(retto_amd.synthetic_session_config(0, dtype="f16"))
+    yield s
+    s.close()
+
+
+@pytest.fixture(scope="module")
+def server_models():
+    return synth.synth_server_models(0)
+
+
+@pytest.fixture(scope="module")
+def hip_server():
+    s = retto_amd.RettoSession(retto_amd.synthetic_session_config(0, server=True, dtype="f16"))
+    yield s
+    s.close()
+
+
+def _model_info(sess):
+    lib = sess.worker._hd.lib
+    lib.rt_model_info.restype = C.c_char_p
+    lib.rt_model_info.argtypes = [C.c_void_p]
+    return lib.rt_model_info(sess.worker._hd.h).decode()
+
+
+def test_model_selection(hip_session, hip16, hip_server):
+    assert _model_info(hip_session) == "mobile/f32 f32 mobile/f32"
+    assert _model_info(hip16) == "mobile/f16 f16 mobile/f16"
+    assert _model_info(hip_server) == "server/f16 f16 server/f16"
+    with pytest.raises(retto_amd.RettoError):   # the server graphs exist in fp16 only
+        retto_amd.RettoSession(retto_amd.synthetic_session_config(0, server=True))
+
+
+# ---------------------------------------------------------------- the implicit-GEMM conv kernel on its own
+def _conv16(sess, x, w, b, sh, sw, act):
+    lib, h = sess.worker._hd.lib, sess.worker._hd.h
+    n, cin, H, W = x.shape
+    cout, _, kh, kw = w.shape
+    ho, wo = (H - 1) // sh + 1, (W - 1) // sw + 1
+    out = np.empty((n, cout, ho, wo), np.float32)
+    lib.rt_debug_conv16.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                    C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+    rc = lib.rt_debug_conv16(h, x.ctypes.data, n, cin, H, W, w.ctypes.data, cout, kh, kw, sh, sw,
+                             b.ctypes.data if b is not None else None, act, out.ctypes.data)
+    assert rc == 0, lib.rt_last_error(h)
+    return out
+
+
+@pytest.mark.parametrize("n,cin,cout,k,stride,hw,act", [
+    (1, 8, 16, (3, 3), (2, 2), (64, 96), 0),        # stem-like: 8 input channels (one short slab)
+    (2, 32, 32, (3, 3), (1, 1), (20, 37), 1),       # odd map sizes, one slab
+    (1, 128, 128, (3, 3), (1, 1), (48, 48), 1),     # PPHGNet stage-1 layer
+    (1, 160, 160, (3, 3), (1, 1), (24, 40), 1),     # 5 column tiles
+    (1, 192, 192, (3, 3), (1, 1), (17, 33), 1),     # two 96-column blocks
+    (2, 768, 224, (3, 3), (1, 1), (6, 40), 1),      # 224 = 128 + 96 columns, short maps (rec stage 4)
+    (1, 256, 64, (9, 9), (1, 1), (30, 30), 0),      # LKPAN 9x9
+    (1, 64, 64, (3, 3), (2, 2), (32, 48), 0),       # LKPAN stride-2 3x3
+    (3, 32, 32, (7, 7), (1, 1), (15, 15), 0),       # IntraCL 7x7
+    (1, 240, 480, (1, 1), (1, 1), (12, 80), 2),     # 1x1, hardswish
+    (4, 480, 60, (1, 3), (1, 1), (1, 50), 3),       # SVTR 1x3, swish, N = 60 -> pitch 64
+    (1, 80, 64, (2, 2), (1, 1), (16, 16), 1),       # 2.5 slabs
+    (2, 96, 24, (3, 3), (1, 1), (40, 56), 0),       # mobile FPN 3x3
+    (1, 1216, 512, (1, 1), (1, 1), (8, 20), 1),     # HG aggregation conv
+])
+def test_conv16_kernel(hip16, n, cin, cout, k, stride, hw, act):
+    """fp16 inputs / weights, fp32 accumulation: against torch conv2d on the SAME fp16-rounded operands the only
+    differences are the accumulation order and the final rounding to fp16 (2^-11 relative)."""
+    rng = np.random.default_rng(cin * 131 + cout)
+    H, W = hw
+    kh, kw = k
+    if (kh, kw) == (2, 2):
+        pytest.skip("even kernels have no symmetric 'same' padding (used only with explicit pads by the PFHeadLocal path)")
+    x = rng.standard_normal((n, cin, H, W)).astype(np.float16).astype(np.float32)
+    w = (rng.standard_normal((cout, cin, kh, kw)) * np.sqrt(2.0 / (cin * kh * kw))).astype(np.float16).astype(np.float32)
+    b = (rng.standard_normal(cout) * 0.1).astype(np.float32)
+    got = _conv16(hip16, x, w, b, stride[0], stride[1], act)
+    ref = F.conv2d(torch.from_numpy(x).double(), torch.from_numpy(w).double(), torch.from_numpy(b).double(), stride=stride,
+                   padding=(kh // 2, kw // 2))
+    ref = {0: lambda t: t, 1: F.relu, 2: N.hswish, 3: N.swish, 4: torch.sigmoid}[act](ref).numpy()
+    assert got.shape == ref.shape
+    err = np.abs(got - ref)
+    tol = 2e-3 * np.abs(ref) + 2e-3     # one fp16 rounding of the result + fp32 accumulation noise
+    assert (err <= tol).all(), f"max err {err.max()} at {np.unravel_index(err.argmax(), err.shape)} (ref {ref.flat[err.argmax()]})"
+
+
+# ---------------------------------------------------------------- mobile networks in fp16 vs the fp32 oracle
+@pytest.mark.parametrize("n,h,w", [(1, 64, 96), (2, 160, 128), (1, 320, 320), (2, 960, 960)])
+def test_det_net_f16(hip16, oracle_session, n, h, w):
+    x = np.random.default_rng(h + w).uniform(-1, 1, (n, 3, h, w)).astype(np.float32)
+    got = hip16.worker.det(x)
+    ref = N.det_forward(oracle_session.wd, torch.from_numpy(x)).numpy()
+    assert got.shape == ref.shape and np.isfinite(got).all()
+    err = np.abs(got - ref)
+    assert err.max() <= DET_ATOL_F16 and err.mean() <= DET_MEAN_F16, f"det map max abs err {err.max()} (mean {err.mean()})"
+    # the thresholded mask agrees wherever the fp32 map is not within the tolerance of the 0.3 threshold
+    far = np.abs(ref - 0.3) > DET_ATOL_F16
+    assert ((got > 0.3) == (ref > 0.3))[far].all()
+
+
+@pytest.mark.parametrize("n", [7, 300])
+def test_cls_net_f16(hip16, oracle_session, n):
+    x = np.random.default_rng(5).uniform(-1, 1, (n, 3, 48, 192)).astype(np.float32)
+    got = hip16.worker.cls(x)
+    ref = N.cls_forward(oracle_session.wc, torch.from_numpy(x)).numpy()
+    assert np.abs(got - ref).max() <= CLS_ATOL_F16
+    decisive = np.abs(ref[:, 1] - ref[:, 0]) > 2 * CLS_ATOL_F16
+    assert (got.argmax(1) == ref.argmax(1))[decisive].all()
+
+
+def _check_rec(got, ref, atol, margin):
+    assert got.shape == ref.shape and np.isfinite(got).all()
+    err = np.abs(got - ref).max()
+    assert err <= atol, f"rec prob max abs err {err}"
+    ga, ra = got.argmax(-1), ref.argmax(-1)
+    top2 = np.sort(ref, -1)[..., -2:]
+    decisive = (top2[..., 1] - top2[..., 0]) > margin
+    assert (ga[decisive] == ra[decisive]).all()
+    return float(decisive.mean()), float((ga == ra).mean())
+
+
+@pytest.mark.parametrize("n,w", [(1, 320), (3, 321), (2, 487), (6, 640), (1, 1600)])
+def test_rec_net_f16(hip16, oracle_session, n, w):
+    x = np.random.default_rng(w).uniform(-1, 1, (n, 3, 48, w)).astype(np.float32)
+    x[:, :, :, w // 2:] = 0.0
+    got = hip16.worker.rec(x)
+    ref = N.rec_forward(oracle_session.wr, torch.from_numpy(x)).numpy()
+    frac_decisive, frac_equal = _check_rec(got, ref, REC_ATOL_F16, REC_MARGIN_F16)
+    print(f"rec f16 n={n} w={w}: decisive {frac_decisive:.3f}, argmax equal {frac_equal:.3f}")
+    assert frac_equal > 0.9
+
+
+# ---------------------------------------------------------------- server networks (config 5) vs the fp32 oracle
+@pytest.mark.parametrize("n,h,w", [(1, 64, 96), (2, 160, 128), (1, 320, 416)])
+def test_server_det_net(hip_server, server_models, n, h, w):
+    wd = N.read_blob(server_models[0])
+    x = np.random.default_rng(h * 7 + w).uniform(-1, 1, (n, 3, h, w)).astype(np.float32)
+    got = hip_server.worker.det(x)
+    ref = N.sdet_forward(wd, torch.from_numpy(x)).numpy()
+    assert got.shape == ref.shape == (n, 1, h, w) and np.isfinite(got).all()
+    err = np.abs(got - ref)
+    assert err.max() <= DET_ATOL_F16 and err.mean() <= DET_MEAN_F16, f"server det map max abs err {err.max()} (mean {err.mean()})"
+    print(f"server det {n}x{h}x{w}: max err {err.max():.4f}, mean {err.mean():.5f}")
+    far = np.abs(ref - 0.3) > DET_ATOL_F16
+    assert ((got > 0.3) == (ref > 0.3))[far].all()
+
+
+@pytest.mark.parametrize("n,w", [(1, 320), (3, 333), (2, 640)])
+def test_server_rec_net(hip_server, server_models, n, w):
+    wr = N.read_blob(server_models[2])
+    x = np.random.default_rng(w + 1).uniform(-1, 1, (n, 3, 48, w)).astype(np.float32)
+    x[:, :, :, (2 * w) // 3:] = 0.0
+    got = hip_server.worker.rec(x)
+    ref = N.srec_forward(wr, torch.from_numpy(x)).numpy()
+    frac_decisive, frac_equal = _check_rec(got, ref, REC_ATOL_F16, REC_MARGIN_F16)
+    print(f"server rec n={n} w={w}: decisive {frac_decisive:.3f}, argmax equal {frac_equal:.3f}")
+
+
+# ---------------------------------------------------------------- whole pipeline in fp16: discrete stages stay bit-exact
+@pytest.mark.parametrize("which", ["mobile", "server"])
+def test_pipeline_f16_teacher_forced(hip16, hip_server, models, server_models, which):
+    """The stages around the networks are the same kernels in every dtype: with the oracle's three workers replaced by
+    the fp16 HIP worker (identical tensors on both sides), boxes / labels / tokens must be bit-exact."""
+    from oracle.pipeline import OracleSession
+    sess = hip16 if which == "mobile" else hip_server
+    det, cls, rec, dic = models if which == "mobile" else server_models
+    o = OracleSession(*(models[:3] + (dic,)))   # the oracle's own nets are unused: all three workers are replaced
+    o.det_worker, o.cls_worker, o.rec_worker = sess.worker.det, sess.worker.cls, sess.worker.rec
+    h, w, lines = 320, 480, 5
+    page, rects = workload.planted_page(h, w, lines, seed=11)
+    dh, dw = R.resize_either_dims(h, w)
+    pmap = workload.planted_map(dh, dw, h, w, rects)
+    got = sess.run_batch([page], det_map_override=[pmap])[0]
+    ref = o.run(page, det_map_override=pmap)
+    assert len(got.det_result) == len(ref.det_boxes) == lines
+    assert np.array_equal(np.stack([d.boxes.as_array() for d in got.det_result]), ref.det_boxes)
+    assert [c.label.label for c in got.cls_result] == list(ref.cls_labels)
+    for g, t in zip(got.rec_result, ref.rec_tokens):
+        assert np.array_equal(g.tokens, t)
