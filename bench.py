@@ -2,21 +2,28 @@
 """bench.py -- images/sec of the end-to-end PP-OCRv4 det+cls+rec path on MI355X.
 
 Metric (BASELINE.json): images/sec end-to-end PP-OCRv4 det+rec @960x960; 1 -> 8 GPU scaling.
-Workload at every N: BASELINE config C3 -- 32 synthetic 960x960 RGB pages per GPU per
-step (weak scaling), 32 planted text lines per page, full pipeline
-(resize/normalise -> DBNet -> DB post -> crops -> angle cls -> SVTR/CTC rec) through
-libretto_hip's rt_run_batch with pages resident in HBM.  One process per GPU; weights are
-broadcast once over RCCL (torch.distributed "nccl"); there is no per-step collective.
+Default workload at every N: BASELINE config C3 -- 32 synthetic 960x960 RGB pages per GPU per step (weak
+scaling), 32 planted text lines per page, full pipeline (resize/normalise -> DBNet -> DB post -> crops ->
+angle cls -> SVTR/CTC rec) through libretto_hip's rt_run_batch, fp32, pages resident in HBM when the timed
+region starts.  One process per GPU; weights are broadcast once over RCCL; there is no per-step collective.
 
-Prints ONE JSON line on rank 0 (see the driver contract) with `roofline` for the dominant
-kernel family (HIP-event times measured live on the session's stream during the timed
-region) and `cpu_baseline` (the CPU oracle timed on a bounded sample, rank 0, N=1 only).
+Other workloads (never substituted for the C3 headline; `config.workload` names what ran):
+  --workload c2   det only, one 960x960 page, batch 1 (launch-gap accounting in `c2`)
+  --workload c4   mixed page sizes; with --global-batch B one list of B pages is sharded over the ranks
+                  (retto_amd.dist.shard_pages), results are gathered in input order and checked for rank invariance
+  --workload c5   PP-OCRv4 server det+rec in fp16 (BASELINE config 5), own roofline against the fp16 MFMA peak
+
+Prints ONE JSON line on rank 0 (driver contract) with `roofline` for the dominant kernel family (HIP-event
+times measured live on the session's stream) and `cpu_baseline` (rank 0, N=1 only).
 """
 from __future__ import annotations
 
 import argparse
+import ctypes as C
+import hashlib
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -27,12 +34,14 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 FP32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: f32 MFMA / vector peak
+FP16_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: BF16/FP16 MFMA ~2.5 PF dense
+
+C4_SIZES = [(640, 640), (960, 960), (720, 1280), (1080, 1920), (1754, 1240), (3508, 2480)]
 
 
 def _flush_c_stdio():
-    import ctypes
     try:
-        ctypes.CDLL(None).fflush(None)
+        C.CDLL(None).fflush(None)
     except Exception:
         pass
 
@@ -40,23 +49,60 @@ def _flush_c_stdio():
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--pages", type=int, default=32, help="pages per GPU per step (C3: 32)")
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--pages", type=int, default=None, help="pages per GPU per step (C3: 32, C5: 128, C2: 1)")
     ap.add_argument("--size", type=int, default=960)
-    ap.add_argument("--lines", type=int, default=32, help="planted text lines per page")
-    ap.add_argument("--workload", default="c3", choices=["c3", "c4"],
-                    help="c3 (default, the metric's configuration): pages of --size x --size; c4: mixed page sizes "
-                         "drawn (seeded) from SURVEY 8d's set, 2480x3508 scans included (resize_both shrinks them)")
+    ap.add_argument("--lines", type=int, default=None, help="planted text lines per page (default 32; C2: 0)")
+    ap.add_argument("--workload", default="c3", choices=["c2", "c3", "c4", "c5"])
+    ap.add_argument("--global-batch", type=int, default=0,
+                    help="c4: one list of this many mixed-size pages sharded over the ranks (strong scaling); 0 = per-rank pages")
+    ap.add_argument("--dtype", default=None, choices=["f32", "f16"], help="arithmetic of the networks (default f32; c5: f16)")
+    ap.add_argument("--models", default=None, choices=["mobile", "server"], help="PP-OCRv4 graphs (default mobile; c5: server)")
+    ap.add_argument("--pages-on", default="hbm", choices=["hbm", "host"],
+                    help="where the pages are when the timed region starts (value is always quoted with hbm; the host rate is "
+                         "reported beside it in `pages_on_host`)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-torch", action="store_true", help="also time the torch-CPU oracle (second column of cpu_baseline)")
     ap.add_argument("--det-sub-batch", type=int, default=0)
-    ap.add_argument("--variants", type=str, default="", help="debug: gemm,dw,fuse kernel variants")
+    ap.add_argument("--variants", type=str, default="", help="debug: gemm,dw,flags kernel variants")
     ap.add_argument("--lanes", type=int, default=0, help="concurrent page streams inside rt_run_batch (0 = library default)")
-    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for single-GPU smoke tests of the multi-rank path)")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for CPU-side tests)")
     ap.add_argument("--share-gpu", action="store_true", help="test only: every rank uses device 0")
-    ap.add_argument("--cpu-pages", type=int, default=3, help="pages of the same workload timed on the CPU oracle")
+    ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the CPU baseline leg")
     ap.add_argument("--profile-all", action="store_true", help="print the per-family table to stderr")
-    return ap.parse_args()
+    a = ap.parse_args()
+    if a.workload == "c5":
+        a.dtype = a.dtype or "f16"; a.models = a.models or "server"
+        a.pages = a.pages or 128; a.steps = a.steps or 3; a.warmup = a.warmup if a.warmup is not None else 2
+    if a.workload == "c2":
+        a.pages = a.pages or 1; a.lines = 0 if a.lines is None else a.lines
+        a.steps = a.steps or 200; a.warmup = a.warmup if a.warmup is not None else 20
+    a.dtype = a.dtype or "f32"; a.models = a.models or "mobile"
+    a.pages = a.pages or 32; a.lines = 32 if a.lines is None else a.lines
+    a.steps = a.steps or 20; a.warmup = 5 if a.warmup is None else a.warmup
+    return a
+
+
+def git_sha():
+    try:
+        return subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short=12", "HEAD"], stderr=subprocess.DEVNULL).decode().strip()
+    except Exception:
+        return None
+
+
+def page_digest(lib, r, i):
+    """Stable digest of one page's discrete results (boxes, labels, token ids): what must not depend on the rank / batch."""
+    n = lib.rt_results_count(r, i)
+    hsh = hashlib.sha256()
+    if n:
+        hsh.update(np.ctypeslib.as_array(lib.rt_results_boxes(r, i), (n, 8)).tobytes())
+        hsh.update(np.ctypeslib.as_array(lib.rt_results_cls_labels(r, i), (n,)).tobytes())
+        for k in range(n):
+            tp = C.POINTER(C.c_int32)()
+            nt = lib.rt_results_rec_tokens(r, i, k, C.byref(tp))
+            hsh.update(bytes(np.ctypeslib.as_array(tp, (nt,)).tobytes()) if nt else b"-")
+    return hsh.hexdigest()[:16], n
 
 
 def main():
@@ -64,10 +110,9 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            print("bench.py: --gpus %d needs torch.distributed.run with %d ranks" % (a.gpus, a.gpus), file=sys.stderr)
-            sys.exit(2)
+    if world != a.gpus and world == 1 and a.gpus > 1:
+        print("bench.py: --gpus %d needs torch.distributed.run with %d ranks" % (a.gpus, a.gpus), file=sys.stderr)
+        sys.exit(2)
     import torch
     import torch.distributed as dist
     dist_on = world > 1 or os.environ.get("RT_BENCH_FORCE_DIST") == "1"  # (test hook: run the RCCL path with a single rank)
@@ -83,52 +128,83 @@ def main():
 
     import retto_amd
     from retto_amd import synth, workload, workmodel
+    from retto_amd.dist import broadcast_blobs, shard_pages
 
     # ---- weights: generated on rank 0, RCCL-broadcast once -------------------------------
     if rank == 0:
-        blobs = list(synth.synth_models(0))
+        blobs = list(synth.synth_server_models(0) if a.models == "server" else synth.synth_models(0))
     else:
         blobs = [None] * 4
     if dist_on:
-        from retto_amd.dist import broadcast_blobs
         blobs = broadcast_blobs(blobs, 4, rank, device=tdev)  # RCCL over xGMI, once
     det_b, cls_b, rec_b, dict_b = blobs
     cfg = retto_amd.RettoSessionConfig()
     cfg.det_sub_batch = a.det_sub_batch
     cfg.lanes = a.lanes
+    cfg.dtype = a.dtype
     cfg.worker_config = retto_amd.RettoHipWorkerConfig(device=device, models=retto_amd.RettoWorkerModelProvider(
         det=retto_amd.RettoWorkerModelSource.Blob(det_b), rec=retto_amd.RettoWorkerModelSource.Blob(rec_b),
         cls=retto_amd.RettoWorkerModelSource.Blob(cls_b)))
     cfg.rec_processor_config.character_source = retto_amd.RettoWorkerModelSource.Blob(dict_b)
     sess = retto_amd.RettoSession(cfg)
     lib, h = sess._hd.lib, sess._hd.h
+    lib.rt_model_info.restype = C.c_char_p
+    model_info = lib.rt_model_info(h).decode()
     if a.variants:
         lib.rt_debug_set_variants(*[int(v) for v in a.variants.split(',')])
 
-    # ---- synthetic pages + planted maps, staged to HBM once -------------------------------
-    import ctypes as C
+    # ---- the page list of this rank ---------------------------------------------------------
     S = a.size
-    C4_SIZES = [(640, 640), (960, 960), (720, 1280), (1080, 1920), (1754, 1240), (3508, 2480)]
-    rng_sizes = np.random.default_rng(77 + rank)
-    pages, maps, d_pages, d_maps, det_dims = [], [], [], [], []
-    for i in range(a.pages):
-        ph, pw = (S, S) if a.workload == "c3" else C4_SIZES[int(rng_sizes.integers(0, len(C4_SIZES)))]
-        page, rects = workload.planted_page(ph, pw, a.lines, seed=1000 * rank + i)
+    global_mode = a.workload == "c4" and a.global_batch > 0
+    if global_mode:
+        # ONE list of B pages (same seeds on every rank), LPT-sharded by estimated work; each rank keeps its shard in input order
+        rng_sizes = np.random.default_rng(77)
+        all_sizes = [C4_SIZES[int(rng_sizes.integers(0, len(C4_SIZES)))] for _ in range(a.global_batch)]
+        my_ids = sorted(shard_pages(all_sizes, world, rank, est_lines=[a.lines] * a.global_batch))
+        sizes = [all_sizes[i] for i in my_ids]
+        seeds = [5000 + i for i in my_ids]
+    else:
+        rng_sizes = np.random.default_rng(77 + rank)
+        sizes = [(S, S) if a.workload != "c4" else C4_SIZES[int(rng_sizes.integers(0, len(C4_SIZES)))] for _ in range(a.pages)]
+        seeds = [1000 * rank + i for i in range(a.pages)]
+        my_ids = list(range(a.pages))
+    n_my = len(sizes)
+
+    def make_page(sz, seed):
+        ph, pw = sz
+        page, rects = workload.planted_page(ph, pw, a.lines, seed=seed)
         rh, rw, dh, dw = C.c_int(), C.c_int(), C.c_int(), C.c_int()
         assert lib.rt_resize_both_dims(h, ph, pw, C.byref(rh), C.byref(rw)) == 0      # a2: session size limits
         assert lib.rt_det_input_dims(h, rh.value, rw.value, C.byref(dh), C.byref(dw)) == 0  # a3: det input size
         m = workload.planted_map(dh.value, dw.value, ph, pw, rects)
-        pages.append(page); maps.append(m); det_dims.append((dh.value, dw.value))
+        return page, m, (dh.value, dw.value)
+
+    pages, maps, d_pages, d_maps, det_dims = [], [], [], [], []
+    for sz, seed in zip(sizes, seeds):
+        page, m, dd = make_page(sz, seed)
+        pages.append(page); maps.append(m); det_dims.append(dd)
         for arr, lst in ((page, d_pages), (m, d_maps)):
             p = C.c_void_p()
             assert lib.rt_device_malloc(h, arr.nbytes, C.byref(p)) == 0
             assert lib.rt_memcpy_h2d(h, p, arr.ctypes.data, arr.nbytes) == 0
             lst.append(p.value)
     hs = [p.shape[0] for p in pages]; ws = [p.shape[1] for p in pages]
+    h_pages = [p.ctypes.data for p in pages]   # host-resident variant (pinned by the library's own staging)
+    chunk = a.pages if global_mode else n_my   # a step of the global mode walks the shard in calls of --pages pages
 
-    def step():
-        r = sess.run_batch_raw(d_pages, hs, ws, retto_amd.RT_MEM_DEVICE, d_maps)
-        return r
+    def step(on_host=False, keep=False):
+        outs = []
+        for c0 in range(0, n_my, chunk):
+            c1 = min(n_my, c0 + chunk)
+            if on_host:
+                r = sess.run_batch_raw(h_pages[c0:c1], hs[c0:c1], ws[c0:c1], retto_amd.RT_MEM_HOST, [m.ctypes.data for m in maps[c0:c1]])
+            else:
+                r = sess.run_batch_raw(d_pages[c0:c1], hs[c0:c1], ws[c0:c1], retto_amd.RT_MEM_DEVICE, d_maps[c0:c1])
+            if keep:
+                outs.append((r, c1 - c0))
+            else:
+                lib.rt_results_free(r)
+        return outs
 
     def barrier():
         lib.rt_synchronize(h)
@@ -141,20 +217,47 @@ def main():
     n_lines = 0
     checksum = 0.0
     for _ in range(max(a.warmup, 1)):
-        r = step()
-        n_lines = sum(lib.rt_results_count(r, i) for i in range(a.pages))
-        checksum = lib.rt_results_det_checksum(r)
-        widths_probe = r
-        lib.rt_results_free(r)
+        outs = step(keep=True)
+        n_lines = sum(lib.rt_results_count(r, i) for r, n in outs for i in range(n))
+        checksum = sum(lib.rt_results_det_checksum(r) for r, n in outs)
+        for r, n in outs:
+            lib.rt_results_free(r)
     # ---- timed region: EXACTLY K steps at the production setting (concurrent lanes) -------
+    on_host = a.pages_on == "host"
     barrier()
     t0 = time.perf_counter()
     for _ in range(a.steps):
-        r = step()
-        lib.rt_results_free(r)
+        step(on_host)
     barrier()
-    t1 = time.perf_counter()
-    elapsed = t1 - t0
+    elapsed = time.perf_counter() - t0
+    # the same steps with the pages starting in host memory (PCIe inside the timed region): reported beside `value`, never as it
+    other_rate = None
+    if not global_mode:
+        step(not on_host)
+        lib.rt_synchronize(h)
+        k2 = max(2, a.steps // 4)
+        t2 = time.perf_counter()
+        for _ in range(k2):
+            step(not on_host)
+        lib.rt_synchronize(h)
+        other_rate = n_my * k2 / (time.perf_counter() - t2)
+    # ---- global mode: gather every page's digest in INPUT order; rank invariance is checked on rank 0 below -------
+    gathered = None
+    if global_mode:
+        outs = step(keep=True)
+        mine = []
+        k = 0
+        for r, n in outs:
+            for i in range(n):
+                mine.append((my_ids[k], ) + page_digest(lib, r, i)); k += 1
+            lib.rt_results_free(r)
+        if dist_on:
+            lst = [None] * world
+            dist.all_gather_object(lst, mine)
+            gathered = sorted(x for part in lst for x in part)
+        else:
+            gathered = sorted(mine)
+        assert [g[0] for g in gathered] == list(range(a.global_batch)), "gather lost or duplicated pages"
     # ---- roofline pass (rank 0 only): the same K steps strictly serial on one stream with HIP
     # events around every launch.  Concurrent lanes share the GPU and stretch each other's
     # kernels, so a kernel's own duration can only be read from a serial pass.
@@ -162,15 +265,15 @@ def main():
     if rank == 0:
         lib.rt_set_lanes(h, 1)
         for _ in range(2):  # lane 0's arenas re-size for the whole batch
-            r = step(); lib.rt_results_free(r)
+            step()
         sess.profile_enable(True)
         lib.rt_synchronize(h)
         ts = time.perf_counter()
-        for _ in range(a.steps):
-            r = step()
-            lib.rt_results_free(r)
+        psteps = min(a.steps, 20)
+        for _ in range(psteps):
+            step()
         lib.rt_synchronize(h)
-        serial_ms = 1000.0 * (time.perf_counter() - ts) / a.steps
+        serial_ms = 1000.0 * (time.perf_counter() - ts) / psteps
         prof = sess.profile_get()
         sess.profile_enable(False)
         lib.rt_set_lanes(h, 1 << 20)
@@ -178,11 +281,11 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=tdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        cnt = torch.tensor([n_lines], dtype=torch.int64, device=tdev)
+        cnt = torch.tensor([n_lines, n_my], dtype=torch.int64, device=tdev)
         dist.all_reduce(cnt)
-        n_lines_total = int(cnt.item())
+        n_lines_total, pages_total = int(cnt[0].item()), int(cnt[1].item())
     else:
-        n_lines_total = n_lines
+        n_lines_total, pages_total = n_lines, n_my
 
     # RCCL prints a version banner through C stdio at init; in a pipe it would only come out at process exit,
     # i.e. after (rank 0) or interleaved with (other ranks) the JSON line.  Push it out now, on every rank.
@@ -193,116 +296,156 @@ def main():
         _flush_c_stdio()
         return
 
-    total_pages = world * a.pages * a.steps
-    value = total_pages / elapsed
+    value = pages_total * a.steps / elapsed
     ms_per_step = 1000.0 * elapsed / a.steps
 
-    # ---- roofline of the dominant kernel family -------------------------------------------
-    # rec line widths of this rank's pages, from the same planning rule as the pipeline
-    from retto_amd import _lib as L
-    res = sess.run_batch(pages[:a.pages], det_map_override=maps[:a.pages])
+    # ---- rank invariance of the global batch: pages that other ranks processed, re-run here one by one ---------------
+    rank_invariance = None
+    if global_mode:
+        foreign = [g for g in gathered if g[0] not in set(my_ids)] or gathered
+        sample = foreign[:: max(1, len(foreign) // 6)][:6]
+        bad = []
+        for gid, dig, nl in sample:
+            page, m, _dd = make_page(all_sizes[gid], 5000 + gid)
+            r = sess.run_batch_raw([page.ctypes.data], [page.shape[0]], [page.shape[1]], retto_amd.RT_MEM_HOST, [m.ctypes.data])
+            d2 = page_digest(lib, r, 0)
+            lib.rt_results_free(r)
+            if d2 != (dig, nl):
+                bad.append(gid)
+        if bad:
+            raise RuntimeError("bench rank-invariance check failed for pages %s" % bad)
+        rank_invariance = {"pages_checked": [g[0] for g in sample], "ok": True,
+                           "digest_of_all_pages": hashlib.sha256("".join(g[1] for g in gathered).encode()).hexdigest()[:16]}
+
+    # ---- work model of what ran (rank 0's pages) ------------------------------------------------------------
     widths = []
-    for pr in res:
-        dims = []
-        for d in pr.det_result:
-            b = d.boxes.as_array().reshape(1, 8).astype(np.float32)
-            wv = np.zeros(1, np.int32); hv = np.zeros(1, np.int32)
-            lib.rt_crop_dims(b.ctypes.data, 1, wv.ctypes.data, hv.ctypes.data)
-            dims.append((int(hv[0]), int(wv[0])))
-        order = sorted(range(len(dims)), key=lambda i: -(dims[i][0] / dims[i][1]))
-        ratio = np.float32(320) / np.float32(48)
-        for s0 in range(0, len(order), 6):
-            idx = order[s0:s0 + 6]
-            for i in idx:
-                ratio = max(ratio, np.float32(dims[i][1]) / np.float32(dims[i][0]))
-            widths += [lib.rt_resize_norm_width(48, 320, float(ratio))] * len(idx)
-    work = workmodel.det_work(det_dims)
-    for k, v in workmodel.rec_work(widths).items():
+    if a.lines > 0:
+        res = []
+        for c0 in range(0, n_my, 32):
+            res += sess.run_batch(pages[c0:c0 + 32], det_map_override=maps[c0:c0 + 32])
+        for pr in res:
+            dims = []
+            for d in pr.det_result:
+                b = d.boxes.as_array().reshape(1, 8).astype(np.float32)
+                wv = np.zeros(1, np.int32); hv = np.zeros(1, np.int32)
+                lib.rt_crop_dims(b.ctypes.data, 1, wv.ctypes.data, hv.ctypes.data)
+                dims.append((int(hv[0]), int(wv[0])))
+            order = sorted(range(len(dims)), key=lambda i: -(dims[i][0] / dims[i][1]))
+            ratio = np.float32(320) / np.float32(48)
+            for s0 in range(0, len(order), 6):
+                idx = order[s0:s0 + 6]
+                for i in idx:
+                    ratio = max(ratio, np.float32(dims[i][1]) / np.float32(dims[i][0]))
+                widths += [lib.rt_resize_norm_width(48, 320, float(ratio))] * len(idx)
+    if a.models == "server":
+        det_w, rec_w = workmodel.sdet_work(det_dims), workmodel.srec_work(widths)
+    elif a.dtype == "f16":
+        det_w, rec_w = workmodel.det16_work(det_dims), workmodel.rec16_work(widths)
+    else:
+        det_w, rec_w = workmodel.det_work(det_dims), workmodel.rec_work(widths)
+    work = {k: dict(v) for k, v in det_w.items()}
+    for k, v in rec_w.items():
         if k in work:
             work[k]["bytes"] += v["bytes"]; work[k]["flops"] += v["flops"]
         else:
             work[k] = dict(v)
-    nets = {name[4:]: ms / a.steps for name, (ms, calls) in prof.items() if calls and name.startswith("net/")}
+    psteps = min(a.steps, 20)
+    nets = {name[4:]: ms / psteps for name, (ms, calls) in prof.items() if calls and name.startswith("net/")}
     fams = sorted(((ms, calls, name) for name, (ms, calls) in prof.items() if calls and not name.startswith("net/")), reverse=True)
     total_ms = sum(f[0] for f in fams)
     if a.profile_all:
         for ms, calls, name in fams:
             wk = work.get(name, {"bytes": 0.0, "flops": 0.0})
-            per_step_ms = ms / a.steps
-            print("%-16s %9.3f ms/step %6d launches/step  %8.1f GB/s  %7.2f TFLOP/s" % (
-                name, per_step_ms, calls // a.steps, wk["bytes"] / per_step_ms / 1e6 if per_step_ms else 0,
+            per_step_ms = ms / psteps
+            print("%-18s %9.3f ms/step %6d launches/step  %8.1f GB/s  %8.2f TFLOP/s" % (
+                name, per_step_ms, calls // psteps, wk["bytes"] / per_step_ms / 1e6 if per_step_ms else 0,
                 wk["flops"] / per_step_ms / 1e9 if per_step_ms else 0), file=sys.stderr)
-        print("sum of kernel families: %.2f ms/step; wall %.2f ms/step" % (total_ms / a.steps, ms_per_step), file=sys.stderr)
+        print("sum of kernel families: %.2f ms/step; serial wall %.2f ms/step; production wall %.2f ms/step" % (
+            total_ms / psteps, serial_ms, ms_per_step), file=sys.stderr)
     roofline = None
     for ms, calls, name in fams:
         if name in work:
             wk = work[name]
-            launches_per_step = calls / a.steps
+            launches_per_step = calls / psteps
             avg_ms = ms / calls
             bytes_per_launch = wk["bytes"] / launches_per_step
             flops_per_launch = wk["flops"] / launches_per_step
             gbs = bytes_per_launch / (avg_ms * 1e-3) / 1e9
             tfs = flops_per_launch / (avg_ms * 1e-3) / 1e12
-            hbm_frac, mfma_frac = gbs / HBM_PEAK_GBS, tfs / FP32_PEAK_TFLOPS
+            mfma_peak = FP16_PEAK_TFLOPS if "16" in name.split("/")[0] else FP32_PEAK_TFLOPS  # fp16 families carry "16" in their label
+            hbm_frac, mfma_frac = gbs / HBM_PEAK_GBS, tfs / mfma_peak
             if hbm_frac >= mfma_frac:
                 roofline = {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                             "frac": round(hbm_frac, 4), "traffic": None}
             else:
-                roofline = {"bound": "mfma", "achieved": round(tfs, 2), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                roofline = {"bound": "mfma", "achieved": round(tfs, 2), "peak": mfma_peak, "unit": "TFLOP/s",
                             "frac": round(mfma_frac, 4), "traffic": None}
-            # HBM bytes per launch from the committed PMC passes of this same command (profiles/pmc_traffic.json,
-            # tools/pmc_summary.py: separate FETCH_SIZE / WRITE_SIZE passes, gfx950 corrections); only valid for
-            # the default workload the passes were taken on
-            pmc_symbol = {"gemm_pw/k_gemm_wide<4,5,4,3>": "k_gemm_wide<4, 5, 4, 3, 0, 0, 0, 0, 0>",
-                          "gemm_pw/k_gemm_wide<2,5,4,3>+se": "k_gemm_wide<2, 5, 4, 3, 0, 0, 1, 0, 0>",
-                          "gemm_pw/k_gemm_wide<2,4,4,2>": "k_gemm_wide<2, 4, 4, 2, 0, 0, 0, 0, 0>"}.get(name)
-            pmc_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_traffic.json")
-            if pmc_symbol and (a.workload, a.pages, a.size, a.lines) == ("c3", 32, 960, 32) and os.path.exists(pmc_path):
-                k = json.load(open(pmc_path))["kernels"].get(pmc_symbol)
-                if k:
+            # HBM bytes per launch come from separate rocprofv3 --pmc passes (tools/pmc_summary.py: FETCH_SIZE / WRITE_SIZE,
+            # gfx950 corrections) committed as profiles/pmc_traffic.json together with the git SHA and command they were taken
+            # at: used only when they describe THIS workload, and stamped with that SHA (stale = different from HEAD).
+            pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+            if os.path.exists(pmc_path):
+                pj = json.load(open(pmc_path))
+                same_workload = pj.get("workload") == {"workload": a.workload, "pages": a.pages, "size": a.size, "lines": a.lines,
+                                                       "dtype": a.dtype, "models": a.models}
+                k = pj.get("kernels", {}).get(pj.get("labels", {}).get(name, ""))
+                if same_workload and k:
+                    head = git_sha()
                     roofline["traffic"] = k["fetch_bytes_per_launch"] + k["write_bytes_per_launch"]
-                    roofline["traffic_source"] = "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload, FETCH_SIZE x2)"
+                    roofline["traffic_source"] = {"file": "profiles/pmc_traffic.json", "collected_at_sha": pj.get("git_sha"),
+                                                  "head_sha": head, "stale": bool(head and pj.get("git_sha") and head != pj.get("git_sha")),
+                                                  "how": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (FETCH_SIZE x2 on gfx950)"}
                     if "sq" in k:  # SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8) and the clock of that pass
                         roofline["mfma_util_pmc"] = k["sq"]["mfma_util"]
                         roofline["clock_ghz_pmc"] = k["sq"]["clock_ghz"]
             roofline.update({"kernel": name, "avg_launch_ms": round(avg_ms, 4), "launches_per_step": launches_per_step,
-                             "measured": "HIP events on the session stream, serial pass (lanes=1) of the same %d steps, %.2f ms/step" % (a.steps, serial_ms),
+                             "measured": "HIP events on the session stream, serial pass (lanes=1) of %d steps, %.2f ms/step" % (psteps, serial_ms),
                              "share_of_kernel_time": round(ms / total_ms, 3),
                              "algorithmic_bytes_per_launch": int(bytes_per_launch),
                              "algorithmic_flops_per_launch": int(flops_per_launch)})
             break
 
-    # ---- whole networks (HIP events around DetNet / ClsNet / RecNet::run in the same serial pass) -----------
+    # ---- whole networks (HIP events around the det / cls / rec forward in the same serial pass) -----------
     # north_star's "DBNet-backbone achieved HBM": B_layer = 500 MB per 960x960 page (every conv layer's
     # input read + output written once, fp32) over the det network's device time, against the 8 TB/s peak.
     networks = None
     if nets:
-        det_flops = sum(v["flops"] for v in workmodel.det_work(det_dims).values())
-        rec_flops = sum(v["flops"] for v in workmodel.rec_work(widths).values())
-        b_layer = 500e6 * sum(dh_ * dw_ for dh_, dw_ in det_dims) / (960.0 * 960.0)
+        det_flops = sum(v["flops"] for v in det_w.values())
+        rec_flops = sum(v["flops"] for v in rec_w.values())
+        det_bytes = sum(v["bytes"] for v in det_w.values())
+        mfma_peak = FP16_PEAK_TFLOPS if a.dtype == "f16" else FP32_PEAK_TFLOPS
         networks = {"det_ms": round(nets.get("det", 0.0), 3), "cls_ms": round(nets.get("cls", 0.0), 3),
                     "rec_ms": round(nets.get("rec", 0.0), 3),
                     "det_tflops": round(det_flops / (nets["det"] * 1e-3) / 1e12, 2) if nets.get("det") else None,
                     "rec_tflops": round(rec_flops / (nets["rec"] * 1e-3) / 1e12, 2) if nets.get("rec") else None,
-                    "det_b_layer_gbs": round(b_layer / (nets["det"] * 1e-3) / 1e9, 1) if nets.get("det") else None,
-                    "det_b_layer_frac_of_hbm_peak": round(b_layer / (nets["det"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if nets.get("det") else None,
-                    "note": "per step of %d pages, one lane; fp32 MFMA peak %.1f TFLOP/s, HBM peak %.0f GB/s" % (a.pages, FP32_PEAK_TFLOPS, HBM_PEAK_GBS)}
+                    "det_layer_bytes_gbs": round(det_bytes / (nets["det"] * 1e-3) / 1e9, 1) if nets.get("det") else None,
+                    "note": "per step of %d pages, one lane; %s MFMA peak %.1f TFLOP/s, HBM peak %.0f GB/s; det_layer_bytes = per-launch "
+                            "algorithmic bytes of the det net as executed (retto_amd/workmodel.py)" % (n_my, a.dtype, mfma_peak, HBM_PEAK_GBS)}
+        if a.models == "mobile" and a.dtype == "f32" and nets.get("det"):
+            b_layer = 500e6 * sum(dh_ * dw_ for dh_, dw_ in det_dims) / (960.0 * 960.0)
+            networks["det_b_layer_gbs"] = round(b_layer / (nets["det"] * 1e-3) / 1e9, 1)
+            networks["det_b_layer_frac_of_hbm_peak"] = round(b_layer / (nets["det"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
 
-    # ---- CPU baseline: the oracle on a bounded sample of the same workload -------------------
+    # ---- C2: launch-gap accounting of the batch-1 det path ----------------------------------------------------
+    c2 = None
+    if a.workload == "c2":
+        launches = sum(calls for _ms, calls, _n in fams) / psteps
+        c2 = {"det_net_ms": round(nets.get("det", 0.0), 4), "kernel_ms_per_step": round(total_ms / psteps, 4),
+              "serial_wall_ms_per_step": round(serial_ms, 4), "production_wall_ms_per_step": round(ms_per_step, 4),
+              "launches_per_step": round(launches, 1),
+              "gap_ms_per_step": round(serial_ms - total_ms / psteps, 4),
+              "note": "one 960x960 page, no text lines: det pre-process + DBNet + DB post; gap = serial wall - sum of kernel time "
+                      "(host launch overhead, the count round trip, event bookkeeping)"}
+
+    # ---- CPU baseline (rank 0, N = 1): the C++ / OpenMP restatement of the same pipeline on the host cores ----
     cpu_baseline = None
     if world == 1 and not a.no_cpu_baseline:
-        import torch as _t
-        from oracle.pipeline import OracleSession
-        o = OracleSession(det_b, cls_b, rec_b, dict_b)
-        k = max(1, min(a.cpu_pages, a.pages))
-        t0c = time.perf_counter()
-        for i in range(k):
-            o.run(pages[i], det_map_override=maps[i])
-        dt = time.perf_counter() - t0c
-        cpu_baseline = {"value": round(k / dt, 4), "unit": "images/s", "cores": _t.get_num_threads(), "kind": "port",
-                        "sample": "%d page(s) of the same %dx%d / %d-line workload through the CPU oracle "
-                                  "(oracle/pipeline.py: torch-CPU fp32 nets + C++ pre/post restatement); "
-                                  "reference ort-CPU itself is not runnable here" % (k, S, S, a.lines)}
+        from oracle import cpu_baseline as CB
+        if a.models == "mobile":   # fresh interpreter: no HIP runtime or torch thread pools inside the timed CPU process
+            cpu_baseline = CB.run_subprocess(S, a.lines, budget_s=a.cpu_seconds, with_torch=a.cpu_torch)
+        else:
+            cpu_baseline = CB.run_torch_server(det_b, cls_b, rec_b, dict_b, pages, maps, budget_s=a.cpu_seconds,
+                                               describe="%dx%d / %d-line pages of this workload" % (S, S, a.lines))
 
     # ---- self-check outside the timed region (rank 0): a page's result must not depend on what else is in the batch.
     # Page 0 alone (small launches, other kernel shapes) against page 0 inside the batch -- boxes and token ids equal,
@@ -317,30 +460,45 @@ def main():
             nt = lib.rt_results_rec_tokens(r, 0, k, C.byref(tp))
             toks.append([tp[t] for t in range(nt)])
         return boxes, sc, toks
-    r_b = step(); in_batch = _page0(r_b); lib.rt_results_free(r_b)
+    c1 = min(n_my, chunk)
+    r_b = sess.run_batch_raw(d_pages[:c1], hs[:c1], ws[:c1], retto_amd.RT_MEM_DEVICE, d_maps[:c1]); in_batch = _page0(r_b); lib.rt_results_free(r_b)
     r_a = sess.run_batch_raw(d_pages[:1], hs[:1], ws[:1], retto_amd.RT_MEM_DEVICE, d_maps[:1]); alone = _page0(r_a); lib.rt_results_free(r_a)
-    if not (np.array_equal(in_batch[0], alone[0]) and in_batch[2] == alone[2] and
-            np.allclose(in_batch[1], alone[1], rtol=1e-4, atol=1e-6, equal_nan=True)):
+    tol = dict(rtol=1e-4, atol=1e-6) if a.dtype == "f32" else dict(rtol=5e-2, atol=5e-3)
+    if not (np.array_equal(in_batch[0], alone[0]) and in_batch[2] == alone[2] and np.allclose(in_batch[1], alone[1], equal_nan=True, **tol)):
         raise RuntimeError("bench self-check failed: page 0 differs between the batch and a run of its own")
     selfcheck = {"batch_invariance_page0": True, "lines": int(len(in_batch[2]))}
 
+    names = {"c2": "C2: PP-OCRv4 %s det only (DBNet + DB post, no text lines), one %dx%d page per call (batch 1), " % (a.models, S, S),
+             "c3": "C3: PP-OCRv4 %s det+cls+rec full pipeline, batch=%d pages of %dx%d per GPU, " % (a.models, n_my, S, S),
+             "c4": ("C4: PP-OCRv4 %s det+cls+rec full pipeline, ONE global batch of %d mixed-size pages (640x640 .. 2480x3508) sharded over "
+                    "%d rank(s) by estimated work (LPT), results gathered in input order, " % (a.models, a.global_batch, world)) if global_mode else
+                   "C4: PP-OCRv4 %s det+cls+rec full pipeline, batch=%d mixed-size pages per GPU (640x640 .. 2480x3508), " % (a.models, n_my),
+             "c5": "C5: PP-OCRv4 SERVER det (PPHGNet_small + LKPAN + PFHeadLocal) + mobile cls + SERVER rec (PPHGNet_small + SVTR/CTC), "
+                   "fp16 MFMA, batch=%d pages of %dx%d per GPU, " % (n_my, S, S)}
+    wl = names[a.workload] + ("%d planted lines/page (planted DB map drives box extraction; det net fully executed, checksum %.6g); "
+                               "pages %s when the timed region starts" % (
+                                   a.lines, checksum, "resident in HBM" if not on_host else "in host memory (H2D inside the timed region)"))
     out = {
         "metric": "images/sec end-to-end PP-OCRv4 det+rec @960x960",
         "value": round(value, 3), "unit": "images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-        "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
-        "config": {"workload": ("C3: PP-OCRv4 mobile det+cls+rec full pipeline, batch=%d pages of %dx%d per GPU, " % (a.pages, S, S)
-                                if a.workload == "c3" else
-                                "C4: PP-OCRv4 mobile det+cls+rec full pipeline, batch=%d mixed-size pages per GPU (640x640 .. 2480x3508), " % a.pages) +
-                               "%d planted lines/page (planted DB map drives box extraction; det net fully executed, "
-                               "checksum %.6g)" % (a.lines, checksum),
-                   "pages_per_gpu_per_step": a.pages, "lines_per_step_all_gpus": n_lines_total,
-                   "weights": "seeded synthetic, PP-OCRv4 mobile shapes", "parallelism": "dp%d (pages sharded, no per-step collective)" % world},
+        "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong" if global_mode else "weak",
+        "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
+        "config": {"workload": wl, "pages_per_gpu_per_step": n_my, "lines_per_step_all_gpus": n_lines_total,
+                   "weights": "seeded synthetic, PP-OCRv4 %s shapes" % a.models, "networks": model_info,
+                   "parallelism": "dp%d (pages sharded, no per-step collective)" % world},
         "roofline": roofline,
         "cpu_baseline": cpu_baseline,
         "networks": networks,
         "selfcheck": selfcheck,
     }
+    if other_rate is not None:
+        out["pages_on_host" if not on_host else "pages_on_hbm"] = {
+            "value": round(other_rate * (world if not global_mode else 1), 3), "unit": "images/s",
+            "note": "same steps on rank 0 with the pages starting in %s, x%d ranks" % ("host memory (H2D copies inside the timed region)" if not on_host else "HBM", world)}
+    if c2:
+        out["c2"] = c2
+    if rank_invariance:
+        out["rank_invariance"] = rank_invariance
     sess.close()
     if dist_on:
         dist.destroy_process_group()

@@ -156,3 +156,183 @@ def page_flops(det_hw: Tuple[int, int], widths: Iterable[int]) -> float:
     d = sum(v["flops"] for v in det_work([det_hw]).values())
     r = sum(v["flops"] for v in rec_work(widths).values())
     return d + r
+
+
+# ---------------------------------------------------------------------------------------------------------
+# fp16 family (rt_config.dtype = f16): labels of nets_f16.cpp's profiler scopes.  Bytes: every launch reads its input
+# activations once and writes its output once at 2 bytes per element (real channel counts) + the fp16 weights once.
+# ---------------------------------------------------------------------------------------------------------
+H2 = 2  # bytes per fp16
+
+
+def conv16_label(kh: int, kw: int, n: int) -> str:
+    """Mirror of nh::conv16_label (retto_amd/csrc/nn_f16.hip)."""
+    if kh == 1 and kw == 1:
+        return "gemm16/thin" if n <= 64 else "gemm16"
+    if (kh, kw) == (3, 3):
+        return "conv16_3x3"
+    if kh == 9:
+        return "conv16_9x9"
+    return "conv16_kxk"
+
+
+def _conv16(add, pix_in, pix_out, cin, cout, kh, kw):
+    add(conv16_label(kh, kw, cout), (pix_in * cin + pix_out * cout) * H2 + kh * kw * cin * cout * H2, 2.0 * pix_out * kh * kw * cin * cout)
+
+
+def _lc16(add, h, ww, blocks):
+    for name, k, cin, cout, sh, sw, se in blocks:
+        ho, wo = _down(h, sh), _down(ww, sw)
+        add("dwconv16_%d" % k, (h * ww + ho * wo) * cin * H2 + k * k * cin * H2, 2.0 * ho * wo * cin * k * k)
+        if se:
+            add("se_pool_fc16", ho * wo * cin * H2)
+            add("scale_channels16", 2 * ho * wo * cin * H2)
+        _conv16(add, ho * wo, ho * wo, cin, cout, 1, 1)
+        h, ww = ho, wo
+        yield name, h, ww
+
+
+def _neck16(add, T, C, classes):
+    D = 120
+    add("avgpool16", (6 * T + T) * C * H2)
+    _conv16(add, T, T, C, C // 8, 1, 3)
+    _conv16(add, T, T, C // 8, D, 1, 1)
+    add("f16_to_f32", 2 * T * D * 6); add("f32_to_f16", T * D * 6)
+    for cin, cout, cnt in ((120, 360, 2), (120, 120, 2), (120, 240, 2), (240, 120, 2)):
+        add("gemm_neck", cnt * (T * (cin + cout) * F + cin * cout * F), cnt * 2.0 * T * cin * cout)
+    add("attention", 2 * T * (360 + 120) * F, 2 * 2 * 2.0 * T * T * 120)
+    add("layernorm", 5 * 3 * T * 120 * F)
+    _conv16(add, T, T, D, C, 1, 1)
+    _conv16(add, T, T, 2 * C, C // 8, 1, 3)
+    _conv16(add, T, T, C // 8, D, 1, 1)
+    tiles = ((classes + 15) // 16 * 16 + 127) // 128
+    add("gemm_ctc_fc", T * 120 * F + 120 * classes * F + T * tiles * 12, 2.0 * T * 120 * classes)
+    add("ctc_argmax", T * tiles * 12 + T * 8)
+
+
+def _adder():
+    w = defaultdict(lambda: {"bytes": 0.0, "flops": 0.0})
+
+    def add(fam, b, f=0.0):
+        w[fam]["bytes"] += b; w[fam]["flops"] += f
+    return w, add
+
+
+def det16_work(pages: Iterable[Tuple[int, int]]) -> Dict[str, Dict[str, float]]:
+    """PP-OCRv4 mobile det in fp16 (DetNetH)."""
+    w, add = _adder()
+    for H, W in pages:
+        add("u8_to_f16", H * W * 3 + H * W * 8 * H2)
+        h, ww = _down(H, 2), _down(W, 2)
+        _conv16(add, H * W, h * ww, 8, 16, 3, 3)
+        taps = {}
+        for name, h, ww in _lc16(add, h, ww, synth.DET_BLOCKS):
+            for j, (tn, tc, oc) in enumerate(synth.DET_TAPS):
+                if tn == name:
+                    _conv16(add, h * ww, h * ww, tc, oc, 1, 1)
+                    taps[j] = (h, ww, oc)
+        for j in range(4):
+            h, ww, oc = taps[j]
+            _conv16(add, h * ww, h * ww, oc, 96, 1, 1)
+            add("se_pool_fc16", h * ww * 96 * H2)
+            add("scale_channels16" if j == 3 else "upsample_add16", (2 * h * ww * 96 + (0 if j == 3 else taps[j + 1][0] * taps[j + 1][1] * 96)) * H2)
+            _conv16(add, h * ww, h * ww, 96, 24, 3, 3)
+            add("se_pool_fc16", h * ww * 24 * H2)
+        h4, w4, _ = taps[0]
+        add("fpn_concat16", (sum(taps[j][0] * taps[j][1] for j in range(4)) * 24 + h4 * w4 * 96) * H2)
+        _conv16(add, h4 * w4, h4 * w4, 96, 24, 3, 3)
+        _conv16(add, h4 * w4, h4 * w4, 24, 96, 1, 1)
+        add("pixel_shuffle16", 2 * h4 * w4 * 96 * H2)
+        add("db_head_tail16", 4 * h4 * w4 * 24 * H2 + H * W * F, 2.0 * 4 * h4 * w4 * 24 * 4)
+    return dict(w)
+
+
+def rec16_work(widths: Iterable[int], classes: int = synth.REC_CLASSES) -> Dict[str, Dict[str, float]]:
+    """PP-OCRv4 mobile rec in fp16 (RecNetH)."""
+    w, add = _adder()
+    for W in widths:
+        H = 48
+        add("f32_to_f16", H * W * (16 + 16))
+        h, ww = _down(H, 2), _down(W, 2)
+        _conv16(add, H * W, h * ww, 8, 16, 3, 3)
+        for _name, h, ww in _lc16(add, h, ww, synth.REC_BLOCKS):
+            pass
+        _neck16(add, (ww - 2) // 2 + 1, 480, classes)
+    return dict(w)
+
+
+def _hgnet_work(add, h, ww, stages, strides):
+    """PPHGNet_small from the stem output resolution (h, ww) on; yields (stage index, h, w, channels)."""
+    for si, ((name, cin, mid, cout, blocks, down), (sh, sw)) in enumerate(zip(stages, strides)):
+        if down:
+            ho, wo = _down(h, sh), _down(ww, sw)
+            add("dwconv16_3", (h * ww + ho * wo) * cin * H2, 2.0 * ho * wo * cin * 9)
+            h, ww = ho, wo
+        for b in range(blocks):
+            bin_ = cin if b == 0 else cout
+            c = bin_
+            for _l in range(synth.HG_LAYERS):
+                _conv16(add, h * ww, h * ww, c, mid, 3, 3)
+                c = mid
+            _conv16(add, h * ww, h * ww, bin_ + synth.HG_LAYERS * mid, cout, 1, 1)
+            add("se_pool_fc16", h * ww * cout * H2 + cout * cout * F)
+            add("scale_channels16", (2 + (1 if b > 0 else 0)) * h * ww * cout * H2)
+        yield si, h, ww, cout
+
+
+def sdet_work(pages: Iterable[Tuple[int, int]]) -> Dict[str, Dict[str, float]]:
+    """PP-OCRv4 server det (DetServerH): PPHGNet_small + LKPAN(256, intracl) + PFHeadLocal, as executed -- the IntraCL branch
+    triples are folded into one k x k conv, PFHeadLocal's 3x3 on the upsampled feature runs as four 2x2 phase convs
+    (K = 4 x 80) at half resolution."""
+    w, add = _adder()
+    for H, W in pages:
+        add("u8_to_f16", H * W * 3 + H * W * 8 * H2)
+        h, ww = _down(H, 2), _down(W, 2)
+        _conv16(add, H * W, h * ww, 8, 64, 3, 3)
+        _conv16(add, h * ww, h * ww, 64, 64, 3, 3)
+        _conv16(add, h * ww, h * ww, 64, 128, 3, 3)
+        h4, w4 = _down(h, 2), _down(ww, 2)
+        add("maxpool16", (h * ww + h4 * w4) * 128 * H2)
+        lv = []
+        for si, hh, wv, c in _hgnet_work(add, h4, w4, synth.HG_STAGES_DET, [(1, 1)] + synth.HG_STRIDES_DET[1:]):
+            lv.append((hh, wv, c))
+        for j, (hh, wv, c) in enumerate(lv):
+            px = hh * wv
+            _conv16(add, px, px, c, 256, 1, 1)
+            if j < 3:
+                add("upsample_add16", (2 * px + lv[j + 1][0] * lv[j + 1][1]) * 256 * H2)
+            _conv16(add, px, px, 256, 64, 9, 9)
+            if j > 0:
+                _conv16(add, lv[j - 1][0] * lv[j - 1][1], px, 64, 64, 3, 3)
+            _conv16(add, px, px, 64, 64, 9, 9)
+            _conv16(add, px, px, 64, 32, 1, 1)
+            for k in (7, 5, 3):
+                add("conv16_kxk", 2 * px * 32 * H2 + k * k * 32 * 32 * H2, 2.0 * px * k * k * 32 * 32)
+            _conv16(add, px, px, 32, 64, 1, 1)
+            if j > 0:
+                add("fpn_concat16", (px + h4 * w4) * 64 * H2)
+        p4 = h4 * w4
+        _conv16(add, p4, p4, 256, 64, 3, 3)
+        _conv16(add, p4, p4, 64, 256, 1, 1)
+        add("pixel_shuffle16", 2 * p4 * 256 * H2)
+        p2 = h * ww
+        add("db_head_tail16", p2 * 64 * H2 + H * W * F, 2.0 * p2 * 64 * 4)
+        add("map_window16", H * W * F + p2 * 16 * H2)
+        add("conv16_local", 4 * (p2 * 80 * H2 + p2 * 2 * F) + 4 * 4 * 80 * 64 * H2, 4 * 2.0 * p2 * (4 * 80 * 64 + 64))
+    return dict(w)
+
+
+def srec_work(widths: Iterable[int], classes: int = synth.REC_CLASSES) -> Dict[str, Dict[str, float]]:
+    """PP-OCRv4 server rec (RecServerH)."""
+    w, add = _adder()
+    for W in widths:
+        H = 48
+        add("f32_to_f16", H * W * (16 + 16))
+        h, ww = _down(H, 2), _down(W, 2)
+        _conv16(add, H * W, h * ww, 8, 64, 3, 3)
+        _conv16(add, h * ww, h * ww, 64, 64, 3, 3)
+        _conv16(add, h * ww, h * ww, 64, 128, 3, 3)
+        for _si, h, ww, _c in _hgnet_work(add, h, ww, synth.HG_STAGES_REC, synth.HG_STRIDES_REC):
+            pass
+        _neck16(add, (ww - 2) // 2 + 1, 1024, classes)
+    return dict(w)

@@ -275,3 +275,34 @@ def test_unclip_area_matches_minkowski_sum():
         out = R.unclip(quad)
         expect = A + P * d + np.pi * d * d
         assert abs(shoelace(out) - expect) <= 0.012 * expect + 2 * P
+
+
+def test_cpp_openmp_nets_match_the_torch_oracle(models):
+    """oracle/nets_cpu.cpp (the C++ / OpenMP networks of bench.py's cpu_baseline leg) is the same fp32 graph as
+    oracle/nets_torch.py: outputs agree to fp32 accumulation-order noise."""
+    import torch
+    from oracle import cpu_baseline as CB
+    from oracle import nets_torch as N
+    det, cls, rec, _dic = models
+    nets = CB.CpuNets(det, cls, rec)
+    try:
+        rng = np.random.default_rng(3)
+        x = rng.uniform(-1, 1, (2, 3, 64, 96)).astype(np.float32)
+        assert np.abs(nets.det(x) - N.det_forward(N.read_blob(det), torch.from_numpy(x)).numpy()).max() <= 1e-4
+        x = rng.uniform(-1, 1, (4, 3, 48, 192)).astype(np.float32)
+        assert np.abs(nets.cls(x) - N.cls_forward(N.read_blob(cls), torch.from_numpy(x)).numpy()).max() <= 1e-4
+        x = rng.uniform(-1, 1, (2, 3, 48, 333)).astype(np.float32)
+        x[:, :, :, 200:] = 0.0
+        got, ref = nets.rec(x), N.rec_forward(N.read_blob(rec), torch.from_numpy(x)).numpy()
+        assert got.shape == ref.shape and np.abs(got - ref).max() <= 2e-4
+    finally:
+        nets.close()
+
+
+def test_cpu_baseline_protocol():
+    """bench.py's cpu_baseline leg: fresh interpreter, warm-up + 3 repetitions, CPU count, 1-thread figure, per-stage breakdown."""
+    from oracle import cpu_baseline as CB
+    out = CB.run_subprocess(160, 2, budget_s=4.0)
+    assert out["kind"] == "port" and out["unit"] == "images/s" and out["value"] and out["value"] > 0 and out["cores"] >= 1
+    assert set(out["stage_cpu_ms_per_page"]) == {"det", "cls", "rec", "pre_post"}
+    assert "3 timed repetitions" in out["sample"] and out["one_thread_images_per_s"] > 0
