@@ -99,10 +99,27 @@ class CpuNets:
 
 
 def host_cpus():
+    """CPUs this process may actually use: the affinity mask, capped by the cgroup CPU quota (the GPU box runs the bench in a
+    pod whose quota -- e.g. 16 CPUs of 256 visible -- is what bounds any CPU baseline: more threads than that only throttle)."""
     try:
-        return len(os.sched_getaffinity(0))
+        n = len(os.sched_getaffinity(0))
     except Exception:
-        return os.cpu_count() or 1
+        n = os.cpu_count() or 1
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]            # cgroup v2: "max 100000" or "<quota> <period>"
+        if q != "max":
+            quota = float(q) / float(per)
+    except Exception:
+        try:
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read()); per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / per
+        except Exception:
+            pass
+    if quota:
+        n = max(1, min(n, int(quota + 0.5)))
+    return n
 
 
 def _make_pages(size, lines, n, seed0=0):
@@ -190,7 +207,7 @@ def measure(size=960, lines=32, budget_s=20.0, with_torch=False):
     P = max(1, cpus // T)
     reps = 3
     # every repetition gives each worker the same number of pages; bounded by the budget (setup + warm-up included)
-    per_worker = max(1, int((budget_s * 0.55 / reps) / (sec_page_4t * 1.3)))
+    per_worker = max(1, min(8, int((budget_s * 0.55 / reps) / (sec_page_4t * 1.5))))
     n_pages = P * per_worker
     rates, stages = _run_config(P, T, size, lines, n_pages, reps)
     one_thread = None
@@ -200,9 +217,9 @@ def measure(size=960, lines=32, budget_s=20.0, with_torch=False):
     out = {"value": round(float(np.median(rates)), 4), "unit": "images/s", "cores": cpus, "kind": "port",
            "sample": "%d pages of %dx%d / %d planted lines per repetition through the CPU oracle (oracle/retto_oracle.cpp pre/post + "
                      "oracle/nets_cpu.cpp C++/OpenMP fp32 networks, %s) in a fresh interpreter: %d worker processes x %d OpenMP threads = "
-                     "%d of the host's %d logical CPUs, 1 warm-up page per worker, %d timed repetitions (rates %s images/s, median "
+                     "%d of the %d CPUs this process may use (affinity mask capped by the cgroup CPU quota; the host shows %d logical CPUs), 1 warm-up page per worker, %d timed repetitions (rates %s images/s, median "
                      "reported). Reference ort-CPU itself is not runnable here (no Rust / ONNX Runtime / model files)" % (
-                         n_pages, size, size, lines, _lib_kind or "see oracle/Makefile", P, T, P * T, cpus, reps,
+                         n_pages, size, size, lines, _lib_kind or "see oracle/Makefile", P, T, P * T, cpus, os.cpu_count() or 0, reps,
                          "/".join("%.2f" % r for r in rates)),
            "workers": P, "threads_per_worker": T, "nproc": os.cpu_count(),
            "one_thread_images_per_s": round(one_thread, 5) if one_thread else None,

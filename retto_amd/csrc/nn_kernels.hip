@@ -7,6 +7,9 @@
 // /root/reference/retto-core/src/worker/ort_worker.rs:189-220.
 #include "nn.h"
 
+#include <algorithm>
+#include <cstdlib>
+
 namespace rt {
 namespace nn {
 
