@@ -79,20 +79,26 @@ static Dw16 pack_dw16(WeightStore& ws, const Blob& b, const std::string& name, i
   p.b = ws.upload(bias);
   return p;
 }
-static std::vector<float> transposed(const BlobTensor& t, int rows, int cols) {  // [rows][cols] -> [cols][rows]
-  std::vector<float> o((size_t)rows * cols);
-  for (int r = 0; r < rows; r++)
-    for (int c = 0; c < cols; c++) o[(size_t)c * rows + r] = t.data[(size_t)r * cols + c];
-  return o;
+// fp32 FC for nn::gemm from a conv-style weight [cout][cin] (1x1): packed [K/32][Npad16][32]
+static PackedDense pack_fc32(WeightStore& ws, const BlobTensor& w, int cout, int cin, const float* bias) {
+  if (w.numel() != (size_t)cout * cin) throw RtError(3, "RTWB: unexpected size of a squeeze-excite weight");
+  PackedDense p;
+  p.K = round_up(cin, 4); p.N = cout; p.Npad = round_up(cout, 16);
+  const int nkc = (p.K + nn::KC - 1) / nn::KC;
+  std::vector<float> host((size_t)nkc * p.Npad * nn::KC, 0.f);
+  for (int n = 0; n < cout; n++)
+    for (int k = 0; k < cin; k++) host[((size_t)(k / nn::KC) * p.Npad + n) * nn::KC + (k % nn::KC)] = w.data[(size_t)n * cin + k];
+  p.w = ws.upload(host);
+  std::vector<float> b(p.Npad, 0.f);
+  memcpy(b.data(), bias, (size_t)cout * sizeof(float));
+  p.b = ws.upload(b);
+  return p;
 }
 // squeeze-excite: fc1 [Cr, C, 1, 1], fc2 [C, Cr, 1, 1]
 static Se16 get_se16(WeightStore& ws, const Blob& b, const std::string& name, int C) {
-  Se16 s; s.C = C; s.Cr = C / 4;
-  const BlobTensor& w1 = b.get(name + ".fc1.w"); const BlobTensor& w2 = b.get(name + ".fc2.w");
-  if (w1.numel() != (size_t)s.Cr * C || w2.numel() != (size_t)s.Cr * C) throw RtError(3, "RTWB: unexpected size for " + name);
-  s.w1t = ws.upload(transposed(w1, s.Cr, C));  // [C][Cr]
-  s.w2t = ws.upload(transposed(w2, C, s.Cr));  // [Cr][C]
-  s.b1 = upload_raw(ws, b, name + ".fc1.b", s.Cr); s.b2 = upload_raw(ws, b, name + ".fc2.b", C);
+  Se16 s; s.C = C; s.Cr = C / 4; s.has_fc1 = true;
+  s.fc1 = pack_fc32(ws, b.get(name + ".fc1.w"), s.Cr, C, b.get(name + ".fc1.b").data);
+  s.fc2 = pack_fc32(ws, b.get(name + ".fc2.w"), C, s.Cr, b.get(name + ".fc2.b").data);
   return s;
 }
 // ESEModule: one 1x1 conv C -> C on the channel means, sigmoid gate
@@ -100,8 +106,7 @@ static Se16 get_ese16(WeightStore& ws, const Blob& b, const std::string& name, i
   Se16 s; s.C = C; s.Cr = C;
   const BlobTensor& w = b.get(name + ".w");
   expect_dims16(w, {C, C, 1, 1}, name + ".w");
-  s.w2t = ws.upload(transposed(w, C, C));
-  s.b2 = upload_raw(ws, b, name + ".b", C);
+  s.fc2 = pack_fc32(ws, w, C, C, b.get(name + ".b").data);
   return s;
 }
 static Lab get_lab16(const Blob& b, const std::string& name) {
@@ -147,12 +152,25 @@ static void dw16(RunCtx& c, const Dw16& w, H16 x, const Level& Lin, const Level&
   nh::dwconv16(c.st, w.k, sh, sw, x.p, x.ld, Lin.d, Lout.d, Lout.n(), Lout.maxH, Lout.maxW, w.Cp, w.w, w.b, act, lab.has, lab.a, lab.c,
                y.p, y.ld);
 }
+// gate factors of a squeeze-excite / ESE layer: deterministic spatial mean (fp32), the FCs as fp32 GEMMs over all images of the
+// level at once (rows = images), then the gate
 static float* se16(RunCtx& c, const Se16& s, H16 x, const Level& L, float slope, int residual) {
-  const int Cp = pitch8(s.C);
-  float* partial = c.arena->alloc<float>((size_t)L.n() * nh::pool_chunks16(L.maxPix) * Cp);
-  float* scale = c.arena->alloc<float>((size_t)L.n() * Cp);
+  const int Cp = pitch8(s.C), n = L.n();
+  float* partial = c.arena->alloc<float>((size_t)n * nh::pool_chunks16(L.maxPix) * Cp);
+  float* mean = c.arena->alloc<float>((size_t)n * Cp);
+  float* scale = c.arena->alloc<float>((size_t)n * Cp);
   ProfScope ps(c.prof, c.st, "se_pool_fc16");
-  nh::se_scale16(c.st, x.p, x.ld, L.d, L.n(), L.maxPix, s.C, Cp, s.w1t, s.b1, s.w2t, s.b2, s.Cr, slope, residual, partial, scale);
+  nh::global_mean16(c.st, x.p, x.ld, L.d, n, L.maxPix, Cp, partial, mean);
+  const float* in = mean; int ldin = Cp;
+  if (s.has_fc1) {
+    const int Crp = round_up(s.Cr, 4);
+    float* hid = c.arena->alloc<float>((size_t)n * Crp);
+    nn::gemm(c.st, mean, Cp, n, s.fc1.K, s.fc1.w, s.Cr, s.fc1.Npad, hid, Crp, 0, make_epi(s.fc1, ACT_RELU));
+    in = hid; ldin = Crp;
+  }
+  float* sv = c.arena->alloc<float>((size_t)n * Cp);
+  nn::gemm(c.st, in, ldin, n, s.fc2.K, s.fc2.w, s.C, s.fc2.Npad, sv, Cp, 0, make_epi(s.fc2, ACT_NONE));
+  nh::gate16(c.st, sv, Cp, n, s.C, Cp, slope, residual, scale);
   return scale;
 }
 static void scale16(RunCtx& c, H16 x, const Level& L, const float* scale, const H16* res, H16 y) {

@@ -16,7 +16,7 @@ struct Conv16 {  // conv16 weights on device: [ceil(cin_p/32)][kh][kw][npad][32]
   int cin = 0, cin_p = 0, cout = 0, npad = 0, kh = 1, kw = 1;
 };
 struct Dw16 { nh::half_t* w = nullptr; float* b = nullptr; int k = 3, C = 0, Cp = 0; };
-struct Se16 { float *w1t = nullptr, *b1 = nullptr, *w2t = nullptr, *b2 = nullptr; int C = 0, Cr = 0; };
+struct Se16 { PackedDense fc1, fc2; bool has_fc1 = false; int C = 0, Cr = 0; };  // fp32 FCs on the channel means (nn::gemm)
 struct H16 { nh::half_t* p = nullptr; int C = 0, ld = 0; };  // view of an fp16 NHWC tensor: C channels at pitch ld
 
 struct LcBlock16 {

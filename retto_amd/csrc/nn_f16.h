@@ -74,6 +74,8 @@ int pool_chunks16(long long max_pix);
 void se_scale16(hipStream_t st, const half_t* x, int ldx, const ImgGeom* geom, int n_img, long long max_pix, int C, int Cp, const float* w1t,
                 const float* b1, const float* w2t, const float* b2, int Cr, float slope, int residual, float* partial,
                 float* scale);
+// gate of a squeeze-excite: scale[img][c] = hardsigmoid(slope) or sigmoid (slope < 0) of s[img][c] (pitch lds), + 1 when residual
+void gate16(hipStream_t st, const float* s, int lds, int n_img, int C, int Cp, float slope, int residual, float* scale);
 // y = x * scale[image] (+ res); in place allowed; x / res / y have their own channel pitches (views into concat buffers)
 void scale_channels16(hipStream_t st, const half_t* x, int ldx, const ImgGeom* geom, int n_img, long long max_pix, int Cp, const float* scale,
                       const half_t* res, int ldr, half_t* y, int ldy);

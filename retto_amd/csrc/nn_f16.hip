@@ -100,20 +100,48 @@ __global__ __launch_bounds__(64 * WN * WP, 2) void k_conv16(const ConvArgs a) {
   const int nrows = nslab * a.KH;
   const int cpp = (lp >> 3) - 1;               // 16-byte chunks per staged LDS row (pixel or output channel) that hold data
   const int wchunks = a.KW * BN * cpp;         // chunks of one staged weight row
+  const int hchunks = HH * HW * cpp;           // chunks of one staged halo tile
   const bool prefetch = wchunks <= WPRE * NTHR;
   const size_t row_halves = (size_t)a.KW * a.Npad * KS;
+  // The index arithmetic of the staging loops (run-time divisions by the halo width and the chunks per row) cost as many
+  // issue cycles as the MFMAs of a stage: a thread's chunks are the same in every stage, so their offsets are computed once.
+  //   weights: chunk c = tid + i * NTHR -> LDS offset wdst[i], global offset wsrc[i] inside a kernel row (-1: padding / none)
+  //   halo:    the first HFIX chunks of a thread -> LDS offset hdst[i], global offset hsrc[i] at slab 0 (-1: outside the image)
+  int wdst[WPRE], wsrc[WPRE];
+#pragma unroll
+  for (int i = 0; i < WPRE; i++) {
+    const int c = tid + i * NTHR;
+    wdst[i] = -1; wsrc[i] = -1;
+    if (c < wchunks) {
+      const int row = c / cpp, qd = c - row * cpp;
+      const int dx = row / BN, n = row - dx * BN;
+      wdst[i] = row * lp + qd * 8;
+      if (nb0 + n < a.Npad) wsrc[i] = (dx * a.Npad + nb0 + n) * KS + qd * 8;
+    }
+  }
+  constexpr int HFIX = 6;
+  int hdst[HFIX], hsrc[HFIX];
+#pragma unroll
+  for (int i = 0; i < HFIX; i++) {
+    const int c = tid + i * NTHR;
+    hdst[i] = -1; hsrc[i] = -1;
+    if (c < hchunks) {
+      const int p = c / cpp, qd = c - p * cpp;
+      const int hy = p / HW, hx = p - hy * HW;
+      const int iy = iy0 + hy, ix = ix0 + hx;
+      hdst[i] = (p * lp + qd * 8) | (qd << 24);   // (chunk index kept in the top bits: the slab's valid channels are tested per stage)
+      if (iy >= 0 && iy < gi.H && ix >= 0 && ix < gi.W) hsrc[i] = (hy * gi.W + hx) * a.ldx + qd * 8;  // relative to the tile's halo origin
+    }
+  }
+  const half_t* ximg = a.x + gi.off * a.ldx;
+  const half_t* xtile = ximg + ((long long)iy0 * gi.W + ix0) * a.ldx;   // (only dereferenced at offsets of pixels inside the image)
   h8 pre[WPRE];
   auto load_row = [&](int rr) {
     const half_t* wg = a.w + (size_t)rr * row_halves;
 #pragma unroll
     for (int i = 0; i < WPRE; i++) {
-      int c = tid + i * NTHR;
       h8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-      if (c < wchunks) {
-        int row = c / cpp, qd = c - row * cpp;
-        int dx = row / BN, n = row - dx * BN;
-        if (nb0 + n < a.Npad) v = *reinterpret_cast<const h8*>(wg + ((size_t)dx * a.Npad + nb0 + n) * KS + qd * 8);
-      }
+      if (wsrc[i] >= 0) v = *reinterpret_cast<const h8*>(wg + wsrc[i]);
       pre[i] = v;
     }
   };
@@ -125,22 +153,33 @@ __global__ __launch_bounds__(64 * WN * WP, 2) void k_conv16(const ConvArgs a) {
     const int ksteps = (cvalid + 15) >> 4;
     __syncthreads();  // every wave is done reading the previous weight row (and, at dy == 0, the previous halo)
     if (dy == 0) {
-      for (int c = tid; c < HH * HW * cpp; c += NTHR) {
+      // all of a thread's halo loads are issued before the first LDS write (branch-free: chunks outside the image read the
+      // tensor's first bytes and are zeroed by a select), so their latencies overlap instead of adding up
+      h8 hv[HFIX];
+#pragma unroll
+      for (int i = 0; i < HFIX; i++) {
+        const bool ok = hsrc[i] >= 0 && (hdst[i] >> 24) * 8 < cvalid;
+        const half_t* src = ok ? xtile + hsrc[i] + s * KS : a.x;
+        hv[i] = *reinterpret_cast<const h8*>(src);
+        if (!ok) hv[i] = h8{0, 0, 0, 0, 0, 0, 0, 0};
+      }
+#pragma unroll
+      for (int i = 0; i < HFIX; i++)
+        if (hdst[i] >= 0) *reinterpret_cast<h8*>(halo + (hdst[i] & 0xffffff)) = hv[i];
+      for (int c = tid + HFIX * NTHR; c < hchunks; c += NTHR) {  // larger halos (9x9 kernels, strided tiles): the remaining chunks
         int p = c / cpp, qd = c - p * cpp;
         int hy = p / HW, hx = p - hy * HW;
         int iy = iy0 + hy, ix = ix0 + hx;
         h8 v = {0, 0, 0, 0, 0, 0, 0, 0};
         if (iy >= 0 && iy < gi.H && ix >= 0 && ix < gi.W && qd * 8 < cvalid)
-          v = *reinterpret_cast<const h8*>(a.x + (gi.off + (long long)iy * gi.W + ix) * a.ldx + s * KS + qd * 8);
+          v = *reinterpret_cast<const h8*>(ximg + ((long long)iy * gi.W + ix) * a.ldx + s * KS + qd * 8);
         *reinterpret_cast<h8*>(halo + (size_t)p * lp + qd * 8) = v;
       }
     }
     if (prefetch) {
 #pragma unroll
-      for (int i = 0; i < WPRE; i++) {
-        int c = tid + i * NTHR;
-        if (c < wchunks) { int row = c / cpp; *reinterpret_cast<h8*>(wl + (size_t)row * lp + (c - row * cpp) * 8) = pre[i]; }
-      }
+      for (int i = 0; i < WPRE; i++)
+        if (wdst[i] >= 0) *reinterpret_cast<h8*>(wl + wdst[i]) = pre[i];
       if (rr + 1 < nrows) load_row(rr + 1);
     } else {
       const half_t* wg = a.w + (size_t)rr * row_halves;
@@ -475,47 +514,72 @@ __global__ __launch_bounds__(256) void k_pool_partial16(const half_t* __restrict
   }
 }
 
-// block per image: mean -> [fc1 -> relu] -> fc2 -> gate
-__global__ __launch_bounds__(256) void k_se_fc16(const float* __restrict__ partial, const ImgGeom* __restrict__ geom, int chunks_alloc,
-                                                 int C, int Cp, const float* __restrict__ w1t, const float* __restrict__ b1,
-                                                 const float* __restrict__ w2t, const float* __restrict__ b2, int Cr, float slope,
-                                                 int residual, float* __restrict__ scale) {
-  extern __shared__ float sm16[];  // mean[Cp] + hid[Cr]
+// block per group of IPB images: mean -> [fc1 -> relu] -> fc2 -> gate.  The FC weights are read once per block and applied to
+// all of its images (the recognition net's ESE layers have C x C weights of up to 4 MB and ~1000 images per launch: one
+// block per image re-read them from L2 a thousand times).
+constexpr int SE_IPB = 8;
+__global__ __launch_bounds__(256) void k_se_fc16(const float* __restrict__ partial, const ImgGeom* __restrict__ geom, int n_img,
+                                                 int chunks_alloc, int C, int Cp, const float* __restrict__ w1t,
+                                                 const float* __restrict__ b1, const float* __restrict__ w2t,
+                                                 const float* __restrict__ b2, int Cr, float slope, int residual,
+                                                 float* __restrict__ scale) {
+  extern __shared__ float sm16[];  // mean[IPB][Cp] + hid[IPB][Cr]
   float* mean = sm16;
-  float* hid = sm16 + Cp;
-  const ImgGeom g = geom[blockIdx.x];
-  const long long npix = (long long)g.H * g.W;
-  const int chunks = (int)((npix + POOL_PIX16 - 1) / POOL_PIX16);
-  const float inv = 1.0f / (float)npix;
-  for (int c = threadIdx.x; c < Cp; c += 256) {
-    float s = 0.f;
-    for (int k = 0; k < chunks; k++) s += partial[((long long)blockIdx.x * chunks_alloc + k) * Cp + c];
-    mean[c] = s * inv;
+  float* hid = sm16 + SE_IPB * Cp;
+  const int img0 = blockIdx.x * SE_IPB, ni = min(SE_IPB, n_img - img0);
+  for (int i = 0; i < ni; i++) {
+    const ImgGeom g = geom[img0 + i];
+    const long long npix = (long long)g.H * g.W;
+    const int chunks = (int)((npix + POOL_PIX16 - 1) / POOL_PIX16);
+    const float inv = 1.0f / (float)npix;
+    for (int c = threadIdx.x; c < Cp; c += 256) {
+      float s = 0.f;
+      for (int k = 0; k < chunks; k++) s += partial[((long long)(img0 + i) * chunks_alloc + k) * Cp + c];
+      mean[i * Cp + c] = s * inv;
+    }
   }
   __syncthreads();
   if (w2t == nullptr) {  // plain global mean
-    for (int c = threadIdx.x; c < Cp; c += 256) scale[(long long)blockIdx.x * Cp + c] = mean[c];
+    for (int i = 0; i < ni; i++)
+      for (int c = threadIdx.x; c < Cp; c += 256) scale[(long long)(img0 + i) * Cp + c] = mean[i * Cp + c];
     return;
   }
   const float* hin = mean;
+  int hpitch = Cp;
   if (w1t) {
     for (int j = threadIdx.x; j < Cr; j += 256) {  // w1t [C][Cr]
-      float s = b1[j];
-      for (int c = 0; c < C; c++) s = fmaf(mean[c], w1t[(size_t)c * Cr + j], s);
-      hid[j] = fmaxf(s, 0.f);
+      float s[SE_IPB];
+#pragma unroll
+      for (int i = 0; i < SE_IPB; i++) s[i] = b1[j];
+      for (int c = 0; c < C; c++) {
+        const float w = w1t[(size_t)c * Cr + j];
+#pragma unroll
+        for (int i = 0; i < SE_IPB; i++) s[i] = fmaf(mean[i * Cp + c], w, s[i]);
+      }
+#pragma unroll
+      for (int i = 0; i < SE_IPB; i++) hid[i * Cr + j] = fmaxf(s[i], 0.f);
     }
     __syncthreads();
-    hin = hid;
+    hin = hid; hpitch = Cr;
   }
   for (int c = threadIdx.x; c < Cp; c += 256) {  // w2t [Cr][C]
-    float o = 0.f;
-    if (c < C) {
-      float s = b2[c];
-      for (int j = 0; j < Cr; j++) s = fmaf(hin[j], w2t[(size_t)j * C + c], s);
-      o = slope < 0.f ? 1.f / (1.f + __expf(-s)) : fminf(fmaxf(fmaf(s, slope, 0.5f), 0.f), 1.f);
-      if (residual) o += 1.0f;
+    float s[SE_IPB];
+#pragma unroll
+    for (int i = 0; i < SE_IPB; i++) s[i] = c < C ? b2[c] : 0.f;
+    if (c < C)
+      for (int j = 0; j < Cr; j++) {
+        const float w = w2t[(size_t)j * C + c];
+#pragma unroll
+        for (int i = 0; i < SE_IPB; i++) s[i] = fmaf(hin[i * hpitch + j], w, s[i]);
+      }
+    for (int i = 0; i < ni; i++) {
+      float o = 0.f;
+      if (c < C) {
+        o = slope < 0.f ? 1.f / (1.f + __expf(-s[i])) : fminf(fmaxf(fmaf(s[i], slope, 0.5f), 0.f), 1.f);
+        if (residual) o += 1.0f;
+      }
+      scale[(long long)(img0 + i) * Cp + c] = o;
     }
-    scale[(long long)blockIdx.x * Cp + c] = o;
   }
 }
 
@@ -528,8 +592,29 @@ void se_scale16(hipStream_t st, const half_t* x, int ldx, const ImgGeom* geom, i
     const int ny = std::min(n_img - y0, RT_MAX_GRID_Y);
     RT_LAUNCH(k_pool_partial16, dim3(chunks, ny), dim3(256), 0, st, x, ldx, geom + y0, Cp, chunks, partial + (size_t)y0 * chunks * Cp);
   }
-  RT_LAUNCH(k_se_fc16, dim3(n_img), dim3(256), (size_t)(Cp + Cr + 4) * sizeof(float), st, partial, geom, chunks, C, Cp, w1t, b1, w2t,
+  const size_t lds = (size_t)SE_IPB * (Cp + Cr + 4) * sizeof(float);
+  static bool attr = false;
+  if (!attr) { RT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_se_fc16), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)); attr = true; }
+  RT_LAUNCH(k_se_fc16, dim3((n_img + SE_IPB - 1) / SE_IPB), dim3(256), lds, st, partial, geom, n_img, chunks, C, Cp, w1t, b1, w2t,
             b2, Cr, slope, residual, scale);
+}
+// scale[img][c] = gate(s[img][c]) (+1 when residual), 0 on the pad channels
+__global__ __launch_bounds__(256) void k_gate16(const float* __restrict__ sv, int lds_, int n_img, int C, int Cp, float slope, int residual,
+                                                float* __restrict__ scale) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n_img * Cp) return;
+  const int img = i / Cp, c = i - img * Cp;
+  float o = 0.f;
+  if (c < C) {
+    const float v = sv[(size_t)img * lds_ + c];
+    o = slope < 0.f ? 1.f / (1.f + __expf(-v)) : fminf(fmaxf(fmaf(v, slope, 0.5f), 0.f), 1.f);
+    if (residual) o += 1.0f;
+  }
+  scale[i] = o;
+}
+void gate16(hipStream_t st, const float* s, int lds_, int n_img, int C, int Cp, float slope, int residual, float* scale) {
+  if (n_img <= 0) return;
+  RT_LAUNCH(k_gate16, dim3((unsigned)((n_img * Cp + 255) / 256)), dim3(256), 0, st, s, lds_, n_img, C, Cp, slope, residual, scale);
 }
 void global_mean16(hipStream_t st, const half_t* x, int ldx, const ImgGeom* geom, int n_img, long long max_pix, int Cp, float* partial,
                    float* out) {
