@@ -69,6 +69,8 @@ def parse():
     ap.add_argument("--lanes", type=int, default=0, help="concurrent page streams inside rt_run_batch (0 = library default)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for CPU-side tests)")
     ap.add_argument("--share-gpu", action="store_true", help="test only: every rank uses device 0")
+    ap.add_argument("--bcast", default="torch", choices=["torch", "cabi"],
+                    help="weight broadcast: torch.distributed (default) or libretto_hip's own RCCL entry point rt_broadcast_blobs")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the CPU baseline leg")
     ap.add_argument("--profile-all", action="store_true", help="print the per-family table to stderr")
     a = ap.parse_args()
@@ -135,7 +137,12 @@ def main():
         blobs = list(synth.synth_server_models(0) if a.models == "server" else synth.synth_models(0))
     else:
         blobs = [None] * 4
-    if dist_on:
+    if dist_on and a.bcast == "cabi":   # the C-ABI hook a Rust / C++ host would use: RCCL id from rank 0, shared out of band
+        from retto_amd.dist import broadcast_blobs_cabi, rccl_unique_id
+        box = [rccl_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        blobs = broadcast_blobs_cabi(blobs, 4, rank, world, device, box[0])
+    elif dist_on:
         blobs = broadcast_blobs(blobs, 4, rank, device=tdev)  # RCCL over xGMI, once
     det_b, cls_b, rec_b, dict_b = blobs
     cfg = retto_amd.RettoSessionConfig()

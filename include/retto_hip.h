@@ -237,6 +237,18 @@ RT_API int rt_format_f32(float v, char* buf, size_t cap);
  * fills for model `which`, one "name d0 d1 ..." line per tensor; returns the length needed. */
 RT_API size_t rt_model_manifest(int which, char* buf, size_t cap);
 
+/* ---- multi-GPU: the one collective of the design ------------------------------------------------------------
+ * Pages shard over the GPUs of a node, one process (one rt_session) per GPU, with no data-path collective; the model blobs are
+ * broadcast ONCE from `root` over RCCL (xGMI).  The reference has no counterpart (retto-cli/src/main.rs:80-86 is a serial loop
+ * in one process).  rt_rccl_unique_id: rank `root` creates the 128-byte RCCL id and hands it to the other ranks out of band
+ * (file / pipe / environment / MPI).  rt_broadcast_blobs: every rank calls it with the same id, world and root; on `root`
+ * data[i] / lens[i] are the blobs to send (caller-owned), on the other ranks they are OUTPUTS: data[i] is library-allocated
+ * (release with rt_buffer_free) and lens[i] its size.  The blobs then go into rt_config.{det,cls,rec,dict}.  librccl.so is
+ * loaded on first use only.  err (optional) receives the failure message. */
+RT_API int rt_rccl_unique_id(void* id, size_t cap, char* err, size_t err_cap);
+RT_API int rt_broadcast_blobs(const void* id, int rank, int world, int device_id, int root, int n_blobs, void** data, size_t* lens,
+                              char* err, size_t err_cap);
+
 /* ---- diagnostics for tools/ (kernel A/B switches and the GEMM micro-benchmark; no reference
  * counterpart, not needed by a drop-in host) ------------------------------------------------
  * rt_debug_set_variants: gemm_variant 0 = production dispatch, 8 / 10 / 15 / 20 force the

@@ -54,3 +54,71 @@ def digest(blobs: Sequence[bytes]) -> str:
     for b in blobs:
         h.update(b)
     return h.hexdigest()
+
+
+def run_global_batch(sizes: Sequence[Tuple[int, int]], rank: int, world: int, process, est_lines: Optional[Sequence[int]] = None,
+                     chunk: int = 32) -> list:
+    """The sharded form of retto-cli's loop over files (/root/reference/retto-cli/src/main.rs:80-86) for ONE list of pages:
+    every rank takes its LPT shard (``shard_pages``), runs ``process(page_ids) -> list of per-page results`` over it in calls
+    of at most ``chunk`` pages (input order inside the shard), and the per-page results of all ranks are gathered and returned
+    in INPUT order on every rank (``torch.distributed.all_gather_object`` of small result records; no tensor collective)."""
+    import torch.distributed as dist
+    mine = sorted(shard_pages(sizes, world, rank, est_lines))
+    out = []
+    for c0 in range(0, len(mine), chunk):
+        ids = mine[c0:c0 + chunk]
+        res = process(ids)
+        if len(res) != len(ids):
+            raise RuntimeError("process() must return one result per page")
+        out += list(zip(ids, res))
+    if world > 1:
+        parts = [None] * world
+        dist.all_gather_object(parts, out)
+        out = [x for part in parts for x in part]
+    out.sort(key=lambda t: t[0])
+    if [i for i, _ in out] != list(range(len(sizes))):
+        raise RuntimeError("gather lost or duplicated pages")
+    return [r for _, r in out]
+
+
+def broadcast_blobs_cabi(blobs: Optional[Sequence[bytes]], n_blobs: int, rank: int, world: int, device_id: int, uid: bytes,
+                         root: int = 0) -> List[bytes]:
+    """The same one-time broadcast through libretto_hip's C ABI (rt_broadcast_blobs: RCCL, no torch involved) -- what a
+    Rust / C++ host would call.  ``uid``: the 128 bytes of ``rccl_unique_id()`` made on ``root`` and shared out of band."""
+    import ctypes as C
+    from . import _lib
+    lib = _lib.load()
+    data = (C.c_void_p * max(n_blobs, 1))()
+    lens = (C.c_size_t * max(n_blobs, 1))()
+    keep = []
+    if rank == root:
+        for i, b in enumerate(blobs):
+            buf = C.create_string_buffer(bytes(b), len(b)); keep.append(buf)
+            data[i] = C.addressof(buf); lens[i] = len(b)
+    err = C.create_string_buffer(512)
+    lib.rt_broadcast_blobs.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p),
+                                       C.POINTER(C.c_size_t), C.c_char_p, C.c_size_t]
+    rc = lib.rt_broadcast_blobs(uid, rank, world, device_id, root, n_blobs, data, lens, err, 512)
+    if rc != 0:
+        raise RuntimeError("rt_broadcast_blobs failed (%d): %s" % (rc, err.value.decode("utf-8", "replace")))
+    if rank == root:
+        return [bytes(b) for b in blobs]
+    out = []
+    lib.rt_buffer_free.argtypes = [C.c_void_p]
+    for i in range(n_blobs):
+        out.append(C.string_at(data[i], lens[i]))
+        lib.rt_buffer_free(data[i])
+    return out
+
+
+def rccl_unique_id() -> bytes:
+    import ctypes as C
+    from . import _lib
+    lib = _lib.load()
+    uid = C.create_string_buffer(128)
+    err = C.create_string_buffer(256)
+    lib.rt_rccl_unique_id.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t]
+    rc = lib.rt_rccl_unique_id(uid, 128, err, 256)
+    if rc != 0:
+        raise RuntimeError("rt_rccl_unique_id failed: " + err.value.decode("utf-8", "replace"))
+    return uid.raw

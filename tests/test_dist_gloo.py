@@ -51,3 +51,49 @@ def test_sharding_uniform_is_even():
         shards = [rdist.shard_pages([(960, 960)] * 32, world, r) for r in range(world)]
         assert sorted(sum(shards, [])) == list(range(32))
         assert all(len(s) == 32 // world for s in shards)
+
+
+# ---- one global batch over the ranks: order-preserving gather, results independent of the world size ------------------
+def _fake_process(sizes):
+    """Stand-in for rt_run_batch on the CPU: a page's 'result' is a pure function of the page (its id and size), like the
+    real pipeline's (a page's boxes / tokens do not depend on what else is in the batch -- checked on the GPU by bench.py)."""
+    import hashlib
+
+    def process(ids):
+        return [hashlib.sha256(("%d:%dx%d" % (i, sizes[i][0], sizes[i][1])).encode()).hexdigest()[:12] for i in ids]
+    return process
+
+
+def _gb_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sizes = [[(640, 640), (960, 960), (720, 1280), (1080, 1920), (1754, 1240), (3508, 2480)][(7 * i) % 6] for i in range(37)]
+    calls = []
+    proc = _fake_process(sizes)
+
+    def process(ids):
+        calls.append(list(ids))
+        return proc(ids)
+    res = rdist.run_global_batch(sizes, rank, world, process, est_lines=[32] * len(sizes), chunk=8)
+    q.put((rank, res, calls))
+    dist.destroy_process_group()
+
+
+def test_global_batch_gather_is_in_input_order_and_world_invariant():
+    sizes = [[(640, 640), (960, 960), (720, 1280), (1080, 1920), (1754, 1240), (3508, 2480)][(7 * i) % 6] for i in range(37)]
+    # world 1 (no process group needed: the gather is skipped)
+    ref = rdist.run_global_batch(sizes, 0, 1, _fake_process(sizes), est_lines=[32] * len(sizes), chunk=8)
+    assert ref == _fake_process(sizes)(list(range(37)))
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_gb_worker, args=(r, 2, port, q)) for r in range(2)]
+    [p.start() for p in ps]
+    res = sorted(q.get(timeout=120) for _ in range(2))
+    [p.join(30) for p in ps]
+    assert all(p.exitcode == 0 for p in ps)
+    for rank, got, calls in res:
+        assert got == ref                                   # every rank holds all results, in input order, equal to world 1
+        assert all(len(c) <= 8 for c in calls) and all(c == sorted(c) for c in calls)
+    ids0 = [i for c in res[0][2] for i in c]; ids1 = [i for c in res[1][2] for i in c]
+    assert sorted(ids0 + ids1) == list(range(37)) and not set(ids0) & set(ids1)

@@ -308,3 +308,26 @@ print("rccl ok")
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", HSA_ENABLE_IPC_MODE_LEGACY="0")
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
     assert out.returncode == 0 and "rccl ok" in out.stdout, out.stderr[-2000:]
+
+
+def test_cabi_rccl_broadcast_single_rank():
+    """rt_rccl_unique_id + rt_broadcast_blobs (the C-ABI form of the one collective: what a Rust / C++ host calls) with the
+    one GPU of this box: communicator of world 1, sizes + blobs through the device staging buffer, bytes unchanged."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r'''
+import sys
+sys.path.insert(0, %r)
+from retto_amd import synth
+from retto_amd.dist import broadcast_blobs_cabi, rccl_unique_id, digest
+blobs = list(synth.synth_models(0))
+uid = rccl_unique_id()
+assert len(uid) == 128 and any(uid)
+got = broadcast_blobs_cabi(blobs, 4, 0, 1, 0, uid)
+assert digest(got) == digest(blobs)
+print("cabi rccl ok")
+''' % root
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0 and "cabi rccl ok" in out.stdout, (out.stdout[-500:], out.stderr[-2000:])
