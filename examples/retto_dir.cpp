@@ -7,6 +7,11 @@
 //
 //   g++ -std=c++17 -Iinclude examples/retto_dir.cpp -Lretto_amd -lretto_hip -Wl,-rpath,$PWD/retto_amd -o examples/retto_dir
 //   examples/retto_dir --det det.onnx --cls cls.onnx --rec rec.onnx --keys ppocr_keys_v1.txt --images DIR
+//
+// --ranks N: the same loop sharded over N GPUs of one node -- N processes (fork, one per GPU, device id = rank),
+// rank 0 reads the model files and broadcasts them ONCE over RCCL through rt_rccl_unique_id / rt_broadcast_blobs (the id
+// travels through a pipe), files are dealt to the ranks by size (greedy longest-processing-time), every output line carries
+// the file's index in the sorted list so that `sort -n` restores the input order.  No per-batch communication.
 #include <algorithm>
 #include <chrono>
 #include <cstdio>
@@ -21,6 +26,9 @@
 #include <thread>
 #include <string>
 #include <vector>
+
+#include <sys/wait.h>
+#include <unistd.h>
 
 #include "retto_hip.h"
 
@@ -68,7 +76,7 @@ static std::unique_ptr<Batch> load_batch(const std::vector<std::string>& files, 
 
 int main(int argc, char** argv) {
   std::string det, cls, rec, keys, images;
-  int batch = 32, device = 0;
+  int batch = 32, device = 0, ranks = 0;
   bool quiet = false;
   for (int i = 1; i + 1 < argc; i += 2) {
     std::string k = argv[i], v = argv[i + 1];
@@ -76,25 +84,82 @@ int main(int argc, char** argv) {
     else if (k == "--keys") keys = v; else if (k == "--images") images = v;
     else if (k == "--quiet") quiet = atoi(v.c_str()) != 0;
     else if (k == "--batch") batch = atoi(v.c_str()); else if (k == "--device-id") device = atoi(v.c_str());
+    else if (k == "--ranks") ranks = atoi(v.c_str());
     else { fprintf(stderr, "unknown option %s\n", k.c_str()); return 2; }
   }
   if (det.empty() || cls.empty() || rec.empty() || keys.empty() || images.empty() || batch <= 0) {
-    fprintf(stderr, "usage: retto_dir --det M --cls M --rec M --keys K --images DIR [--batch N] [--device-id D] [--quiet 1]\n");
+    fprintf(stderr, "usage: retto_dir --det M --cls M --rec M --keys K --images DIR [--batch N] [--device-id D] [--ranks N] [--quiet 1]\n");
     return 2;
   }
-  rt_config cfg;
-  rt_config_default(&cfg);
-  cfg.device_id = device;
-  cfg.det.path = det.c_str(); cfg.cls.path = cls.c_str(); cfg.rec.path = rec.c_str(); cfg.dict.path = keys.c_str();
-  rt_session* s = nullptr;
-  int rc = rt_create(&cfg, &s);
-  if (rc != RT_OK) { fprintf(stderr, "rt_create failed (%d): %s\n", rc, rt_last_error(nullptr)); return 1; }
-
+  // the file list is the same on every rank (sorted walk), so is its split
   std::vector<std::string> files;
   for (auto& e : std::filesystem::recursive_directory_iterator(images))
     if (e.is_regular_file()) files.push_back(e.path().string());
   std::sort(files.begin(), files.end());
-  fprintf(stderr, "Found %zu files, processing...\n", files.size());
+  std::vector<size_t> index(files.size());
+  for (size_t i = 0; i < files.size(); i++) index[i] = i;
+
+  int rank = 0, world = 1;
+  std::vector<std::vector<uint8_t>> blobs(4);   // det, cls, rec, dict after the broadcast
+  std::vector<void*> recv(4, nullptr);
+  rt_config cfg;
+  rt_config_default(&cfg);
+  if (ranks > 0) {
+    world = ranks;
+    char uid[128];
+    int fds[2];
+    if (pipe(fds) != 0) { perror("pipe"); return 1; }
+    std::vector<pid_t> kids;
+    for (int r = 1; r < world; r++) {   // fork BEFORE anything touches the GPU
+      pid_t p = fork();
+      if (p < 0) { perror("fork"); return 1; }
+      if (p == 0) { rank = r; break; }
+      kids.push_back(p);
+    }
+    char err[256] = {0};
+    if (rank == 0) {
+      if (rt_rccl_unique_id(uid, sizeof(uid), err, sizeof(err)) != RT_OK) { fprintf(stderr, "rt_rccl_unique_id: %s\n", err); return 1; }
+      for (int r = 1; r < world; r++) if (write(fds[1], uid, sizeof(uid)) != (ssize_t)sizeof(uid)) { perror("write"); return 1; }
+      const std::string* src[4] = {&det, &cls, &rec, &keys};
+      for (int i = 0; i < 4; i++) if (!read_file(*src[i], &blobs[(size_t)i])) { fprintf(stderr, "cannot read %s\n", src[i]->c_str()); return 1; }
+    } else if (read(fds[0], uid, sizeof(uid)) != (ssize_t)sizeof(uid)) { perror("read"); return 1; }
+    void* data[4]; size_t lens[4];
+    for (int i = 0; i < 4; i++) { data[i] = blobs[(size_t)i].data(); lens[i] = blobs[(size_t)i].size(); }
+    if (rt_broadcast_blobs(uid, rank, world, /*device*/ rank, /*root*/ 0, 4, data, lens, err, sizeof(err)) != RT_OK) {
+      fprintf(stderr, "rank %d: rt_broadcast_blobs: %s\n", rank, err); return 1;
+    }
+    if (rank != 0) for (int i = 0; i < 4; i++) recv[(size_t)i] = data[i];
+    device = rank;
+    rt_model_source* ms[4] = {&cfg.det, &cfg.cls, &cfg.rec, &cfg.dict};
+    for (int i = 0; i < 4; i++) { ms[i]->path = nullptr; ms[i]->data = data[i]; ms[i]->len = lens[i]; }
+    // greedy longest-processing-time split by file size (a stand-in for the page's pixel count)
+    std::vector<std::pair<uintmax_t, size_t>> by_size;
+    for (size_t i = 0; i < files.size(); i++) by_size.push_back({std::filesystem::file_size(files[i]), i});
+    std::sort(by_size.begin(), by_size.end(), [](auto& a, auto& b) { return a.first != b.first ? a.first > b.first : a.second < b.second; });
+    std::vector<uintmax_t> load((size_t)world, 0);
+    std::vector<size_t> mine;
+    for (auto& f : by_size) {
+      size_t o = (size_t)(std::min_element(load.begin(), load.end()) - load.begin());
+      load[o] += f.first + 1;
+      if ((int)o == rank) mine.push_back(f.second);
+    }
+    std::sort(mine.begin(), mine.end());
+    std::vector<std::string> my_files;
+    for (size_t i : mine) my_files.push_back(files[i]);
+    files.swap(my_files); index.swap(mine);
+    if (rank == 0) {   // the parent also waits for its children at exit
+      struct Reaper { std::vector<pid_t> k; ~Reaper() { for (pid_t p : k) { int st; waitpid(p, &st, 0); } } };
+      static Reaper reaper; reaper.k = kids;
+    }
+  } else {
+    cfg.det.path = det.c_str(); cfg.cls.path = cls.c_str(); cfg.rec.path = rec.c_str(); cfg.dict.path = keys.c_str();
+  }
+  cfg.device_id = device;
+  rt_session* s = nullptr;
+  int rc = rt_create(&cfg, &s);
+  for (void* p : recv) rt_buffer_free(p);
+  if (rc != RT_OK) { fprintf(stderr, "rt_create failed (%d): %s\n", rc, rt_last_error(nullptr)); return 1; }
+  fprintf(stderr, "[rank %d/%d] %zu files, processing...\n", rank, world, files.size());
   size_t done = 0;
   const int threads = std::max(1, std::min(16, (int)std::thread::hardware_concurrency()));
   const auto t0 = std::chrono::steady_clock::now();
@@ -113,8 +178,8 @@ int main(int argc, char** argv) {
     if (rc != RT_OK) { fprintf(stderr, "rt_run_batch failed (%d): %s\n", rc, rt_last_error(s)); if (next.valid()) next.wait(); rt_destroy(s); return 1; }
     if (!quiet)
       for (int i = 0; i < rt_results_pages(r); i++)
-        printf("{\"file\":\"%s\",\"det\":%s,\"cls\":%s,\"rec\":%s}\n", cur->pages[(size_t)i].path.c_str(), rt_results_json(r, i, 0),
-               rt_results_json(r, i, 1), rt_results_json(r, i, 2));
+        printf("%zu {\"file\":\"%s\",\"det\":%s,\"cls\":%s,\"rec\":%s}\n", index[b0 + (size_t)i], cur->pages[(size_t)i].path.c_str(),
+               rt_results_json(r, i, 0), rt_results_json(r, i, 1), rt_results_json(r, i, 2));
     done += cur->pages.size();
     rt_results_free(r);
   }

@@ -189,9 +189,19 @@ def test_native_directory_driver(tmp_path):
                           "--keys", str(tmp_path / "keys.txt"), "--images", str(pages_dir), "--batch", "2"],
                          capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr
-    lines = [json.loads(l) for l in out.stdout.strip().split("\n")]
+    assert [int(l.split(" ", 1)[0]) for l in out.stdout.strip().split("\n")] == [0, 1, 2]   # index in the sorted file list
+    lines = [json.loads(l.split(" ", 1)[1]) for l in out.stdout.strip().split("\n")]
     assert [os.path.basename(l["file"]) for l in lines] == ["p0.ppm", "p1.png", "p2.jpg"]
     assert "Successfully processed 3 images" in out.stderr
+    # --ranks 1: the sharded form (model blobs broadcast over RCCL through rt_broadcast_blobs, files dealt by size) with the one
+    # GPU of this box -- same lines
+    out1 = subprocess.run([exe, "--det", str(tmp_path / "det.rtwb"), "--cls", str(tmp_path / "cls.onnx"), "--rec", str(tmp_path / "rec.rtwb"),
+                           "--keys", str(tmp_path / "keys.txt"), "--images", str(pages_dir), "--batch", "2", "--ranks", "1"],
+                          capture_output=True, text=True, timeout=300, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert out1.returncode == 0, out1.stderr
+    import re   # (librccl prints a version banner on stdout at communicator creation: result lines are "<index> {json}")
+    res1 = [l for l in out1.stdout.strip().split("\n") if re.match(r"^\d+ \{", l)]
+    assert sorted(res1) == sorted(out.stdout.strip().split("\n"))
     S = retto_amd.RettoWorkerModelSource
     cfg = retto_amd.RettoSessionConfig()
     cfg.worker_config = retto_amd.RettoHipWorkerConfig(device=0, models=retto_amd.RettoWorkerModelProvider(
