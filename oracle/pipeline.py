@@ -37,6 +37,9 @@ class OracleResult:
     crops: List[np.ndarray] = field(default_factory=list)  # after cls rotation
     rec_widths: List[int] = field(default_factory=list)    # per line: W of its batch tensor
     det_map: np.ndarray = None
+    # decision margins of the fp32 networks (for tests that compare against an INDEPENDENT implementation of the networks):
+    cls_margins: np.ndarray = None                              # |p(0) - p(180)| per crop
+    rec_margins: List[float] = field(default_factory=list)      # per line: min over time steps of (top-1 - top-2) probability
 
 
 # char::is_whitespace (Unicode White_Space), the set str::trim strips
@@ -81,6 +84,7 @@ class OracleSession:
     def cls_process(self, crops: List[np.ndarray], dims):
         n = len(crops)
         labels = np.zeros(n, np.uint16); scores = np.zeros(n, np.float32)
+        self._cls_margins = np.zeros(n, np.float32)
         # sort_by_key(Reverse(ori_ratio)): stable, descending h/w (f64)
         order = sorted(range(n), key=lambda i: -(float(dims[i][0]) / float(dims[i][1])))
         batches = []
@@ -92,6 +96,7 @@ class OracleSession:
             out = self.cls_worker(t)
             idx, sc = R.cls_postprocess(out)
             for j, i in enumerate(idxs):
+                self._cls_margins[i] = abs(float(out[j, 0]) - float(out[j, 1]))
                 label = [0, 180][int(idx[j])]
                 if label == 180 and sc[j] >= np.float32(0.9):
                     crops[i] = R.rotate180(crops[i])
@@ -103,6 +108,7 @@ class OracleSession:
         n = len(crops)
         toks: List[Optional[np.ndarray]] = [None] * n
         scores = np.zeros(n, np.float32); widths = [0] * n
+        self._rec_margins = [0.0] * n
         order = sorted(range(n), key=lambda i: -(float(dims[i][0]) / float(dims[i][1])))
         max_wh_ratio = np.float32(320) / np.float32(48)
         for s in range(0, n, 6):
@@ -114,8 +120,10 @@ class OracleSession:
                           for i in idxs])
             probs = self.rec_worker(t)
             _, _, tk, sc = R.ctc_decode(probs)
+            top2 = np.sort(probs, axis=-1)[..., -2:]
             for j, i in enumerate(idxs):
                 toks[i] = tk[j]; scores[i] = sc[j]; widths[i] = t.shape[3]
+                self._rec_margins[i] = float((top2[j, :, 1] - top2[j, :, 0]).min())
         return toks, scores, widths
 
     # session.rs:75-106
@@ -138,4 +146,4 @@ class OracleSession:
         toks, rscores, widths = self.rec_process(crops, dims)
         text = ["".join(self.dict[t] for t in tk) for tk in toks]
         return OracleResult(boxes_ori, scores, labels, cscores, toks, rscores, text, boxes_after, crops, widths,
-                            det_map)
+                            det_map, self._cls_margins.copy() if len(crops) else np.zeros(0, np.float32), list(self._rec_margins))

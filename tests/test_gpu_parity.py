@@ -526,3 +526,114 @@ def test_extreme_line_shapes(hip_session, oracle_session):
     assert len(o.det_boxes) >= 3
     _assert_page_equal(res, o)
     np.testing.assert_allclose([g.score for g in res.rec_result], o.rec_scores, rtol=1e-4, equal_nan=True)
+
+
+# ---------------------------------------------------------------- independent end-to-end comparison (no teacher forcing)
+def test_pipeline_against_independent_oracle(hip_session, oracle_session):
+    """The HIP pipeline against the oracle pipeline running ITS OWN networks (torch-CPU fp32): nothing is shared but the
+    inputs.  Boxes come from the planted map on both sides and must be bit-exact (so the crops are); the classifier label and
+    the CTC token ids are decisions of two independent fp32 implementations and must agree wherever the oracle's decision
+    margin exceeds EPS (the fp32 tolerance of the network tests is 1e-4 / 2e-4); the fraction of decisive lines is reported."""
+    EPS_CLS, EPS_REC = 1e-3, 1e-3
+    from oracle.pipeline import OracleSession  # a fresh oracle: other tests of this module teacher-force the shared fixture
+    from retto_amd import synth
+    det, cls, rec, dic = synth.synth_models(0)
+    o = OracleSession(det, cls, rec, dic)
+    n_lines = n_dec = n_cls_dec = 0
+    for seed, (h, w, lines) in enumerate([(320, 480, 5), (480, 640, 9), (256, 704, 4)]):
+        page, rects = workload.planted_page(h, w, lines, seed=40 + seed)
+        dh, dw = R.resize_either_dims(h, w)
+        pmap = workload.planted_map(dh, dw, h, w, rects)
+        got = hip_session.run_batch([page], det_map_override=[pmap])[0]
+        ref = o.run(page, det_map_override=pmap)
+        assert len(got.det_result) == len(ref.det_boxes) == lines
+        assert np.array_equal(np.stack([d.boxes.as_array() for d in got.det_result]), ref.det_boxes)
+        assert np.array_equal(np.array([d.score for d in got.det_result], np.float32).view(np.uint32), ref.det_scores.view(np.uint32))
+        for k in range(lines):
+            n_lines += 1
+            if ref.cls_margins[k] > EPS_CLS:
+                n_cls_dec += 1
+                assert got.cls_result[k].label.label == int(ref.cls_labels[k])
+                assert abs(got.cls_result[k].label.score - float(ref.cls_scores[k])) <= 1e-4
+            if ref.rec_margins[k] > EPS_REC:
+                n_dec += 1
+                assert np.array_equal(got.rec_result[k].tokens, ref.rec_tokens[k]), f"page {seed} line {k}"
+                assert got.rec_result[k].text == ref.rec_text[k]
+                if len(ref.rec_tokens[k]):
+                    assert abs(got.rec_result[k].score - float(ref.rec_scores[k])) <= 2e-4
+    print(f"independent oracle: {n_lines} lines, cls decisive {n_cls_dec}, rec decisive {n_dec}")
+    assert n_dec >= n_lines // 2 and n_cls_dec >= n_lines // 2
+
+
+# ---------------------------------------------------------------- differential fuzz on the ill-defined corners (SURVEY A.4 / A.5)
+@pytest.mark.parametrize("seed", range(6))
+def test_det_postprocess_non_transitive_reading_order(hip_session, seed):
+    """A.5: the reading-order comparator (|dy| < 10 -> by x, else by y) is not transitive on staircases of boxes whose centres
+    are < 10 px apart pairwise-adjacent but > 10 px apart end to end.  Rust's sort is unspecified there; the contract of this
+    build is the bottom-up stable merge sort over contour discovery order -- device and oracle must apply the same one."""
+    rng = np.random.default_rng(500 + seed)
+    H, W = 512, 768
+    m = np.full((H, W), 0.01, np.float32)
+    x = 20
+    y = int(rng.integers(30, 60))
+    for _ in range(int(rng.integers(8, 14))):          # a staircase: each box 4-8 px lower than the previous one, shuffled x order
+        bw, bh = int(rng.integers(30, 50)), int(rng.integers(12, 18))
+        xs = int(rng.integers(10, W - 60))
+        m[y:y + bh, xs:xs + bw] = 0.9
+        y += bh + int(rng.integers(4, 8)) if rng.uniform() < 0.4 else int(rng.integers(4, 8))
+        if y > H - 40:
+            break
+    # plus two clean rows far below, so that the sorted prefix / suffix is unambiguous
+    m[440:455, 100:200] = 0.9; m[440:455, 300:420] = 0.9
+    gb, gs = hip_session.det_postprocess(m, H, W)
+    rb, rs = R.det_postprocess(m, H, W)
+    assert len(gb) == len(rb) >= 3
+    assert np.array_equal(gb, rb) and np.array_equal(gs.view(np.uint32), rs.view(np.uint32))
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_det_postprocess_degenerate_hulls_without_dilation(seed):
+    """A.4: with the dilation kernel disabled (dilation_kernel = None) isolated pixels and 1-pixel-wide runs reach min_area_rect as
+    1- and 2-point hulls and collinear point sets; imageproc's draw_polygon_mut panics on some of them in the reference.  The
+    defined behaviour here (score 0 -> dropped, everything else as usual) must be the same on the device and in the oracle."""
+    import retto_amd
+    cfg = retto_amd.synthetic_session_config(0)
+    cfg.det_processor_config.dilation_kernel = None
+    s = retto_amd.RettoSession(cfg)
+    try:
+        rng = np.random.default_rng(700 + seed)
+        H, W = 192, 256
+        m = np.full((H, W), 0.02, np.float32)
+        for _ in range(40):                                   # single pixels, horizontal / vertical / diagonal 2-6 pixel runs
+            y0, x0 = int(rng.integers(0, H)), int(rng.integers(0, W))
+            n, (dy, dx) = int(rng.integers(1, 7)), [(0, 1), (1, 0), (1, 1), (1, -1)][int(rng.integers(0, 4))]
+            for k in range(n):
+                yy, xx = y0 + k * dy, x0 + k * dx
+                if 0 <= yy < H and 0 <= xx < W:
+                    m[yy, xx] = 0.95
+        m[60:75, 40:180] = 0.9                                # one real line
+        m[0, :] = 0.9; m[:, W - 1] = 0.9                      # 1-pixel strips hugging the frame
+        gb, gs = s.det_postprocess(m, H, W)
+        rb, rs = R.det_postprocess(m, H, W, dilate=False)
+        assert len(gb) == len(rb) >= 1
+        assert np.array_equal(gb, rb) and np.array_equal(gs.view(np.uint32), rs.view(np.uint32))
+    finally:
+        s.close()
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_det_postprocess_border_hugging_contours(hip_session, seed):
+    """Blobs that touch or run along the frame (1-3 pixel strips on each side, corners, a frame-wide bar): border start pixels,
+    hull points on the image edge, clipped boxes."""
+    rng = np.random.default_rng(900 + seed)
+    H, W = 160 + 32 * seed, 224
+    m = np.full((H, W), 0.05, np.float32)
+    t = int(rng.integers(1, 4))
+    m[:t, 10:150] = 0.9; m[H - t:, 40:200] = 0.9; m[20:120, :t] = 0.9; m[30:100, W - t:] = 0.9
+    m[:12, :14] = 0.9; m[H - 9:, W - 16:] = 0.9               # corners
+    m[70:82, :] = 0.85                                        # a bar across the whole width
+    m[100:130, 60:160] = np.clip(rng.normal(0.7, 0.2, (30, 100)), 0, 1).astype(np.float32)
+    gb, gs = hip_session.det_postprocess(m, H, W)
+    rb, rs = R.det_postprocess(m, H, W)
+    assert len(gb) == len(rb) >= 2
+    assert np.array_equal(gb, rb) and np.array_equal(gs.view(np.uint32), rs.view(np.uint32))

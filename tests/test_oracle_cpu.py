@@ -306,3 +306,124 @@ def test_cpu_baseline_protocol():
     assert out["kind"] == "port" and out["unit"] == "images/s" and out["value"] and out["value"] > 0 and out["cores"] >= 1
     assert set(out["stage_cpu_ms_per_page"]) == {"det", "cls", "rec", "pre_post"}
     assert "3 timed repetitions" in out["sample"] and out["one_thread_images_per_s"] > 0
+
+
+# ---- independent numpy re-derivations of two third-party algorithms from their published descriptions,
+# ---- written array-at-a-time from the text, not from oracle/retto_oracle.cpp
+def _np_thumbnail(img, nh, nw):
+    """image::imageops::thumbnail (B.1): per output pixel the source span [ceil(o * r), ceil((o + 1) * r)) in f32; non-empty spans
+    are box-averaged with integer rounding (sum + n/2) / n, an empty span interpolates linearly between the two neighbouring
+    source pixels with fraction (fract(lo) + fract(hi)) / 2 and truncates."""
+    h, w = img.shape[:2]
+    f = np.float32
+
+    def spans(n_src, n_dst):
+        r = f(n_src) / f(n_dst)
+        lo_f = np.arange(n_dst, dtype=np.float32) * r
+        hi_f = lo_f + r
+        lo = np.clip(np.ceil(lo_f).astype(np.int64), 0, n_src - 1)
+        hi = np.clip(np.ceil(hi_f).astype(np.int64), lo, n_src)
+        frac = ((lo_f - np.floor(lo_f)) + (hi_f - np.floor(hi_f))) / f(2.0)
+        return lo, hi, frac.astype(np.float32)
+    y0, y1, fy = spans(h, nh)
+    x0, x1, fx = spans(w, nw)
+    out = np.zeros((nh, nw, 3), np.uint8)
+    src = img.astype(np.int64)
+    for oy in range(nh):
+        for ox in range(nw):
+            ny, nx = y1[oy] - y0[oy], x1[ox] - x0[ox]
+            if ny and nx:
+                blk = src[y0[oy]:y1[oy], x0[ox]:x1[ox]].reshape(-1, 3)
+                n = blk.shape[0]
+                out[oy, ox] = np.minimum((blk.sum(0) + n // 2) // n, 255)
+            elif ny:      # no column falls into the span: between columns x1-1 and x1
+                l = x1[ox] - 1
+                sl = src[y0[oy]:y1[oy], l].sum(0).astype(np.float32); sr = src[y0[oy]:y1[oy], l + 1].sum(0).astype(np.float32)
+                v = (f(1.0) - fx[ox]) / f(ny) * sl + fx[ox] / f(ny) * sr
+                out[oy, ox] = v.astype(np.float32).astype(np.uint8)
+            elif nx:
+                b = y1[oy] - 1
+                sb = src[b, x0[ox]:x1[ox]].sum(0).astype(np.float32); st = src[b + 1, x0[ox]:x1[ox]].sum(0).astype(np.float32)
+                v = (f(1.0) - fy[oy]) / f(nx) * sb + fy[oy] / f(nx) * st
+                out[oy, ox] = v.astype(np.float32).astype(np.uint8)
+            else:
+                l, b = x1[ox] - 1, y1[oy] - 1
+                k = src[b:b + 2, l:l + 2].astype(np.float32)
+                v = ((f(1) - fy[oy]) * fx[ox] * k[0, 1] + fy[oy] * fx[ox] * k[1, 1]
+                     + (f(1) - fy[oy]) * (f(1) - fx[ox]) * k[0, 0] + fy[oy] * (f(1) - fx[ox]) * k[1, 0])
+                out[oy, ox] = v.astype(np.float32).astype(np.uint8)
+    return out
+
+
+@pytest.mark.parametrize("hw,new", [((40, 60), (13, 20)), ((17, 23), (48, 61)), ((30, 200), (48, 320)), ((64, 64), (64, 64)),
+                                    ((9, 31), (48, 160)), ((50, 37), (25, 80)), ((37, 41), (48, 54))])
+def test_thumbnail_matches_independent_numpy_derivation(hw, new):
+    """Downscale (box average), upscale (the fractional paths, as resize_norm_image hits for crops lower than 48 px) and mixed."""
+    rng = np.random.default_rng(hw[0] * 100 + new[1])
+    img = rng.integers(0, 256, hw + (3,), dtype=np.uint8)
+    ref = _np_thumbnail(img, new[0], new[1])
+    got = R.thumbnail(img, new[0], new[1])
+    assert got.shape == ref.shape
+    assert np.array_equal(got, ref), f"{int((got != ref).sum())} of {got.size} samples differ"
+
+
+def _np_bicubic_warp(img, box, cw, ch, out_w, out_h):
+    """imageproc warp_into(Bicubic) (B.6): homography box -> (0,0),(cw,0),(cw,ch),(0,ch) by the 8x8 DLT system, every output
+    pixel (x, y) mapped back through its inverse, 4x4 cubic-convolution (a = -0.5) footprint floor(p) - 1 .. floor(p) + 2, pixels
+    whose footprint leaves the image are white.  Weights form of the kernel, float64 -- an independent arithmetic."""
+    src_pts = np.asarray(box, np.float64).reshape(4, 2)
+    dst_pts = np.array([[0, 0], [cw, 0], [cw, ch], [0, ch]], np.float64)
+    A, b = [], []
+    for (x, y), (u, v) in zip(src_pts, dst_pts):
+        A.append([x, y, 1, 0, 0, 0, -u * x, -u * y]); b.append(u)
+        A.append([0, 0, 0, x, y, 1, -v * x, -v * y]); b.append(v)
+    hvec = np.linalg.solve(np.asarray(A), np.asarray(b))
+    Hm = np.append(hvec, 1.0).reshape(3, 3)
+    Hi = np.linalg.inv(Hm)
+    H, W = img.shape[:2]
+    ys, xs = np.mgrid[0:out_h, 0:out_w].astype(np.float64)
+    d = Hi[2, 0] * xs + Hi[2, 1] * ys + Hi[2, 2]
+    px = (Hi[0, 0] * xs + Hi[0, 1] * ys + Hi[0, 2]) / d
+    py = (Hi[1, 0] * xs + Hi[1, 1] * ys + Hi[1, 2]) / d
+
+    def wts(t):   # cubic convolution, a = -0.5, taps at -1, 0, 1, 2
+        a = -0.5
+        x = np.stack([t + 1, t, 1 - t, 2 - t])
+        return np.where(x <= 1, (a + 2) * x ** 3 - (a + 3) * x ** 2 + 1, a * x ** 3 - 5 * a * x ** 2 + 8 * a * x - 4 * a)
+    out = np.full((out_h, out_w, 3), 255, np.uint8)
+    fx, fy = np.floor(px), np.floor(py)
+    inside = (fx - 1 >= 0) & (fx + 3 < W) & (fy - 1 >= 0) & (fy + 3 < H)
+    wx, wy = wts(px - fx), wts(py - fy)
+    exact = np.zeros((out_h, out_w), bool)
+    for oy, ox in zip(*np.nonzero(inside)):
+        x0, y0 = int(fx[oy, ox]) - 1, int(fy[oy, ox]) - 1
+        patch = img[y0:y0 + 4, x0:x0 + 4].astype(np.float64)
+        rows = np.clip(np.floor(np.clip((patch * wx[:, oy, ox][None, :, None]).sum(1), 0, 255)), 0, 255)   # u8 intermediates, as the pixel type forces
+        out[oy, ox] = np.clip((rows * wy[:, oy, ox][:, None]).sum(0), 0, 255).astype(np.uint8)
+    return out, inside
+
+
+@pytest.mark.parametrize("box", [
+    [[10.0, 12.0], [90.0, 12.0], [90.0, 40.0], [10.0, 40.0]],          # axis aligned, integer corners
+    [[20.0, 30.0], [100.0, 18.0], [105.0, 47.0], [25.0, 60.0]],         # rotated quadrilateral
+    [[2.0, 2.0], [60.0, 5.0], [58.0, 30.0], [1.0, 27.0]],               # footprint leaves the image near the border -> white
+])
+def test_crop_matches_independent_numpy_derivation(box):
+    rng = np.random.default_rng(7)
+    img = np.repeat(np.repeat(rng.integers(0, 256, (20, 32, 3), dtype=np.uint8), 4, 0), 4, 1)   # 80 x 128, smooth in 4 x 4 blocks
+    b = np.asarray(box, np.float32)
+    got = R.get_crop_img(img, b)
+    w_c, h_c = R.crop_dims(b)[:2] if hasattr(R, "crop_dims") else (got.shape[1], got.shape[0])
+    cw = max(np.hypot(*(b[3] - b[2])), np.hypot(*(b[0] - b[1])))
+    ch = max(np.hypot(*(b[1] - b[2])), np.hypot(*(b[0] - b[3])))
+    if got.shape[0] / got.shape[1] >= 1.5:
+        pytest.skip("rotated crops are covered by the rotate270 known-answer test")
+    ref, inside = _np_bicubic_warp(img, b, float(np.float32(cw)), float(np.float32(ch)), got.shape[1], got.shape[0])
+    assert got.shape == ref.shape
+    # same footprint rule: white exactly where the independent derivation says the 4x4 window leaves the image
+    white = (got == 255).all(-1)
+    assert (white | inside).all() and (~inside <= white).all()
+    diff = np.abs(got.astype(int) - ref.astype(int))
+    # f32 polynomial form (two truncations to u8) vs f64 weights form: a grey level per truncation at most
+    assert diff.max() <= 2, f"max diff {diff.max()}"
+    assert (diff <= 1).mean() > 0.98 and (diff == 0).mean() > 0.75, ((diff <= 1).mean(), (diff == 0).mean())
