@@ -97,8 +97,9 @@ class GraphWriter:
         return out
 
     # ---- parameter-carrying patterns -------------------------------------------------------
-    def conv(self, w, b=None, bn=False, pre_lab=False, transpose=False, bias_as_add=False):
-        """Emits a conv whose folded form is (w, b).  bn / pre_lab un-fold it first."""
+    def conv(self, w, b=None, bn=False, pre_lab=False, transpose=False, bias_as_add=False, record=None):
+        """Emits a conv whose folded form is (w, b).  bn / pre_lab un-fold it first.  record (a dict) receives the UN-FOLDED
+        parameters exactly as written into the file: w, b (or None), bn = (scale, B, mean, var, eps) or None, lab = (a, c) or None."""
         w = w.astype(np.float64)
         cout = w.shape[1] if transpose else w.shape[0]
         b = np.zeros(cout) if b is None else b.astype(np.float64)
@@ -128,6 +129,10 @@ class GraphWriter:
         if lab:
             self.op("Mul", [self.param(np.array([lab[0]], np.float32))])
             self.op("Add", [self.param(np.array([lab[1]], np.float32))])
+        if record is not None:
+            record.update(w=w.astype(np.float32), b=b.astype(np.float32) if has_bias else None,
+                          bn=tuple(np.asarray(v, np.float32) for v in bnp[:4]) + (bnp[4],) if bnp else None,
+                          lab=(np.float32(lab[0]), np.float32(lab[1])) if lab else None, transpose=transpose)
 
     def lab(self, a, c):
         self.op("Mul", [self.param(np.asarray(a, np.float32).reshape(1))])
@@ -136,6 +141,11 @@ class GraphWriter:
     def hardswish(self, decomposed=False):
         if not decomposed:
             self.op("HardSwish")
+            return
+        if decomposed == "hardsigmoid":   # x * HardSigmoid(alpha = 1/6, beta = 0.5)(x): the opset < 14 export of hard_swish
+            x = self.cur
+            self.op("HardSigmoid", attrs=[attr_float("alpha", 1.0 / 6.0), attr_float("beta", 0.5)])
+            out = self._name("t"); self.node("Mul", [x, self.cur], [out]); self.cur = out
             return
         x = self.cur  # x * clip(x + 3, 0, 6) / 6 with scalar constants: must not be taken for a LAB
         self.op("Add", [self.param(np.array([3.0], np.float32))])
@@ -160,6 +170,8 @@ class GraphWriter:
 
     def distract(self):
         self.op("Reshape", [self.param(np.array([0, -1, 120], np.int64))])
+        self.op("Transpose", attrs=[attr_ints("perm", [0, 2, 1, 3])])               # head split / merge around the attention
+        self.op("Clip", attrs=[attr_float("min", 0.0), attr_float("max", 6.0)])     # opset < 11 form: limits as attributes
         self.op("Mul", [self.param(np.array([0.2581989], np.float32))])  # attention scale: scalar Mul without Add
         self.op("HardSigmoid", attrs=[attr_float("alpha", 0.2), attr_float("beta", 0.5)])
 
@@ -168,10 +180,11 @@ class GraphWriter:
         return _vi(1, 8) + _ld(7, graph)
 
 
-def build_model_onnx(manifest_text, tensors, seed=0, style=0):
+def build_model_onnx(manifest_text, tensors, seed=0, style=0, unfolded=None):
     """manifest_text: rt_model_manifest output; tensors: RTWB name -> array (retto_amd.synth).  style varies the
     patterns (0: BN un-folded + initializers + decomposed LayerNorm; 1: Constant nodes, LayerNormalization op,
-    Gemm head, bias as a separate Add, decomposed hardswish)."""
+    Gemm head, bias as a separate Add, hardswish as Add / Clip / Mul / Div; 2: like 0 with hardswish as x * HardSigmoid(x)).
+    unfolded (a dict) receives, per conv base name, the parameters as they stand in the file (GraphWriter.conv)."""
     g = GraphWriter(seed, constants_as_nodes=(style == 1))
     names = [l.split()[0] for l in manifest_text.strip().split("\n")]
     i = 0
@@ -184,10 +197,13 @@ def build_model_onnx(manifest_text, tensors, seed=0, style=0):
             b = tensors[base + ".b"] if has_b else None
             if w.ndim == 4:
                 lc = base.endswith(".dw") or base.endswith(".pw")
-                g.conv(w, b, bn=(has_b and style == 0 and not lc), pre_lab=lc and base.split(".")[0] != "cls",
-                       transpose="deconv" in base, bias_as_add=(style == 1 and has_b and not lc))
+                rec = {} if unfolded is not None else None
+                g.conv(w, b, bn=(has_b and style != 1 and not lc), pre_lab=lc and base.split(".")[0] != "cls",
+                       transpose="deconv" in base, bias_as_add=(style == 1 and has_b and not lc), record=rec)
+                if unfolded is not None:
+                    unfolded[base] = rec
                 if lc and base + ".a" in tensors:
-                    g.hardswish(decomposed=(style == 1))
+                    g.hardswish(decomposed={0: False, 1: True, 2: "hardsigmoid"}[style])
                 elif not lc:
                     g.op("Relu")
             else:

@@ -341,3 +341,65 @@ print("cabi rccl ok")
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
     assert out.returncode == 0 and "cabi rccl ok" in out.stdout, (out.stdout[-500:], out.stderr[-2000:])
+
+
+@pytest.mark.parametrize("style", [0, 1, 2])
+def test_onnx_import_against_unfolded_torch_forward(style):
+    """The importer against an INDEPENDENT evaluation of what the file says: the .onnx files are written with un-folded
+    parameters (Conv weights + separate BatchNormalization statistics, LearnableAffineBlock scalars in front of the activation,
+    bias as its own Add, three spellings of hardswish); the torch oracle is fed those un-folded tensors as they stand in the
+    file (conv -> bias -> BN with the file's epsilon -> affine), the HIP session is created from the .onnx bytes.  Agreement
+    to 1e-4 checks the importer's matching AND its folding arithmetic, not the importer against itself."""
+    import sys
+    sys.path.insert(0, os.path.dirname(__file__))
+    import torch
+    import torch.nn.functional as F
+    import retto_amd
+    from oracle import nets_torch as N
+    from retto_amd import synth
+    from onnx_writer import build_model_onnx
+    tens = [synth.det_tensors(1), synth.cls_tensors(3), synth.rec_tensors(2)]
+    kinds = [retto_amd.MODEL_DET, retto_amd.MODEL_CLS, retto_amd.MODEL_REC]
+    unf = [{}, {}, {}]
+    onnx = [build_model_onnx(retto_amd.model_manifest(k), t, seed=30 + style, style=style, unfolded=u) for k, t, u in zip(kinds, tens, unf)]
+    S = retto_amd.RettoWorkerModelSource
+    cfg = retto_amd.synthetic_session_config(0)
+    cfg.worker_config.models = retto_amd.RettoWorkerModelProvider(det=S.Blob(onnx[0]), rec=S.Blob(onnx[2]), cls=S.Blob(onnx[1]))
+    sess = retto_amd.RettoSession(cfg)
+
+    def unfolded_conv(u):
+        def conv(w, name, x, stride=(1, 1), pad=(0, 0), groups=1):
+            r = u.get(name)
+            if r is None:                       # not a conv written by GraphWriter.conv (never happens for 4-d weights)
+                return F.conv2d(x, w[name + ".w"], w.get(name + ".b"), stride=stride, padding=pad, groups=groups)
+            y = F.conv2d(x, torch.from_numpy(r["w"]), None if r["b"] is None else torch.from_numpy(r["b"]), stride=stride, padding=pad, groups=groups)
+            if r["bn"] is not None:
+                s_, B, mean, var, eps = r["bn"]
+                y = F.batch_norm(y, torch.from_numpy(mean), torch.from_numpy(var), torch.from_numpy(s_), torch.from_numpy(B), False, 0.0, eps)
+            if r["lab"] is not None:
+                y = y * float(r["lab"][0]) + float(r["lab"][1])
+            return y
+        return conv
+    saved = N._conv
+    try:
+        rng = np.random.default_rng(5 + style)
+        x = rng.uniform(-1, 1, (1, 3, 96, 160)).astype(np.float32)
+        N._conv = unfolded_conv(unf[0])
+        w = {k: torch.from_numpy(v) for k, v in tens[0].items()}
+        ref = N.det_forward(w, torch.from_numpy(x)).numpy()
+        # (the two transposed convs of the DB head are not routed through _conv: they stay folded in the oracle)
+        assert np.abs(sess.worker.det(x) - ref).max() <= 1e-4
+        x = rng.uniform(-1, 1, (3, 3, 48, 192)).astype(np.float32)
+        N._conv = unfolded_conv(unf[1])
+        ref = N.cls_forward({k: torch.from_numpy(v) for k, v in tens[1].items()}, torch.from_numpy(x)).numpy()
+        assert np.abs(sess.worker.cls(x) - ref).max() <= 1e-4
+        x = rng.uniform(-1, 1, (2, 3, 48, 320)).astype(np.float32)
+        N._conv = unfolded_conv(unf[2])
+        ref = N.rec_forward({k: torch.from_numpy(v) for k, v in tens[2].items()}, torch.from_numpy(x)).numpy()
+        assert np.abs(sess.worker.rec(x) - ref).max() <= 2e-4
+        n_bn = sum(1 for u in unf for r in u.values() if r["bn"] is not None)
+        assert n_bn == 0 if style == 1 else n_bn > 10      # style 1 writes folded convs with the bias as a separate Add
+        assert sum(1 for u in unf for r in u.values() if r["lab"] is not None) > 20
+    finally:
+        N._conv = saved
+        sess.close()
