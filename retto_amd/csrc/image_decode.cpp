@@ -741,6 +741,15 @@ void decode_image(const uint8_t* data, size_t len, std::vector<uint8_t>* rgb, in
   if (data[0] == 0xff && data[1] == 0xd8) { JpegDec j{data, len}; return j.run(rgb, h, w); }
   if (data[0] == 'P' && (data[1] == '2' || data[1] == '3' || data[1] == '5' || data[1] == '6')) return decode_pnm(data, len, rgb, h, w);
   if (data[0] == 'B' && data[1] == 'M') return decode_bmp(data, len, rgb, h, w);
+  // Formats image 0.25.6 reads with its default features (/root/reference/Cargo.toml:23) that this decoder does not: named,
+  // so that a caller sees WHICH decoder is missing instead of the reference's "format could not be determined".
+  struct Sig { const char* magic; size_t n; size_t off; const char* name; };
+  static const Sig sigs[] = {{"GIF87a", 6, 0, "GIF"}, {"GIF89a", 6, 0, "GIF"}, {"WEBP", 4, 8, "WebP"}, {"II*\0", 4, 0, "TIFF"}, {"MM\0*", 4, 0, "TIFF"},
+                             {"\x76\x2f\x31\x01", 4, 0, "OpenEXR"}, {"#?RADIANCE", 10, 0, "Radiance HDR"}, {"qoif", 4, 0, "QOI"},
+                             {"\0\0\1\0", 4, 0, "ICO"}, {"DDS ", 4, 0, "DDS"}, {"farbfeld", 8, 0, "farbfeld"}, {"ftypavif", 8, 4, "AVIF"}};
+  for (const Sig& g : sigs)
+    if (len >= g.off + g.n && !memcmp(data + g.off, g.magic, g.n))
+      bad(std::string(g.name) + " input: the reference decodes it (image crate default features), this decoder reads PNG, JPEG, PNM and BMP only");
   bad("unrecognised image format (PNG, JPEG, PNM and BMP are read)");
 }
 

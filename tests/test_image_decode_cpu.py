@@ -253,3 +253,13 @@ def test_jpeg_unsupported_and_corrupt():
     cmyk = _save(Image.fromarray(np.dstack([a, a[..., :1]]), "CMYK"), "JPEG")
     with pytest.raises(retto_amd.ImageError, match="CMYK"):
         retto_amd.decode_image(cmyk)
+
+
+@pytest.mark.parametrize("head,name", [(b"GIF89a" + b"\0" * 32, "GIF"), (b"RIFF\x10\0\0\0WEBPVP8 " + b"\0" * 16, "WebP"),
+                                       (b"II*\0" + b"\0" * 16, "TIFF"), (b"MM\0*" + b"\0" * 16, "TIFF"), (b"qoif" + b"\0" * 16, "QOI")])
+def test_formats_the_reference_reads_but_this_decoder_does_not_are_named(head, name):
+    """image 0.25.6 with default features (the reference's Cargo.toml:23) also reads GIF / WebP / TIFF / ...; here they fail
+    with ImageError naming the format (the documented gap), never with a silent mis-decode."""
+    with pytest.raises(retto_amd.ImageError) as e:
+        retto_amd.decode_image(head)
+    assert name in str(e.value)

@@ -57,3 +57,51 @@ def test_import_errors():
     with pytest.raises(retto_amd.RettoError) as ei:
         retto_amd.onnx_to_rtwb(retto_amd.MODEL_CLS, g.finish())  # stops at the first missing layer
     assert "cls.b0.expand.w" in str(ei.value)
+
+
+def test_real_paddle2onnx_files_when_present():
+    """Opt-in: RETTO_REAL_MODELS=<dir with ch_PP-OCRv4_det_infer.onnx, ch_PP-OCRv4_rec_infer.onnx,
+    ch_ppocr_mobile_v2.0_cls_infer.onnx, ppocr_keys_v1.txt> (the files retto-core/build.rs:7-12 downloads).  None exists offline,
+    so this is skipped here; with the files it checks that the importer's event matcher accepts the real graphs (manifest match)
+    and -- when onnxruntime is importable and a GPU is present -- one forward pass per network against onnxruntime-CPU."""
+    import os
+    import pytest
+    d = os.environ.get("RETTO_REAL_MODELS")
+    if not d:
+        pytest.skip("RETTO_REAL_MODELS not set (the real PP-OCRv4 .onnx files are not available offline)")
+    import retto_amd
+    files = {retto_amd.MODEL_DET: "ch_PP-OCRv4_det_infer.onnx", retto_amd.MODEL_CLS: "ch_ppocr_mobile_v2.0_cls_infer.onnx",
+             retto_amd.MODEL_REC: "ch_PP-OCRv4_rec_infer.onnx"}
+    blobs = {}
+    for kind, name in files.items():
+        data = open(os.path.join(d, name), "rb").read()
+        blobs[kind] = retto_amd.onnx_to_rtwb(kind, data)       # raises with the offending node / tensor on any mismatch
+        assert blobs[kind][:4] == b"RTWB"
+    keys = open(os.path.join(d, "ppocr_keys_v1.txt"), "rb").read()
+    from oracle.pipeline import load_dictionary
+    assert len(load_dictionary(keys)) == 6625
+    try:
+        import onnxruntime as ort
+    except ImportError:
+        pytest.skip("onnxruntime not installed: manifest match checked, forward comparison skipped")
+    S = retto_amd.RettoWorkerModelSource
+    cfg = retto_amd.RettoSessionConfig()
+    cfg.worker_config = retto_amd.RettoHipWorkerConfig(device=0, models=retto_amd.RettoWorkerModelProvider(
+        det=S.Path(os.path.join(d, files[retto_amd.MODEL_DET])), rec=S.Path(os.path.join(d, files[retto_amd.MODEL_REC])),
+        cls=S.Path(os.path.join(d, files[retto_amd.MODEL_CLS]))))
+    cfg.rec_processor_config.character_source = S.Path(os.path.join(d, "ppocr_keys_v1.txt"))
+    try:
+        sess = retto_amd.RettoSession(cfg)
+    except retto_amd.BackendError:
+        pytest.skip("no GPU: manifest match checked, forward comparison skipped")
+    try:
+        rng = np.random.default_rng(0)
+        for kind, shape, fn, tol in ((retto_amd.MODEL_DET, (1, 3, 320, 480), sess.worker.det, 1e-4),
+                                     (retto_amd.MODEL_CLS, (2, 3, 48, 192), sess.worker.cls, 1e-4),
+                                     (retto_amd.MODEL_REC, (2, 3, 48, 320), sess.worker.rec, 2e-4)):
+            x = rng.uniform(-1, 1, shape).astype(np.float32)
+            o = ort.InferenceSession(os.path.join(d, files[kind]), providers=["CPUExecutionProvider"])
+            ref = o.run(None, {o.get_inputs()[0].name: x})[0]
+            assert np.abs(fn(x) - ref).max() <= tol
+    finally:
+        sess.close()
