@@ -86,13 +86,6 @@ def parse():
     return a
 
 
-def git_sha():
-    try:
-        return subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short=12", "HEAD"], stderr=subprocess.DEVNULL).decode().strip()
-    except Exception:
-        return None
-
-
 def page_digest(lib, r, i):
     """Stable digest of one page's discrete results (boxes, labels, token ids): what must not depend on the rank / batch."""
     n = lib.rt_results_count(r, i)
@@ -388,21 +381,25 @@ def main():
                 roofline = {"bound": "mfma", "achieved": round(tfs, 2), "peak": mfma_peak, "unit": "TFLOP/s",
                             "frac": round(mfma_frac, 4), "traffic": None}
             # HBM bytes per launch come from separate rocprofv3 --pmc passes (tools/pmc_summary.py: FETCH_SIZE / WRITE_SIZE,
-            # gfx950 corrections) committed as profiles/pmc_traffic.json together with the git SHA and command they were taken
-            # at: used only when they describe THIS workload, and stamped with that SHA (stale = different from HEAD).
-            pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+            # gfx950 corrections) committed as profiles/pmc_traffic_<workload>.json together with the workload flags and a digest
+            # of the kernel sources they were taken on: used only when both match this run.
+            pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic_%s.json" % a.workload)
             if os.path.exists(pmc_path):
+                from retto_amd import _lib as _L
                 pj = json.load(open(pmc_path))
                 same_workload = pj.get("workload") == {"workload": a.workload, "pages": a.pages, "size": a.size, "lines": a.lines,
                                                        "dtype": a.dtype, "models": a.models}
                 k = pj.get("kernels", {}).get(pj.get("labels", {}).get(name, ""))
                 if same_workload and k:
-                    head = git_sha()
-                    roofline["traffic"] = k["fetch_bytes_per_launch"] + k["write_bytes_per_launch"]
-                    roofline["traffic_source"] = {"file": "profiles/pmc_traffic.json", "collected_at_sha": pj.get("git_sha"),
-                                                  "head_sha": head, "stale": bool(head and pj.get("git_sha") and head != pj.get("git_sha")),
-                                                  "how": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (FETCH_SIZE x2 on gfx950)"}
-                    if "sq" in k:  # SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8) and the clock of that pass
+                    now = _L.source_digest()
+                    stale = now != pj.get("csrc_digest")
+                    # a profile of other sources is not evidence for this build: reported as stale, never copied into `traffic`
+                    roofline["traffic"] = None if stale else k["fetch_bytes_per_launch"] + k["write_bytes_per_launch"]
+                    roofline["traffic_source"] = {"file": "profiles/" + os.path.basename(pmc_path), "collected_on_csrc_digest": pj.get("csrc_digest"),
+                                                  "this_build_csrc_digest": now, "stale": stale,
+                                                  "how": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (FETCH_SIZE x2 on gfx950), "
+                                                         "tools/pmc_summary.py"}
+                    if "sq" in k and not stale:  # SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8) and the clock of that pass
                         roofline["mfma_util_pmc"] = k["sq"]["mfma_util"]
                         roofline["clock_ghz_pmc"] = k["sq"]["clock_ghz"]
             roofline.update({"kernel": name, "avg_launch_ms": round(avg_ms, 4), "launches_per_step": launches_per_step,

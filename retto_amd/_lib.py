@@ -59,6 +59,20 @@ STAGE_CALLBACK = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.c_int, C.c_char_p)  # 
 _lib = None
 
 
+def source_digest() -> str:
+    """sha256 over the kernel / host sources of libretto_hip (retto_amd/csrc/*.hip, *.cpp, *.h and the public header): what a
+    committed profile (profiles/pmc_traffic.json) was collected on.  Content-based, so it is the same in a git checkout and in
+    the snapshot a GPU box receives (which has no .git)."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(glob.glob(os.path.join(_HERE, "csrc", "*.hip")) + glob.glob(os.path.join(_HERE, "csrc", "*.cpp")) +
+                   glob.glob(os.path.join(_HERE, "csrc", "*.h")) + [os.path.join(os.path.dirname(_HERE), "include", "retto_hip.h")])
+    for f in files:
+        h.update(os.path.basename(f).encode()); h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def load():
     """Loads the HIP library; raises (never falls back) when it is absent."""
     global _lib

@@ -2,7 +2,11 @@
 HIP-event profiler labels every LCNet block kernel "family@shape"; prints time per launch with
 the algorithmic bytes and FLOPs of that launch.
 
-    RT_PROFILE_DETAIL=1 python tools/layer_profile.py [pages] [steps]
+    RT_PROFILE_DETAIL=1 python tools/layer_profile.py [pages] [steps] [lines]     (lines = 0: det network + DB post only)
+
+Columns: ms per step, family, shape, launches per step, ms per launch, algorithmic TB/s and TFLOP/s of a launch (input read once +
+output written once, fp32; 2 x MACs), and the fraction of the roofline that binds it: max(TB/s / 8.0, TFLOP/s / 157.3) with the
+binding side named (MI355X_MICROARCH.md: HBM3E 8 TB/s spec -- about 6.3 achievable --, fp32 MFMA 157.3 TFLOP/s).
 """
 import ctypes as C, os, sys
 os.environ.setdefault("RT_PROFILE_DETAIL", "1")
@@ -12,6 +16,7 @@ from retto_amd import workload
 
 pages_n = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+lines_n = int(sys.argv[3]) if len(sys.argv) > 3 else 32
 cfg = retto_amd.synthetic_session_config(0)
 cfg.lanes = 1
 s = retto_amd.RettoSession(cfg)
@@ -20,7 +25,7 @@ if os.environ.get("VARIANTS"):
     lib.rt_debug_set_variants(*[int(v) for v in os.environ["VARIANTS"].split(",")])
 d_pages, d_maps = [], []
 for i in range(pages_n):
-    page, rects = workload.planted_page(960, 960, 32, seed=i)
+    page, rects = workload.planted_page(960, 960, lines_n, seed=i)
     m = workload.planted_map(960, 960, 960, 960, rects)
     for arr, lst in ((page, d_pages), (m, d_maps)):
         p = C.c_void_p()
@@ -51,9 +56,11 @@ for name, (ms, calls) in s.profile_get().items():
 rows.sort(reverse=True)
 tot = sum(r[0] for r in rows)
 print("total profiled %.2f ms/step" % tot)
-print("%8s %-34s %-28s %5s %9s %8s %8s" % ("ms/step", "family", "shape", "n/stp", "ms/launch", "TB/s", "TFLOP/s"))
+print("%8s %-34s %-28s %5s %9s %8s %8s %6s %s" % ("ms/step", "family", "shape", "n/stp", "ms/launch", "TB/s", "TFLOP/s", "frac", "bound"))
 only = os.environ.get("ONLY")
 for r in rows:
     if only and only not in r[1]:
         continue
-    print("%8.3f %-34s %-28s %5d %9.3f %8.2f %8.1f" % (r[0], r[1], r[2], r[3], r[4], r[5] / 1e3, r[6] / 1e3))
+    fh, fm = r[5] / 1e3 / 8.0, r[6] / 1e3 / 157.3
+    print("%8.3f %-34s %-28s %5d %9.3f %8.2f %8.1f %6.2f %s" % (r[0], r[1], r[2], r[3], r[4], r[5] / 1e3, r[6] / 1e3, max(fh, fm),
+                                                              "" if not (r[5] or r[6]) else ("hbm" if fh >= fm else "mfma")))

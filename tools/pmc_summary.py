@@ -45,9 +45,22 @@ def agg_multi(path):
     return d
 
 
+# profiler-label -> kernel symbol of the families bench.py's roofline can name
+LABELS = {"gemm_pw/k_gemm_wide<4,5,4,3>": "k_gemm_wide<4, 5, 4, 3, 0, 0, 0, 0, 0>",
+          "gemm_pw/k_gemm_wide<2,5,4,3>+se": "k_gemm_wide<2, 5, 4, 3, 0, 0, 1, 0, 0>",
+          "gemm_pw/k_gemm_wide<2,4,4,2>": "k_gemm_wide<2, 4, 4, 2, 0, 0, 0, 0, 0>",
+          "conv16_3x3": "k_conv16<4, 2, 1, 4, 0>", "gemm16": "k_conv16<4, 2, 1, 4, 0>"}
+
+
 def main():
+    """pmc_summary.py fetch.csv write.csv out.json [sq.csv] [workload-json]   (workload-json: the dict bench.py compares with its
+    own flags, e.g. '{"workload": "c3", "pages": 32, "size": 960, "lines": 32, "dtype": "f32", "models": "mobile"}')"""
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from retto_amd import _lib
     f, w, out = agg(sys.argv[1]), agg(sys.argv[2]), sys.argv[3]
-    sq = agg_multi(sys.argv[4]) if len(sys.argv) > 4 else {}
+    sq = agg_multi(sys.argv[4]) if len(sys.argv) > 4 and sys.argv[4] else {}
+    wl = json.loads(sys.argv[5]) if len(sys.argv) > 5 else {"workload": "c3", "pages": 32, "size": 960, "lines": 32, "dtype": "f32", "models": "mobile"}
     res = {}
     for k, (n, fv) in f.items():
         wn, wv = w.get(k, [0, 0.0])
@@ -66,7 +79,8 @@ def main():
             "wave_wait_inst_frac": round(avg.get("SQ_WAIT_INST_ANY", 0.0) / max(avg.get("SQ_WAVE_CYCLES", 1.0), 1.0), 3),
             "wave_active_inst_frac": round(avg.get("SQ_ACTIVE_INST_ANY", 0.0) / max(avg.get("SQ_WAVE_CYCLES", 1.0), 1.0), 3)}
     top = dict(sorted(res.items(), key=lambda kv: -(kv[1]["fetch_bytes_per_launch"] + kv[1]["write_bytes_per_launch"]) * kv[1]["launches"])[:40])
-    json.dump({"command": "bench.py --steps 2 --warmup 2 --no-cpu-baseline --lanes 1 (C3 workload), separate --pmc FETCH_SIZE / --pmc WRITE_SIZE passes",
+    json.dump({"command": "bench.py --steps 2 --warmup 2 --no-cpu-baseline --lanes 1 (+ the workload flags below), separate --pmc FETCH_SIZE / --pmc WRITE_SIZE passes",
+               "workload": wl, "csrc_digest": _lib.source_digest(), "labels": LABELS,
                "corrections": "KiB -> bytes; FETCH_SIZE x2 (gfx950 128-byte requests tallied at 64 bytes); WRITE_SIZE as is",
                "kernels": top}, open(out, "w"), indent=1)
     for k, v in list(top.items())[:12]:
