@@ -76,7 +76,7 @@ def parse():
     a = ap.parse_args()
     if a.workload == "c5":
         a.dtype = a.dtype or "f16"; a.models = a.models or "server"
-        a.pages = a.pages or 128; a.steps = a.steps or 3; a.warmup = a.warmup if a.warmup is not None else 2
+        a.pages = a.pages or 128; a.steps = a.steps or 3; a.warmup = a.warmup if a.warmup is not None else 3   # (the arenas of the 3 lanes settle after 3 calls)
     if a.workload == "c2":
         a.pages = a.pages or 1; a.lines = 0 if a.lines is None else a.lines
         a.steps = a.steps or 200; a.warmup = a.warmup if a.warmup is not None else 20
