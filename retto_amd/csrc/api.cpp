@@ -2,6 +2,8 @@
 #include <thread>
 #include <atomic>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 
@@ -403,10 +405,38 @@ RT_API int rt_debug_conv16(rt_session* s, const float* x, int n, int cin, int h,
     RunCtx c = s->ctx(&s->arena);
     upload_levels(c, {&Li, &Lo});
     nh::Epi16 e; e.bias = db; e.act = act;
-    nh::conv16(s->st, dx, cp, Li.d, Lo.d, n, Lo.maxH, Lo.maxW, cp, kh, kw, sh, sw, kh / 2, kw / 2, dw, cout, npad, dy, op, 0, e);
+    long long* d_st = nullptr;
+    const bool stamps = getenv("RT_CONV_STAMPS") != nullptr;
+    if (stamps) { d_st = s->arena.alloc<long long>(4096); RT_HIP_CHECK(hipMemsetAsync(d_st, 0, 4096 * 8, s->st)); nh::g_conv_stamps = d_st; }
+    hipEvent_t ev0, ev1;
+    RT_HIP_CHECK(hipEventCreate(&ev0)); RT_HIP_CHECK(hipEventCreate(&ev1));
+    const int reps = stamps ? 5 : 1;
+    for (int rep = 0; rep < reps; rep++) {
+      if (rep == reps - 1) RT_HIP_CHECK(hipEventRecord(ev0, s->st));
+      nh::conv16(s->st, dx, cp, Li.d, Lo.d, n, Lo.maxH, Lo.maxW, cp, kh, kw, sh, sw, kh / 2, kw / 2, dw, cout, npad, dy, op, 0, e);
+    }
+    RT_HIP_CHECK(hipEventRecord(ev1, s->st));
     std::vector<half_t> hy((size_t)n * ho * wo * op);
     RT_HIP_CHECK(hipMemcpyAsync(hy.data(), dy, hy.size() * 2, hipMemcpyDeviceToHost, s->st));
     s->sync();
+    if (!stamps) { (void)hipEventDestroy(ev0); (void)hipEventDestroy(ev1); }
+    if (stamps) {
+      nh::g_conv_stamps = nullptr;
+      std::vector<long long> hs(4096);
+      RT_HIP_CHECK(hipMemcpy(hs.data(), d_st, 4096 * 8, hipMemcpyDeviceToHost));
+      const int nrows = ((cp + 31) / 32) * kh;
+      float ms = 0.f;
+      RT_HIP_CHECK(hipEventElapsedTime(&ms, ev0, ev1));
+      fprintf(stderr, "launch %.3f ms = %.1f TFLOP/s; one workgroup (k_conv16v2): entry->requests %lld, ->data landed %lld, main loop %lld, epilogue %lld ticks (barrier %lld, math + transpose + store issue %lld, store drain %lld)\n",
+              ms, 2.0 * n * ho * wo * (double)cout * cin * kh * kw / ms / 1e9, hs[4001] - hs[4000], hs[4002] - hs[4001], hs[4003] - hs[4002], hs[4004] - hs[4003], hs[4005] - hs[4003], hs[4006] - hs[4005], hs[4004] - hs[4006]);
+      (void)hipEventDestroy(ev0); (void)hipEventDestroy(ev1);
+      fprintf(stderr, "conv16 stamps (s_memtime ticks): stage: t1-t0 | t2-t1 | t3-t2 | t4-t3 | next t0 - t0   (k_conv16: barrier, staging, barrier, MFMAs; k_conv16v2: DMA issue, MFMAs, vmcnt wait, barrier)\n");
+      for (int r = 0; r < nrows && r < 790; r++) {
+        const long long* t = &hs[(size_t)r * 5];
+        const long long nxt = r + 1 < nrows ? hs[(size_t)(r + 1) * 5] : t[4];
+        fprintf(stderr, "  %3d: %6lld %6lld %6lld %6lld | %6lld\n", r, t[1] - t[0], t[2] - t[1], t[3] - t[2], t[4] - t[3], nxt - t[0]);
+      }
+    }
     for (int i = 0; i < n; i++)
       for (int o = 0; o < cout; o++)
         for (int p = 0; p < ho * wo; p++) out[((size_t)i * cout + o) * ho * wo + p] = (float)hy[((size_t)i * ho * wo + p) * op + o];

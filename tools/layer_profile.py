@@ -6,7 +6,8 @@ the algorithmic bytes and FLOPs of that launch.
 
 Columns: ms per step, family, shape, launches per step, ms per launch, algorithmic TB/s and TFLOP/s of a launch (input read once +
 output written once, fp32; 2 x MACs), and the fraction of the roofline that binds it: max(TB/s / 8.0, TFLOP/s / 157.3) with the
-binding side named (MI355X_MICROARCH.md: HBM3E 8 TB/s spec -- about 6.3 achievable --, fp32 MFMA 157.3 TFLOP/s).
+binding side named (MI355X_MICROARCH.md: HBM3E 8 TB/s spec -- about 6.3 achievable --, fp32 MFMA 157.3 TFLOP/s, fp16 MFMA
+2500 TFLOP/s dense for the conv16 / gemm16 families).  WORKLOAD=c5 profiles the server models in fp16, DTYPE=f16 the mobile ones.
 """
 import ctypes as C, os, sys
 os.environ.setdefault("RT_PROFILE_DETAIL", "1")
@@ -17,7 +18,8 @@ from retto_amd import workload
 pages_n = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 lines_n = int(sys.argv[3]) if len(sys.argv) > 3 else 32
-cfg = retto_amd.synthetic_session_config(0)
+F16 = os.environ.get("WORKLOAD", "c3") == "c5" or os.environ.get("DTYPE") == "f16"   # WORKLOAD=c5: server models, fp16
+cfg = retto_amd.synthetic_session_config(0, server=os.environ.get("WORKLOAD", "c3") == "c5", dtype="f16" if F16 else "f32")
 cfg.lanes = 1
 s = retto_amd.RettoSession(cfg)
 lib, h = s._hd.lib, s._hd.h
@@ -47,7 +49,11 @@ for name, (ms, calls) in s.profile_get().items():
     by = fl = 0.0
     if shape:
         a, b, c, d = (int(v) for v in shape.split(","))
-        if fam.startswith("dwconv"):
+        if fam.startswith("dwconv16"):
+            k = int(fam[-1]); by = (a + b) * c * 2.0; fl = 2.0 * b * c * k * k
+        elif fam.startswith("conv16") or fam.startswith("gemm16"):
+            fl = 2.0 * a * b * c          # fp16 family: the MFMA side is what binds; bytes depend on the window and are left out
+        elif fam.startswith("dwconv"):
             k = int(fam[-1]); by = (a + b) * c * 4.0; fl = 2.0 * b * c * k * k
         else:
             by = a * (b + c) * 4.0 if not fam.startswith("conv3x3") else a * (96 + 24) * 4.0
@@ -61,6 +67,6 @@ only = os.environ.get("ONLY")
 for r in rows:
     if only and only not in r[1]:
         continue
-    fh, fm = r[5] / 1e3 / 8.0, r[6] / 1e3 / 157.3
+    fh, fm = r[5] / 1e3 / 8.0, r[6] / 1e3 / (2500.0 if "16" in r[1] else 157.3)
     print("%8.3f %-34s %-28s %5d %9.3f %8.2f %8.1f %6.2f %s" % (r[0], r[1], r[2], r[3], r[4], r[5] / 1e3, r[6] / 1e3, max(fh, fm),
                                                               "" if not (r[5] or r[6]) else ("hbm" if fh >= fm else "mfma")))
