@@ -407,6 +407,7 @@ RT_API int rt_debug_conv16(rt_session* s, const float* x, int n, int cin, int h,
     nh::Epi16 e; e.bias = db; e.act = act;
     long long* d_st = nullptr;
     const bool stamps = getenv("RT_CONV_STAMPS") != nullptr;
+    if (stamps && !nh::conv_stamps_compiled()) fprintf(stderr, "RT_CONV_STAMPS: this library was built without the stamp code (make STAMPS=1): times only\n");
     if (stamps) { d_st = s->arena.alloc<long long>(4096); RT_HIP_CHECK(hipMemsetAsync(d_st, 0, 4096 * 8, s->st)); nh::g_conv_stamps = d_st; }
     hipEvent_t ev0, ev1;
     RT_HIP_CHECK(hipEventCreate(&ev0)); RT_HIP_CHECK(hipEventCreate(&ev1));

@@ -8,6 +8,15 @@
 namespace rt {
 namespace nh {
 
+// In-kernel time stamps (tools/conv16_stamps.py) exist only in a diagnostic build (make STAMPS=1): even behind a false
+// run-time flag an s_memtime in the stage loop is a pending scalar-memory event to hipcc's wait-count pass, which then
+// writes lgkmcnt(0) before every MFMA group and serialises the software-pipelined fragment reads.
+#ifdef RT_CONV_STAMPS_BUILD
+#define RT_STAMP_ON(expr) (expr)
+#else
+#define RT_STAMP_ON(expr) false
+#endif
+
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 typedef _Float16 h2 __attribute__((ext_vector_type(2)));
@@ -263,7 +272,7 @@ __global__ __launch_bounds__(64 * WN * WP, 2) void k_conv16(const ConvArgs a) {
     const int s = rr / a.KH, dy = rr - s * a.KH;
     const int cvalid = min(KS, a.Cin - s * KS);
     const int ksteps = (cvalid + 15) >> 4;
-    const bool stamp = a.stamps && blockIdx.y == 0 && blockIdx.x == gridDim.x / 2 && tid == 0;
+    const bool stamp = RT_STAMP_ON(a.stamps && blockIdx.y == 0 && blockIdx.x == gridDim.x / 2 && tid == 0);
     if (stamp) a.stamps[rr * 5 + 0] = __builtin_amdgcn_s_memtime();
     __syncthreads();  // every wave is done reading the previous weight row (and, at dy == 0, the previous halo)
     if (stamp) a.stamps[rr * 5 + 1] = __builtin_amdgcn_s_memtime();
@@ -374,8 +383,16 @@ __global__ __launch_bounds__(64 * WN * WP, 2) void k_conv16(const ConvArgs a) {
 //     16-byte chunk index with bits 2-3 of the row, applied to the per-lane SOURCE address and again on the fragment reads.
 // Same fragment maps, K order and epilogue as k_conv16: results are bit-identical.
 // ---------------------------------------------------------------------------------------------------------------------
-#define RT_GLDS16(gp, lp) \
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gp), (__attribute__((address_space(3))) void*)(lp), 16, 0, 0)
+// The LDS-DMA request is written as inline asm: with the builtin (__builtin_amdgcn_global_load_lds) in a loop hipcc's
+// wait-count pass treats the LDS counter as out of order and emits lgkmcnt(0) before every MFMA group -- which also waits
+// for the fragment reads just issued for the NEXT k-step (checked on a reduced kernel: counted lgkmcnt(5/4/1) without the
+// DMA or with this form, lgkmcnt(0) everywhere with the builtin).  M0 = wave-uniform LDS byte address; lane i writes
+// 16 bytes at M0 + 16 i.  The kernel counts vmcnt for these requests by hand (nothing else loads inside the loop).
+__device__ __forceinline__ void glds16(const void* g, void* l) {
+  const unsigned la = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char*)l);
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(la) : "memory", "m0");
+}
+#define RT_GLDS16(gp, lp) glds16((gp), (lp))
 
 struct ConvArgs2 {
   ConvArgs a;
@@ -385,11 +402,11 @@ struct ConvArgs2 {
 };
 constexpr int V2_HMAX = 6;   // DMA instructions per thread for one halo tile (6 * 512 * 16 B = 48 KB)
 
-template <int NTN>
+template <int NTN, int KW>
 __global__ __launch_bounds__(512, 1) void k_conv16v2(const ConvArgs2 c2) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem2[];
   const ConvArgs& a = c2.a;
-  const bool kstamp = a.stamps && blockIdx.y == 0 && blockIdx.x == gridDim.x / 2 && threadIdx.x == 0;
+  const bool kstamp = RT_STAMP_ON(a.stamps && blockIdx.y == 0 && blockIdx.x == gridDim.x / 2 && threadIdx.x == 0);
   if (kstamp) a.stamps[4000] = __builtin_amdgcn_s_memtime();
   constexpr int NTHR = 512, NTP = 2, BN = 32 * NTN, ROW = KS;  // LDS row = 32 halves (64 bytes), un-padded
   const int TH = a.TH, TW = a.TW;
@@ -400,10 +417,10 @@ __global__ __launch_bounds__(512, 1) void k_conv16v2(const ConvArgs2 c2) {
   const ImgGeom gi = a.gin[blockIdx.y];
   const int ty0 = (tile / tiles_x) * TH, tx0 = (tile % tiles_x) * TW;
   const int nb0 = zb * BN;
-  const int HH = (TH - 1) * a.SH + a.KH, HW = (TW - 1) * a.SW + a.KW;
+  const int HH = (TH - 1) * a.SH + a.KH, HW = (TW - 1) * a.SW + KW;
   half_t* hbuf = reinterpret_cast<half_t*>(smem2);
   half_t* wring = hbuf + (size_t)c2.hbufs * c2.hbuf_halves;
-  const int wbuf_halves = ((a.KW * BN * 4 + 511) & ~511) * 8;   // whole groups of 512 DMA slots
+  constexpr int wbuf_halves = ((KW * BN * 4 + 511) & ~511) * 8;   // whole groups of 512 DMA slots
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
 
@@ -430,7 +447,7 @@ __global__ __launch_bounds__(512, 1) void k_conv16v2(const ConvArgs2 c2) {
 
   const int iy0 = ty0 * a.SH - a.PT, ix0 = tx0 * a.SW - a.PL;
   const int nslab = (a.Cin + KS - 1) / KS, nrows = nslab * a.KH;
-  const int hchunks = HH * HW * 4, wchunks = a.KW * BN * 4;
+  const int hchunks = HH * HW * 4; constexpr int wchunks = KW * BN * 4;
   const half_t* xtile = a.x + gi.off * a.ldx + ((long long)iy0 * gi.W + ix0) * a.ldx;
   // per-thread DMA sources, computed once: slot e = tid + 512 * i of a buffer holds (row e >> 2, physical chunk e & 3),
   // i.e. the logical chunk (e & 3) ^ ((row >> 2) & 3) of that row
@@ -457,7 +474,7 @@ __global__ __launch_bounds__(512, 1) void k_conv16v2(const ConvArgs2 c2) {
       if (nb0 + n < a.Npad) wsrc[i] = (dx * a.Npad + nb0 + n) * KS + cl * 8;
     }
   }
-  const size_t row_halves = (size_t)a.KW * a.Npad * KS;
+  const size_t row_halves = (size_t)KW * a.Npad * KS;
   const int wave_slot = wid * 64 * 8;   // halves: this wave's 64 consecutive 16-byte slots inside a group of 512
   auto dma_halo = [&](int s) {          // slab s -> halo buffer s % hbufs
     half_t* dst = hbuf + (size_t)(s % c2.hbufs) * c2.hbuf_halves;
@@ -494,17 +511,21 @@ __global__ __launch_bounds__(512, 1) void k_conv16v2(const ConvArgs2 c2) {
     const int s = rr / a.KH, dy = rr - s * a.KH;
     const int cvalid = min(KS, a.Cin - s * KS);
     const int ksteps = (cvalid + 15) >> 4;
-    const bool stamp = a.stamps && blockIdx.y == 0 && blockIdx.x == gridDim.x / 2 && tid == 0;
+    const bool stamp = RT_STAMP_ON(a.stamps && blockIdx.y == 0 && blockIdx.x == gridDim.x / 2 && tid == 0);
     if (stamp) { a.stamps[rr * 5 + 0] = __builtin_amdgcn_s_memtime(); a.stamps[rr * 5 + 1] = a.stamps[rr * 5 + 0]; }
     // ---- multiply kernel row rr: the k-steps (dx, 16 channels) of the row in one software-pipelined sequence -- the
     // fragments of step i + 1 are requested from LDS before the MFMAs of step i are issued, so only the first read of a
     // stage is exposed; the DMA requests for later stages go out behind the first MFMA group ----
     const half_t* wl = wring + (size_t)(rr % 3) * wbuf_halves;
     const half_t* halo = hbuf + (size_t)(s % c2.hbufs) * c2.hbuf_halves;
-    const int nk = a.KW * ksteps;
+    // (a slab with fewer than 32 real channels still runs both 16-deep k-steps: its LDS rows and the packed weights are
+    // zero-filled, and a fixed step count keeps the sequence below straight-line code -- with the steps behind run-time
+    // tests hipcc waits lgkmcnt(0) before every MFMA group, which also waits for the prefetch just issued)
+    (void)ksteps;
+    constexpr int NK = KW * 2;
     const int tap0 = dy * HW;
     auto frags = [&](int it, h8 (&A)[NTN], h8 (&B)[NTP]) {
-      const int dx = ksteps == 2 ? it >> 1 : it, ks = it - dx * ksteps;
+      const int dx = it >> 1, ks = it & 1;
       const int cl = ks * 2 + h;
       const half_t* wrow = wl + (size_t)(dx * BN + r) * ROW + ((cl ^ aswz) << 3);
 #pragma unroll
@@ -521,22 +542,25 @@ __global__ __launch_bounds__(512, 1) void k_conv16v2(const ConvArgs2 c2) {
 #pragma unroll
         for (int j = 0; j < NTP; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[i], B[j], acc[i][j], 0, 0, 0);
     };
-    h8 A0[NTN], B0[NTP], A1[NTN], B1[NTP];
-    frags(0, A0, B0);
-    if (nk > 1) frags(1, A1, B1);
-    mfmas(A0, B0);
+    // (sched_barrier: hipcc otherwise sinks every fragment read down to its first use and waits lgkmcnt(0) there)
+    h8 Af[2][NTN], Bf[2][NTP];
+    frags(0, Af[0], Bf[0]);
+    frags(1, Af[1], Bf[1]);
+    __builtin_amdgcn_sched_barrier(0);
+    mfmas(Af[0], Bf[0]);
+    __builtin_amdgcn_sched_barrier(0);
     // ---- requests for later stages (the buffers they overwrite were last read before the barrier this wave just passed) ----
     if (rr + 2 < nrows) dma_wrow(rr + 2);
     bool halo_now = false;
     if (c2.hbufs == 2) { if (dy == 0 && s + 1 < nslab) { dma_halo(s + 1); halo_now = true; } }
     (void)halo_now;
-    if (nk > 2) frags(2, A0, B0);
-    if (nk > 1) mfmas(A1, B1);
-    for (int it = 2; it < nk; it += 2) {
-      if (it + 1 < nk) frags(it + 1, A1, B1);
-      mfmas(A0, B0);
-      if (it + 2 < nk) frags(it + 2, A0, B0);
-      if (it + 1 < nk) mfmas(A1, B1);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int it = 1; it < NK; it++) {
+      if (it + 1 < NK) frags(it + 1, Af[(it + 1) & 1], Bf[(it + 1) & 1]);
+      __builtin_amdgcn_sched_barrier(0);
+      mfmas(Af[it & 1], Bf[it & 1]);
+      __builtin_amdgcn_sched_barrier(0);
     }
     if (stamp) { a.stamps[rr * 5 + 2] = __builtin_amdgcn_s_memtime(); a.stamps[rr * 5 + 3] = a.stamps[rr * 5 + 2]; }
     if (rr + 1 == nrows) break;
@@ -597,6 +621,13 @@ static const half_t* zero_page16() {   // per device: DMA source of padding (one
 }
 
 long long* g_conv_stamps = nullptr;  // diagnostics: device buffer for stage time stamps (rt_debug_conv16 with RT_CONV_STAMPS)
+bool conv_stamps_compiled() {
+#ifdef RT_CONV_STAMPS_BUILD
+  return true;
+#else
+  return false;
+#endif
+}
 
 template <int NTN, int DOT>
 static void launch_conv16(hipStream_t st, const ConvArgs& a, dim3 grid, size_t lds) {
@@ -654,7 +685,7 @@ void conv16(hipStream_t st, const half_t* x, int ldx, const ImgGeom* gin, const 
   a.lp = round_up(std::min(Cin, KS), 16) + 8;  // whole 16-deep k-steps of real (zero-filled) data + one pad chunk
   const bool dot = epi.dot_w != nullptr;
   // ---- LDS-DMA kernel for the 3x3-class layers ----
-  if (g_conv16_v2 && !dot && KH <= 3 && KW <= 3 && KH * KW > 1 && Cin >= 32 && n_img <= RT_MAX_GRID_Y) {
+  if (g_conv16_v2 && !dot && KH <= 3 && (KW == 1 || KW == 3) && KH * KW > 1 && Cin >= 32 && n_img <= RT_MAX_GRID_Y) {
     int bn2 = 32, best = 1 << 30;
     for (int bn : {128, 96, 64, 32}) {
       const int nb = (Npad + bn - 1) / bn, cost = nb * bn + 16 * nb;
@@ -678,18 +709,21 @@ void conv16(hipStream_t st, const half_t* x, int ldx, const ImgGeom* gin, const 
       dim3 grid2((unsigned)(tiles2 * c2.a.nzb), (unsigned)n_img);
       static bool attr2 = false;
       if (!attr2) {
-        RT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv16v2<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        RT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv16v2<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        RT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv16v2<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        RT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv16v2<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        for (const void* f : {(const void*)k_conv16v2<1, 1>, (const void*)k_conv16v2<2, 1>, (const void*)k_conv16v2<3, 1>, (const void*)k_conv16v2<4, 1>,
+                              (const void*)k_conv16v2<1, 3>, (const void*)k_conv16v2<2, 3>, (const void*)k_conv16v2<3, 3>, (const void*)k_conv16v2<4, 3>})
+          RT_HIP_CHECK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr2 = true;
       }
+#define RT_V2_LAUNCH(NT) \
+      switch (KW) { case 1: RT_LAUNCH((k_conv16v2<NT, 1>), grid2, dim3(512), lds2, st, c2); break; \
+                    default: RT_LAUNCH((k_conv16v2<NT, 3>), grid2, dim3(512), lds2, st, c2); break; }
       switch (bn2 / 32) {
-        case 1: RT_LAUNCH(k_conv16v2<1>, grid2, dim3(512), lds2, st, c2); break;
-        case 2: RT_LAUNCH(k_conv16v2<2>, grid2, dim3(512), lds2, st, c2); break;
-        case 3: RT_LAUNCH(k_conv16v2<3>, grid2, dim3(512), lds2, st, c2); break;
-        default: RT_LAUNCH(k_conv16v2<4>, grid2, dim3(512), lds2, st, c2); break;
+        case 1: RT_V2_LAUNCH(1); break;
+        case 2: RT_V2_LAUNCH(2); break;
+        case 3: RT_V2_LAUNCH(3); break;
+        default: RT_V2_LAUNCH(4); break;
       }
+#undef RT_V2_LAUNCH
       return;
     }
   }
