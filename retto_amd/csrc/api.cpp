@@ -402,8 +402,10 @@ RT_API int rt_debug_conv16(rt_session* s, const float* x, int n, int cin, int h,
     RT_HIP_CHECK(hipMemcpyAsync(dw, hw.data(), hw.size() * 2, hipMemcpyHostToDevice, s->st));
     RT_HIP_CHECK(hipMemcpyAsync(db, hb.data(), hb.size() * 4, hipMemcpyHostToDevice, s->st));
     Level Li = make_level(std::vector<std::pair<int, int>>((size_t)n, {h, w})), Lo = make_level(std::vector<std::pair<int, int>>((size_t)n, {ho, wo}));
+    const bool flat = kh == 1 && kw == 1 && sh == 1 && sw == 1;   // as the networks run their 1x1 layers: one GEMM over all pixels
+    Level Lf = flat ? flat_level(Li) : Level();
     RunCtx c = s->ctx(&s->arena);
-    upload_levels(c, {&Li, &Lo});
+    if (flat) upload_levels(c, {&Li, &Lo, &Lf}); else upload_levels(c, {&Li, &Lo});
     nh::Epi16 e; e.bias = db; e.act = act;
     long long* d_st = nullptr;
     const bool stamps = getenv("RT_CONV_STAMPS") != nullptr;
@@ -414,7 +416,8 @@ RT_API int rt_debug_conv16(rt_session* s, const float* x, int n, int cin, int h,
     const int reps = stamps ? 5 : 1;
     for (int rep = 0; rep < reps; rep++) {
       if (rep == reps - 1) RT_HIP_CHECK(hipEventRecord(ev0, s->st));
-      nh::conv16(s->st, dx, cp, Li.d, Lo.d, n, Lo.maxH, Lo.maxW, cp, kh, kw, sh, sw, kh / 2, kw / 2, dw, cout, npad, dy, op, 0, e);
+      if (flat) nh::conv16(s->st, dx, cp, Lf.d, Lf.d, 1, 1, Lf.maxW, cp, 1, 1, 1, 1, 0, 0, dw, cout, npad, dy, op, 0, e);
+      else nh::conv16(s->st, dx, cp, Li.d, Lo.d, n, Lo.maxH, Lo.maxW, cp, kh, kw, sh, sw, kh / 2, kw / 2, dw, cout, npad, dy, op, 0, e);
     }
     RT_HIP_CHECK(hipEventRecord(ev1, s->st));
     std::vector<half_t> hy((size_t)n * ho * wo * op);

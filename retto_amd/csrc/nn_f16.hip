@@ -1,177 +1,12 @@
 // fp16-storage / fp32-accumulate kernels for gfx950 (see nn_f16.h).  Written for CDNA4 only:
 // v_mfma_f32_32x32x16_f16, 64-wide waves, ds_read_b128 fragment reads from padded LDS rows.
-#include "nn_f16.h"
+#include "nn_f16_dev.h"
 
 #include <algorithm>
 #include <cmath>
 
 namespace rt {
 namespace nh {
-
-// In-kernel time stamps (tools/conv16_stamps.py) exist only in a diagnostic build (make STAMPS=1): even behind a false
-// run-time flag an s_memtime in the stage loop is a pending scalar-memory event to hipcc's wait-count pass, which then
-// writes lgkmcnt(0) before every MFMA group and serialises the software-pipelined fragment reads.
-#ifdef RT_CONV_STAMPS_BUILD
-#define RT_STAMP_ON(expr) (expr)
-#else
-#define RT_STAMP_ON(expr) false
-#endif
-
-typedef _Float16 h8 __attribute__((ext_vector_type(8)));
-typedef _Float16 h4 __attribute__((ext_vector_type(4)));
-typedef _Float16 h2 __attribute__((ext_vector_type(2)));
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-__device__ __forceinline__ float act_f(float v, int act) {
-  switch (act) {
-    case ACT_RELU: return fmaxf(v, 0.f);
-    case ACT_HSWISH: return v * fminf(fmaxf(v + 3.f, 0.f), 6.f) * (1.f / 6.f);
-    case ACT_SWISH: return v / (1.f + __expf(-v));
-    case ACT_SIGMOID: return 1.f / (1.f + __expf(-v));
-    default: return v;
-  }
-}
-
-// ---------------------------------------------------------------------------------------------------------------------
-// Dense convolution as implicit GEMM on v_mfma_f32_32x32x16_f16.
-//
-//   D[n][pixel] += W[n][k] . X[k][pixel]      A operand = weights (rows = output channels), B operand = activations
-//
-// so that a lane ends up with 16 output channels of ONE pixel (4 groups of 4 consecutive channels -> 8-byte stores into the
-// NHWC result).  A workgroup owns a TH x TW pixel tile (TH * TW <= BP = 32 * NTP * WP) of one image and BN = 32 * NTN * WN
-// output channels; its waves are WN x WP, each 32 * NTN channels x 32 * NTP pixels.  K runs over 32-channel slabs of the
-// input and, inside a slab, over the kernel rows:
-//   * the (TH-1)*SH+KH x (TW-1)*SW+KW halo tile of the slab is staged once in LDS ([pixel][32 + 8 halves]: 80-byte rows make
-//     the 16-byte fragment reads of 16 consecutive pixels conflict-free) and shared by all KH * KW taps;
-//   * the weights of one kernel row (KW taps x BN channels x 32) are staged per row, the next row prefetched into registers
-//     while the MFMAs of the current one run;
-//   * per tap and 16-deep k-step a wave reads NTN + NTP fragments for NTN * NTP MFMAs.
-// Pixel tiles are TH x TW with run-time TW (not a power of two: the 3 / 6 / 12 / 24-row maps of the recognition net take
-// full-height tiles), a 1x1 conv over a whole batch runs as one "image" of 1 x M pixels.
-// ---------------------------------------------------------------------------------------------------------------------
-struct ConvArgs {
-  const half_t* x; int ldx;
-  const ImgGeom* gin; const ImgGeom* gout;
-  int Cin, KH, KW, SH, SW, PT, PL;
-  const half_t* w; int N, Npad;
-  half_t* y; int ldy, coff;
-  int TH, TW, nzb;   // pixel tile, number of channel blocks (fastest block coordinate: neighbours share the input in L2)
-  int lp;            // LDS row pitch in halves: min(Cin, 32) rounded up to 16, + 8
-  long long* stamps; // diagnostics (RT_CONV_STAMPS): s_memtime of wave 0 at 5 points of every stage of one workgroup, or null
-  Epi16 epi;
-};
-
-// Epilogue of both conv kernels: bias / activation / LAB / residual on the accumulators, fp16 NHWC store.
-// After the MFMAs a lane holds 16 channels of ONE pixel in four runs of 4: storing them directly is 8-byte pieces at a pixel
-// pitch (every wave-store touches 64 different cache lines; measured 40 k cycles for a 512 x 128 tile, as long as the 12
-// MFMA stages of a 3x3 128->128 layer).  So each wave transposes its 32-pixel fragments through a private LDS scratch
-// ([pixel][BN + 8] halves) and stores 16 bytes per lane with consecutive lanes on consecutive channels of one pixel: whole
-// 64 ... 256-byte channel runs per pixel.  Taken when the output pitch and channel offset are multiples of 8 and there is
-// no residual (the residual form adds in fp32 before the one rounding, per lane, as before); same values either way.
-// scratch: wave-private, 32 * (BN + 8) halves + 32 long long; the caller has synchronised the workgroup after its last
-// main-loop LDS read.
-template <int NTN>
-__device__ __forceinline__ size_t epi_scratch_halves() { return (size_t)32 * (32 * NTN + 8) + 128; }
-
-template <int ACT>
-__device__ __forceinline__ float act_c(float v) {   // activation known at compile time: no per-element branch
-  if (ACT == ACT_RELU) return fmaxf(v, 0.f);
-  if (ACT == ACT_HSWISH) return v * fminf(fmaxf(v + 3.f, 0.f), 6.f) * (1.f / 6.f);
-  if (ACT == ACT_SWISH) return v / (1.f + __expf(-v));
-  if (ACT == ACT_SIGMOID) return 1.f / (1.f + __expf(-v));
-  return v;
-}
-
-// ACT: the activation; EDGE: this channel block holds the last real output channel (values beyond N are forced to zero);
-// WIDE: LDS-transposed 16-byte stores (no residual, pitches multiples of 8), else 8-byte stores per lane with the residual.
-// All three are workgroup-uniform and resolved ONCE (store_tile16 below): with run-time tests inside the 16 * NTN * NTP
-// element loops the compiler emitted ~1300 scalar branches and the epilogue of a 512 x 128 tile ran 40 k cycles.
-template <int NTN, int NTP, int ACT, bool EDGE, bool WIDE>
-__device__ __forceinline__ void store_tile16_t(const ConvArgs& a, const f32x16 (&acc)[NTN][NTP], half_t* scratch, int lane, int nb0,
-                                               const int (&oys)[NTP], const int (&oxs)[NTP], const ImgGeom& go) {
-  constexpr int BN = 32 * NTN, PITCH = BN + 8, CPP = 4 * NTN;   // 16-byte chunks per pixel
-  const Epi16& e = a.epi;
-  const int r = lane & 31, h = lane >> 5;
-  const int nstore = (a.N + 7) & ~7;  // the channel pitch is a multiple of 8: the pad channels are written too (zeros), consumers read them
-  const float lab_a = e.has_lab ? e.lab_a : 1.f, lab_c = e.has_lab ? e.lab_c : 0.f;
-  const bool has_lab = e.has_lab != 0;
-  long long* ptab = reinterpret_cast<long long*>(scratch + 32 * PITCH);
-  const bool has_bias = e.bias != nullptr;
-#pragma unroll
-  for (int j = 0; j < NTP; j++) {
-    const int oy = oys[j], ox = oxs[j];
-    const bool okp = oy >= 0 && oy < go.H && ox < go.W;
-    const long long pixo = go.off + (long long)oy * go.W + ox;
-    if (!WIDE && !okp) continue;
-#pragma unroll
-    for (int i = 0; i < NTN; i++)
-#pragma unroll
-      for (int g = 0; g < 4; g++) {
-        const int nl = i * 32 + 8 * g + 4 * h, n = nb0 + nl;
-        if (!WIDE && EDGE && n >= nstore) continue;
-        f32x4 v;
-#pragma unroll
-        for (int t = 0; t < 4; t++) v[t] = acc[i][j][4 * g + t];
-        if (has_bias && (!EDGE || n < a.Npad)) v += *reinterpret_cast<const f32x4*>(e.bias + n);
-#pragma unroll
-        for (int t = 0; t < 4; t++) v[t] = act_c<ACT>(v[t]);
-        if (has_lab) {   // (uniform; LAB follows an activation in the PPLCNet blocks only)
-#pragma unroll
-          for (int t = 0; t < 4; t++) v[t] = fmaf(v[t], lab_a, lab_c);
-        }
-        if (!WIDE && e.residual) {
-          h4 rs = *reinterpret_cast<const h4*>(e.residual + pixo * e.ld_res + n);
-#pragma unroll
-          for (int t = 0; t < 4; t++) v[t] += (float)rs[t];
-        }
-        h4 o;
-#pragma unroll
-        for (int t = 0; t < 4; t++) o[t] = (!EDGE || n + t < a.N) ? (half_t)v[t] : (half_t)0.f;
-        if (WIDE) *reinterpret_cast<h4*>(scratch + r * PITCH + nl) = o;
-        else *reinterpret_cast<h4*>(a.y + pixo * a.ldy + a.coff + n) = o;
-      }
-    if (!WIDE) continue;
-    if (h == 0) ptab[r] = okp ? pixo : -1;
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the wave's own LDS writes are complete (in order) and visible to its lanes
-#pragma unroll
-    for (int k = 0; k < 2 * NTN; k++) {
-      const int idx = lane + 64 * k, pp = idx / CPP, ch = idx - pp * CPP;
-      const long long po = ptab[pp];
-      const int n = nb0 + ch * 8;
-      if (po >= 0 && (!EDGE || n < nstore)) {
-        const h8 v = *reinterpret_cast<const h8*>(scratch + pp * PITCH + ch * 8);
-        *reinterpret_cast<h8*>(a.y + po * a.ldy + a.coff + n) = v;
-      }
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // reads returned before the next fragment overwrites the scratch
-  }
-}
-
-template <int NTN, int NTP, int ACT>
-__device__ __forceinline__ void store_tile16_a(const ConvArgs& a, const f32x16 (&acc)[NTN][NTP], half_t* scratch, int lane, int nb0,
-                                               const int (&oys)[NTP], const int (&oxs)[NTP], const ImgGeom& go) {
-  const bool wide = !a.epi.residual && !((a.ldy | a.coff) & 7);
-  const bool edge = nb0 + 32 * NTN > a.N;
-  if (wide) {
-    if (edge) store_tile16_t<NTN, NTP, ACT, true, true>(a, acc, scratch, lane, nb0, oys, oxs, go);
-    else store_tile16_t<NTN, NTP, ACT, false, true>(a, acc, scratch, lane, nb0, oys, oxs, go);
-  } else {
-    store_tile16_t<NTN, NTP, ACT, true, false>(a, acc, scratch, lane, nb0, oys, oxs, go);
-  }
-}
-
-template <int NTN, int NTP>
-__device__ __forceinline__ void store_tile16(const ConvArgs& a, const f32x16 (&acc)[NTN][NTP], half_t* scratch, int lane, int nb0,
-                                             const int (&oys)[NTP], const int (&oxs)[NTP], const ImgGeom& go) {
-  switch (a.epi.act) {
-    case ACT_RELU: store_tile16_a<NTN, NTP, ACT_RELU>(a, acc, scratch, lane, nb0, oys, oxs, go); break;
-    case ACT_HSWISH: store_tile16_a<NTN, NTP, ACT_HSWISH>(a, acc, scratch, lane, nb0, oys, oxs, go); break;
-    case ACT_SWISH: store_tile16_a<NTN, NTP, ACT_SWISH>(a, acc, scratch, lane, nb0, oys, oxs, go); break;
-    case ACT_SIGMOID: store_tile16_a<NTN, NTP, ACT_SIGMOID>(a, acc, scratch, lane, nb0, oys, oxs, go); break;
-    default: store_tile16_a<NTN, NTP, ACT_NONE>(a, acc, scratch, lane, nb0, oys, oxs, go); break;
-  }
-}
 
 constexpr int WPRE = 8;  // 16-byte chunks of the next weight row a thread can hold in registers
 
@@ -370,255 +205,8 @@ __global__ __launch_bounds__(64 * WN * WP, 2) void k_conv16(const ConvArgs a) {
   store_tile16<NTN, NTP>(a, acc, reinterpret_cast<half_t*>(smem) + (size_t)wid * epi_scratch_halves<NTN * WN>(), lane, nb0, oys, oxs, go);
 }
 
-// ---------------------------------------------------------------------------------------------------------------------
-// k_conv16v2: the same implicit GEMM for the 3x3 / 1x3 / 3x1 layers that dominate the server graphs, staged by LDS-DMA.
-// The first form stages through registers and needs its VGPRs for the accumulators, so it can only prefetch one kernel row
-// of weights and nothing of the halo: the in-kernel stamps show 2300 (row) to 5800 (row + halo) cycles of exposed L2 / HBM
-// latency per 3500-cycle MFMA phase.  Here both operands go global -> LDS by global_load_lds (no VGPR staging):
-//   * 8 waves on a 512-pixel tile x 32 * NTN channels (weights are re-read per 512 instead of 256 pixels);
-//   * weights: a ring of 3 kernel-row buffers -- row r + 2 is requested while row r is multiplied (two MFMA phases of
-//     latency cover); halo: two buffers, the next slab's tile is requested at the first row of the current slab;
-//   * one raw s_barrier per row, counted s_waitcnt vmcnt (hipcc's __syncthreads would drain the DMA queue);
-//   * LDS rows are un-padded 64-byte slabs (the DMA writes lane-linear), conflicts are avoided by an XOR swizzle of the
-//     16-byte chunk index with bits 2-3 of the row, applied to the per-lane SOURCE address and again on the fragment reads.
-// Same fragment maps, K order and epilogue as k_conv16: results are bit-identical.
-// ---------------------------------------------------------------------------------------------------------------------
-// The LDS-DMA request is written as inline asm: with the builtin (__builtin_amdgcn_global_load_lds) in a loop hipcc's
-// wait-count pass treats the LDS counter as out of order and emits lgkmcnt(0) before every MFMA group -- which also waits
-// for the fragment reads just issued for the NEXT k-step (checked on a reduced kernel: counted lgkmcnt(5/4/1) without the
-// DMA or with this form, lgkmcnt(0) everywhere with the builtin).  M0 = wave-uniform LDS byte address; lane i writes
-// 16 bytes at M0 + 16 i.  The kernel counts vmcnt for these requests by hand (nothing else loads inside the loop).
-__device__ __forceinline__ void glds16(const void* g, void* l) {
-  const unsigned la = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char*)l);
-  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(la) : "memory", "m0");
-}
-#define RT_GLDS16(gp, lp) glds16((gp), (lp))
 
-struct ConvArgs2 {
-  ConvArgs a;
-  const half_t* zeros;   // >= 16 zero bytes in device memory: DMA source of padding pixels / channels
-  int hbuf_halves;       // size of one halo buffer (halves, multiple of 8)
-  int hbufs;             // 2: next slab's halo prefetched; 1: single buffer (large halos)
-};
-constexpr int V2_HMAX = 6;   // DMA instructions per thread for one halo tile (6 * 512 * 16 B = 48 KB)
-
-template <int NTN, int KW>
-__global__ __launch_bounds__(512, 1) void k_conv16v2(const ConvArgs2 c2) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem2[];
-  const ConvArgs& a = c2.a;
-  const bool kstamp = RT_STAMP_ON(a.stamps && blockIdx.y == 0 && blockIdx.x == gridDim.x / 2 && threadIdx.x == 0);
-  if (kstamp) a.stamps[4000] = __builtin_amdgcn_s_memtime();
-  constexpr int NTHR = 512, NTP = 2, BN = 32 * NTN, ROW = KS;  // LDS row = 32 halves (64 bytes), un-padded
-  const int TH = a.TH, TW = a.TW;
-  const ImgGeom go = a.gout[blockIdx.y];
-  const int tiles_x = (go.W + TW - 1) / TW, tiles_y = (go.H + TH - 1) / TH;
-  const int zb = blockIdx.x % a.nzb, tile = blockIdx.x / a.nzb;
-  if (tile >= tiles_x * tiles_y) return;
-  const ImgGeom gi = a.gin[blockIdx.y];
-  const int ty0 = (tile / tiles_x) * TH, tx0 = (tile % tiles_x) * TW;
-  const int nb0 = zb * BN;
-  const int HH = (TH - 1) * a.SH + a.KH, HW = (TW - 1) * a.SW + KW;
-  half_t* hbuf = reinterpret_cast<half_t*>(smem2);
-  half_t* wring = hbuf + (size_t)c2.hbufs * c2.hbuf_halves;
-  constexpr int wbuf_halves = ((KW * BN * 4 + 511) & ~511) * 8;   // whole groups of 512 DMA slots
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int r = lane & 31, h = lane >> 5;
-
-  int pix[NTP], oys[NTP], oxs[NTP];
-#pragma unroll
-  for (int j = 0; j < NTP; j++) {
-    int q = (wid * NTP + j) * 32 + r;
-    int ty = q / TW, tx = q - ty * TW;
-    const bool ok = ty < TH;
-    if (!ok) { ty = 0; tx = 0; }
-    pix[j] = ty * a.SH * HW + tx * a.SW;   // halo pixel of tap (0, 0)
-    oys[j] = ok ? ty0 + ty : -1;
-    oxs[j] = tx0 + tx;
-  }
-  const int aswz = (r >> 2) & 3;            // rows of the weight tile: (row >> 2) & 3 == (r >> 2) & 3 (BN, 32 multiples of 16)
-
-  f32x16 acc[NTN][NTP];
-#pragma unroll
-  for (int i = 0; i < NTN; i++)
-#pragma unroll
-    for (int j = 0; j < NTP; j++)
-#pragma unroll
-      for (int e = 0; e < 16; e++) acc[i][j][e] = 0.f;
-
-  const int iy0 = ty0 * a.SH - a.PT, ix0 = tx0 * a.SW - a.PL;
-  const int nslab = (a.Cin + KS - 1) / KS, nrows = nslab * a.KH;
-  const int hchunks = HH * HW * 4; constexpr int wchunks = KW * BN * 4;
-  const half_t* xtile = a.x + gi.off * a.ldx + ((long long)iy0 * gi.W + ix0) * a.ldx;
-  // per-thread DMA sources, computed once: slot e = tid + 512 * i of a buffer holds (row e >> 2, physical chunk e & 3),
-  // i.e. the logical chunk (e & 3) ^ ((row >> 2) & 3) of that row
-  int hsrc[V2_HMAX];
-#pragma unroll
-  for (int i = 0; i < V2_HMAX; i++) {
-    const int e = tid + i * NTHR;
-    hsrc[i] = -1;
-    if (e < hchunks) {
-      const int p = e >> 2, cl = (e & 3) ^ ((p >> 2) & 3);
-      const int hy = p / HW, hx = p - hy * HW;
-      const int iy = iy0 + hy, ix = ix0 + hx;
-      if (iy >= 0 && iy < gi.H && ix >= 0 && ix < gi.W) hsrc[i] = ((hy * gi.W + hx) * a.ldx + cl * 8) | (cl << 28);
-    }
-  }
-  int wsrc[3];   // a kernel row: KW * BN * 4 <= 3 * 128 * 4 = 1536 chunks = 3 per thread
-#pragma unroll
-  for (int i = 0; i < 3; i++) {
-    const int e = tid + i * NTHR;
-    wsrc[i] = -1;
-    if (e < wchunks) {
-      const int row = e >> 2, cl = (e & 3) ^ ((row >> 2) & 3);
-      const int dx = row / BN, n = row - dx * BN;
-      if (nb0 + n < a.Npad) wsrc[i] = (dx * a.Npad + nb0 + n) * KS + cl * 8;
-    }
-  }
-  const size_t row_halves = (size_t)KW * a.Npad * KS;
-  const int wave_slot = wid * 64 * 8;   // halves: this wave's 64 consecutive 16-byte slots inside a group of 512
-  auto dma_halo = [&](int s) {          // slab s -> halo buffer s % hbufs
-    half_t* dst = hbuf + (size_t)(s % c2.hbufs) * c2.hbuf_halves;
-    const int cvalid = min(KS, a.Cin - s * KS);
-#pragma unroll
-    for (int i = 0; i < V2_HMAX; i++) {
-      if (i * NTHR >= hchunks) break;   // (uniform)
-      const bool ok = hsrc[i] >= 0 && (hsrc[i] >> 28) * 8 < cvalid;
-      const half_t* src = ok ? xtile + (hsrc[i] & 0x0fffffff) + s * KS : c2.zeros;
-      RT_GLDS16(src, dst + (size_t)i * NTHR * 8 + wave_slot);
-    }
-  };
-  auto dma_wrow = [&](int rr) {         // kernel row rr -> ring slot rr % 3
-    half_t* dst = wring + (size_t)(rr % 3) * wbuf_halves;
-    const half_t* wg = a.w + (size_t)rr * row_halves;
-#pragma unroll
-    for (int i = 0; i < 3; i++) {
-      if (i * NTHR >= wchunks) break;   // (uniform)
-      const half_t* src = wsrc[i] >= 0 ? wg + wsrc[i] : c2.zeros;
-      RT_GLDS16(src, dst + (size_t)i * NTHR * 8 + wave_slot);
-    }
-  };
-  // prologue: halo 0, rows 0 and 1 (and halo 1 with two buffers) in flight; wait for everything once
-  dma_halo(0);
-  dma_wrow(0);
-  if (nrows > 1) dma_wrow(1);
-  if (kstamp) a.stamps[4001] = __builtin_amdgcn_s_memtime();
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  if (kstamp) a.stamps[4002] = __builtin_amdgcn_s_memtime();
-  const int nw = (wchunks + NTHR - 1) / NTHR, nh = (hchunks + NTHR - 1) / NTHR;   // DMA instructions per row / per halo, per thread
-
-  for (int rr = 0; rr < nrows; rr++) {
-    const int s = rr / a.KH, dy = rr - s * a.KH;
-    const int cvalid = min(KS, a.Cin - s * KS);
-    const int ksteps = (cvalid + 15) >> 4;
-    const bool stamp = RT_STAMP_ON(a.stamps && blockIdx.y == 0 && blockIdx.x == gridDim.x / 2 && tid == 0);
-    if (stamp) { a.stamps[rr * 5 + 0] = __builtin_amdgcn_s_memtime(); a.stamps[rr * 5 + 1] = a.stamps[rr * 5 + 0]; }
-    // ---- multiply kernel row rr: the k-steps (dx, 16 channels) of the row in one software-pipelined sequence -- the
-    // fragments of step i + 1 are requested from LDS before the MFMAs of step i are issued, so only the first read of a
-    // stage is exposed; the DMA requests for later stages go out behind the first MFMA group ----
-    const half_t* wl = wring + (size_t)(rr % 3) * wbuf_halves;
-    const half_t* halo = hbuf + (size_t)(s % c2.hbufs) * c2.hbuf_halves;
-    // (a slab with fewer than 32 real channels still runs both 16-deep k-steps: its LDS rows and the packed weights are
-    // zero-filled, and a fixed step count keeps the sequence below straight-line code -- with the steps behind run-time
-    // tests hipcc waits lgkmcnt(0) before every MFMA group, which also waits for the prefetch just issued)
-    (void)ksteps;
-    constexpr int NK = KW * 2;
-    const int tap0 = dy * HW;
-    auto frags = [&](int it, h8 (&A)[NTN], h8 (&B)[NTP]) {
-      const int dx = it >> 1, ks = it & 1;
-      const int cl = ks * 2 + h;
-      const half_t* wrow = wl + (size_t)(dx * BN + r) * ROW + ((cl ^ aswz) << 3);
-#pragma unroll
-      for (int i = 0; i < NTN; i++) A[i] = *reinterpret_cast<const h8*>(wrow + i * 32 * ROW);
-#pragma unroll
-      for (int j = 0; j < NTP; j++) {
-        const int p = pix[j] + tap0 + dx;
-        B[j] = *reinterpret_cast<const h8*>(halo + p * ROW + ((cl ^ ((p >> 2) & 3)) << 3));
-      }
-    };
-    auto mfmas = [&](const h8 (&A)[NTN], const h8 (&B)[NTP]) {
-#pragma unroll
-      for (int i = 0; i < NTN; i++)
-#pragma unroll
-        for (int j = 0; j < NTP; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[i], B[j], acc[i][j], 0, 0, 0);
-    };
-    // (sched_barrier: hipcc otherwise sinks every fragment read down to its first use and waits lgkmcnt(0) there)
-    h8 Af[2][NTN], Bf[2][NTP];
-    frags(0, Af[0], Bf[0]);
-    frags(1, Af[1], Bf[1]);
-    __builtin_amdgcn_sched_barrier(0);
-    mfmas(Af[0], Bf[0]);
-    __builtin_amdgcn_sched_barrier(0);
-    // ---- requests for later stages (the buffers they overwrite were last read before the barrier this wave just passed) ----
-    if (rr + 2 < nrows) dma_wrow(rr + 2);
-    bool halo_now = false;
-    if (c2.hbufs == 2) { if (dy == 0 && s + 1 < nslab) { dma_halo(s + 1); halo_now = true; } }
-    (void)halo_now;
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int it = 1; it < NK; it++) {
-      if (it + 1 < NK) frags(it + 1, Af[(it + 1) & 1], Bf[(it + 1) & 1]);
-      __builtin_amdgcn_sched_barrier(0);
-      mfmas(Af[it & 1], Bf[it & 1]);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    if (stamp) { a.stamps[rr * 5 + 2] = __builtin_amdgcn_s_memtime(); a.stamps[rr * 5 + 3] = a.stamps[rr * 5 + 2]; }
-    if (rr + 1 == nrows) break;
-    // ---- the next row's data must have landed: everything except the requests made in THIS iteration ----
-    const int ns = (rr + 1) / a.KH, ndy = (rr + 1) - ns * a.KH;
-    if (c2.hbufs == 1 && ndy == 0) {
-      // single halo buffer: every wave is done with the old tile only after the barrier; request and wait here (exposed)
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      dma_halo(ns);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      continue;
-    }
-    // outstanding and allowed to stay in flight: row rr + 2 (nw instructions, if requested); the halo requested in this
-    // iteration is only needed KH rows later, but it was issued AFTER row rr + 2, so it may stay in flight as well
-    // (with one-row kernels the halo requested in this iteration is needed by the very next row: nothing may stay in flight)
-    const int keep = (halo_now && ndy == 0) ? 0 : (rr + 2 < nrows ? nw : 0) + (halo_now ? nh : 0);
-    // (a halo requested in an earlier iteration of this slab is older than row rr + 1's weights and therefore retired with them)
-    switch (keep) {
-      case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-      case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
-      case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
-      case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
-      case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
-      case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
-      case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
-      case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
-      case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
-      default: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
-    }
-    if (stamp) a.stamps[rr * 5 + 3] = __builtin_amdgcn_s_memtime();
-    __builtin_amdgcn_s_barrier();
-    if (stamp) a.stamps[rr * 5 + 4] = __builtin_amdgcn_s_memtime();
-  }
-
-  if (kstamp) a.stamps[4003] = __builtin_amdgcn_s_memtime();
-  __builtin_amdgcn_s_barrier();   // every wave is done with the last stage's LDS (no DMA is in flight any more)
-  if (kstamp) a.stamps[4005] = __builtin_amdgcn_s_memtime();
-  store_tile16<NTN, NTP>(a, acc, reinterpret_cast<half_t*>(smem2) + (size_t)wid * epi_scratch_halves<NTN>(), lane, nb0, oys, oxs, go);
-  if (kstamp) a.stamps[4006] = __builtin_amdgcn_s_memtime();
-  if (kstamp) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); a.stamps[4004] = __builtin_amdgcn_s_memtime(); }
-}
-
-int g_conv16_v2 = 1;   // 1 = LDS-DMA kernel for the 3x3-class layers (default); 0 = register-staged k_conv16 everywhere (A/B)
-static const half_t* zero_page16() {   // per device: DMA source of padding (one allocation per process and device)
-  static const half_t* z[16] = {nullptr};
-  int dev = 0;
-  RT_HIP_CHECK(hipGetDevice(&dev));
-  if (dev < 0 || dev >= 16) throw RtError(8, "conv16: device index out of range");
-  if (!z[dev]) {
-    void* p = nullptr;
-    RT_HIP_CHECK(hipMalloc(&p, 256));
-    RT_HIP_CHECK(hipMemset(p, 0, 256));
-    z[dev] = (const half_t*)p;
-  }
-  return z[dev];
-}
+int g_conv16_v2 = 1;   // 1 = LDS-DMA kernels where they apply (default); 0 = register-staged k_conv16 everywhere (A/B)
 
 long long* g_conv_stamps = nullptr;  // diagnostics: device buffer for stage time stamps (rt_debug_conv16 with RT_CONV_STAMPS)
 bool conv_stamps_compiled() {
@@ -684,49 +272,8 @@ void conv16(hipStream_t st, const half_t* x, int ldx, const ImgGeom* gin, const 
   a.stamps = g_conv_stamps;
   a.lp = round_up(std::min(Cin, KS), 16) + 8;  // whole 16-deep k-steps of real (zero-filled) data + one pad chunk
   const bool dot = epi.dot_w != nullptr;
-  // ---- LDS-DMA kernel for the 3x3-class layers ----
-  if (g_conv16_v2 && !dot && KH <= 3 && (KW == 1 || KW == 3) && KH * KW > 1 && Cin >= 32 && n_img <= RT_MAX_GRID_Y) {
-    int bn2 = 32, best = 1 << 30;
-    for (int bn : {128, 96, 64, 32}) {
-      const int nb = (Npad + bn - 1) / bn, cost = nb * bn + 16 * nb;
-      if (cost < best) { best = cost; bn2 = bn; }
-    }
-    // 512-pixel tile: full-height tiles on short maps; the halo tile must fit V2_HMAX DMA instructions per thread
-    int th, tw;
-    if (maxHo >= 16) { const int ny = (maxHo + 15) / 16; th = maxHo >= 64 ? 16 : (maxHo + ny - 1) / ny; } else th = std::max(maxHo, 1);
-    tw = std::max(1, std::min(512 / th, maxWo));
-    auto hpix = [&](int t_h, int t_w) { return ((t_h - 1) * SH + KH) * ((t_w - 1) * SW + KW); };
-    while (hpix(th, tw) * 4 > V2_HMAX * 512 && tw > 8) tw--;
-    if (hpix(th, tw) * 4 <= V2_HMAX * 512) {
-      ConvArgs2 c2;
-      c2.a = a; c2.a.TH = th; c2.a.TW = tw; c2.a.lp = KS; c2.a.nzb = (Npad + bn2 - 1) / bn2;
-      c2.zeros = zero_page16();
-      c2.hbuf_halves = ((hpix(th, tw) * 4 + 511) & ~511) * 8;
-      const size_t wbytes = (size_t)((KW * bn2 * 4 + 511) & ~511) * 16 * 3;
-      c2.hbufs = (2 * (size_t)c2.hbuf_halves * 2 + wbytes <= 160 * 1024) ? 2 : 1;
-      const size_t lds2 = std::max((size_t)c2.hbufs * c2.hbuf_halves * 2 + wbytes, (size_t)8 * (32 * (bn2 + 8) + 128) * 2);  // main loop | epilogue scratch
-      const long long tiles2 = (long long)((maxWo + tw - 1) / tw) * ((maxHo + th - 1) / th);
-      dim3 grid2((unsigned)(tiles2 * c2.a.nzb), (unsigned)n_img);
-      static bool attr2 = false;
-      if (!attr2) {
-        for (const void* f : {(const void*)k_conv16v2<1, 1>, (const void*)k_conv16v2<2, 1>, (const void*)k_conv16v2<3, 1>, (const void*)k_conv16v2<4, 1>,
-                              (const void*)k_conv16v2<1, 3>, (const void*)k_conv16v2<2, 3>, (const void*)k_conv16v2<3, 3>, (const void*)k_conv16v2<4, 3>})
-          RT_HIP_CHECK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr2 = true;
-      }
-#define RT_V2_LAUNCH(NT) \
-      switch (KW) { case 1: RT_LAUNCH((k_conv16v2<NT, 1>), grid2, dim3(512), lds2, st, c2); break; \
-                    default: RT_LAUNCH((k_conv16v2<NT, 3>), grid2, dim3(512), lds2, st, c2); break; }
-      switch (bn2 / 32) {
-        case 1: RT_V2_LAUNCH(1); break;
-        case 2: RT_V2_LAUNCH(2); break;
-        case 3: RT_V2_LAUNCH(3); break;
-        default: RT_V2_LAUNCH(4); break;
-      }
-#undef RT_V2_LAUNCH
-      return;
-    }
-  }
+  // ---- LDS-DMA kernels (nn_f16_dma.hip): the 3x3-class layers and the big 1x1 layers ----
+  if (g_conv16_v2 && !dot && conv16_dma(st, a, n_img, maxHo, maxWo)) return;
   int bn = dot ? Npad : choose_bn(Npad);
   if (dot && Npad > 160) throw RtError(8, "conv16: the dot epilogue needs all output channels in one block (N <= 160)");
   choose_tile(maxHo, maxWo, &a.TH, &a.TW);

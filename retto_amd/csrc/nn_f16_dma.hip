@@ -1,0 +1,458 @@
+// fp16 convolution kernels staged by LDS-DMA (global_load_lds) for gfx950: k_conv16v2 (3x3 / 1x3 / 3x1 layers) and k_gemm16
+// (1x1 layers over a flat pixel list).  Same fragment maps, K order and epilogue as k_conv16 (nn_f16.hip).
+#include "nn_f16_dev.h"
+
+#include <algorithm>
+
+namespace rt {
+namespace nh {
+
+// ---------------------------------------------------------------------------------------------------------------------
+// k_conv16v2: the same implicit GEMM for the 3x3 / 1x3 / 3x1 layers that dominate the server graphs, staged by LDS-DMA.
+// The first form stages through registers and needs its VGPRs for the accumulators, so it can only prefetch one kernel row
+// of weights and nothing of the halo: the in-kernel stamps show 2300 (row) to 5800 (row + halo) cycles of exposed L2 / HBM
+// latency per 3500-cycle MFMA phase.  Here both operands go global -> LDS by global_load_lds (no VGPR staging):
+//   * 8 waves on a 512-pixel tile x 32 * NTN channels (weights are re-read per 512 instead of 256 pixels);
+//   * weights: a ring of 3 kernel-row buffers -- row r + 2 is requested while row r is multiplied (two MFMA phases of
+//     latency cover); halo: two buffers, the next slab's tile is requested at the first row of the current slab;
+//   * one raw s_barrier per row, counted s_waitcnt vmcnt (hipcc's __syncthreads would drain the DMA queue);
+//   * LDS rows are un-padded 64-byte slabs (the DMA writes lane-linear), conflicts are avoided by an XOR swizzle of the
+//     16-byte chunk index with bits 2-3 of the row, applied to the per-lane SOURCE address and again on the fragment reads.
+// Same fragment maps, K order and epilogue as k_conv16: results are bit-identical.
+// ---------------------------------------------------------------------------------------------------------------------
+// The LDS-DMA request is written as inline asm: with the builtin (__builtin_amdgcn_global_load_lds) in a loop hipcc's
+// wait-count pass treats the LDS counter as out of order and emits lgkmcnt(0) before every MFMA group -- which also waits
+// for the fragment reads just issued for the NEXT k-step (checked on a reduced kernel: counted lgkmcnt(5/4/1) without the
+// DMA or with this form, lgkmcnt(0) everywhere with the builtin).  M0 = wave-uniform LDS byte address; lane i writes
+// 16 bytes at M0 + 16 i.  The kernel counts vmcnt for these requests by hand (nothing else loads inside the loop).
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"   // M0 is named as clobbered on purpose: nothing else in these kernels uses it
+__device__ __forceinline__ void glds16(const void* g, void* l) {
+  const unsigned la = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char*)l);
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(la) : "memory", "m0");
+}
+#pragma clang diagnostic pop
+#define RT_GLDS16(gp, lp) glds16((gp), (lp))
+
+struct ConvArgs2 {
+  ConvArgs a;
+  const half_t* zeros;   // >= 16 zero bytes in device memory: DMA source of padding pixels / channels
+  int hbuf_halves;       // size of one halo buffer (halves, multiple of 8)
+  int hbufs;             // 2: next slab's halo prefetched; 1: single buffer (large halos)
+};
+constexpr int V2_HMAX = 6;   // DMA instructions per thread for one halo tile (6 * 512 * 16 B = 48 KB)
+
+template <int NTN, int KW>
+__global__ __launch_bounds__(512, 1) void k_conv16v2(const ConvArgs2 c2) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem2[];
+  const ConvArgs& a = c2.a;
+  const bool kstamp = RT_STAMP_ON(a.stamps && blockIdx.y == 0 && blockIdx.x == gridDim.x / 2 && threadIdx.x == 0);
+  if (kstamp) a.stamps[4000] = __builtin_amdgcn_s_memtime();
+  constexpr int NTHR = 512, NTP = 2, BN = 32 * NTN, ROW = KS;  // LDS row = 32 halves (64 bytes), un-padded
+  const int TH = a.TH, TW = a.TW;
+  const ImgGeom go = a.gout[blockIdx.y];
+  const int tiles_x = (go.W + TW - 1) / TW, tiles_y = (go.H + TH - 1) / TH;
+  const int zb = blockIdx.x % a.nzb, tile = blockIdx.x / a.nzb;
+  if (tile >= tiles_x * tiles_y) return;
+  const ImgGeom gi = a.gin[blockIdx.y];
+  const int ty0 = (tile / tiles_x) * TH, tx0 = (tile % tiles_x) * TW;
+  const int nb0 = zb * BN;
+  const int HH = (TH - 1) * a.SH + a.KH, HW = (TW - 1) * a.SW + KW;
+  half_t* hbuf = reinterpret_cast<half_t*>(smem2);
+  half_t* wring = hbuf + (size_t)c2.hbufs * c2.hbuf_halves;
+  constexpr int wbuf_halves = ((KW * BN * 4 + 511) & ~511) * 8;   // whole groups of 512 DMA slots
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+
+  int pix[NTP], oys[NTP], oxs[NTP];
+#pragma unroll
+  for (int j = 0; j < NTP; j++) {
+    int q = (wid * NTP + j) * 32 + r;
+    int ty = q / TW, tx = q - ty * TW;
+    const bool ok = ty < TH;
+    if (!ok) { ty = 0; tx = 0; }
+    pix[j] = ty * a.SH * HW + tx * a.SW;   // halo pixel of tap (0, 0)
+    oys[j] = ok ? ty0 + ty : -1;
+    oxs[j] = tx0 + tx;
+  }
+  const int aswz = (r >> 2) & 3;            // rows of the weight tile: (row >> 2) & 3 == (r >> 2) & 3 (BN, 32 multiples of 16)
+
+  f32x16 acc[NTN][NTP];
+#pragma unroll
+  for (int i = 0; i < NTN; i++)
+#pragma unroll
+    for (int j = 0; j < NTP; j++)
+#pragma unroll
+      for (int e = 0; e < 16; e++) acc[i][j][e] = 0.f;
+
+  const int iy0 = ty0 * a.SH - a.PT, ix0 = tx0 * a.SW - a.PL;
+  const int nslab = (a.Cin + KS - 1) / KS, nrows = nslab * a.KH;
+  const int hchunks = HH * HW * 4; constexpr int wchunks = KW * BN * 4;
+  const half_t* xtile = a.x + gi.off * a.ldx + ((long long)iy0 * gi.W + ix0) * a.ldx;
+  // per-thread DMA sources, computed once: slot e = tid + 512 * i of a buffer holds (row e >> 2, physical chunk e & 3),
+  // i.e. the logical chunk (e & 3) ^ ((row >> 2) & 3) of that row
+  int hsrc[V2_HMAX];
+#pragma unroll
+  for (int i = 0; i < V2_HMAX; i++) {
+    const int e = tid + i * NTHR;
+    hsrc[i] = -1;
+    if (e < hchunks) {
+      const int p = e >> 2, cl = (e & 3) ^ ((p >> 2) & 3);
+      const int hy = p / HW, hx = p - hy * HW;
+      const int iy = iy0 + hy, ix = ix0 + hx;
+      if (iy >= 0 && iy < gi.H && ix >= 0 && ix < gi.W) hsrc[i] = ((hy * gi.W + hx) * a.ldx + cl * 8) | (cl << 28);
+    }
+  }
+  int wsrc[3];   // a kernel row: KW * BN * 4 <= 3 * 128 * 4 = 1536 chunks = 3 per thread
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+    const int e = tid + i * NTHR;
+    wsrc[i] = -1;
+    if (e < wchunks) {
+      const int row = e >> 2, cl = (e & 3) ^ ((row >> 2) & 3);
+      const int dx = row / BN, n = row - dx * BN;
+      if (nb0 + n < a.Npad) wsrc[i] = (dx * a.Npad + nb0 + n) * KS + cl * 8;
+    }
+  }
+  const size_t row_halves = (size_t)KW * a.Npad * KS;
+  const int wave_slot = wid * 64 * 8;   // halves: this wave's 64 consecutive 16-byte slots inside a group of 512
+  auto dma_halo = [&](int s) {          // slab s -> halo buffer s % hbufs
+    half_t* dst = hbuf + (size_t)(s % c2.hbufs) * c2.hbuf_halves;
+    const int cvalid = min(KS, a.Cin - s * KS);
+#pragma unroll
+    for (int i = 0; i < V2_HMAX; i++) {
+      if (i * NTHR >= hchunks) break;   // (uniform)
+      const bool ok = hsrc[i] >= 0 && (hsrc[i] >> 28) * 8 < cvalid;
+      const half_t* src = ok ? xtile + (hsrc[i] & 0x0fffffff) + s * KS : c2.zeros;
+      RT_GLDS16(src, dst + (size_t)i * NTHR * 8 + wave_slot);
+    }
+  };
+  auto dma_wrow = [&](int rr) {         // kernel row rr -> ring slot rr % 3
+    half_t* dst = wring + (size_t)(rr % 3) * wbuf_halves;
+    const half_t* wg = a.w + (size_t)rr * row_halves;
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+      if (i * NTHR >= wchunks) break;   // (uniform)
+      const half_t* src = wsrc[i] >= 0 ? wg + wsrc[i] : c2.zeros;
+      RT_GLDS16(src, dst + (size_t)i * NTHR * 8 + wave_slot);
+    }
+  };
+  // prologue: halo 0, rows 0 and 1 (and halo 1 with two buffers) in flight; wait for everything once
+  dma_halo(0);
+  dma_wrow(0);
+  if (nrows > 1) dma_wrow(1);
+  if (kstamp) a.stamps[4001] = __builtin_amdgcn_s_memtime();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  if (kstamp) a.stamps[4002] = __builtin_amdgcn_s_memtime();
+  const int nw = (wchunks + NTHR - 1) / NTHR, nh = (hchunks + NTHR - 1) / NTHR;   // DMA instructions per row / per halo, per thread
+
+  for (int rr = 0; rr < nrows; rr++) {
+    const int s = rr / a.KH, dy = rr - s * a.KH;
+    const int cvalid = min(KS, a.Cin - s * KS);
+    const int ksteps = (cvalid + 15) >> 4;
+    const bool stamp = RT_STAMP_ON(a.stamps && blockIdx.y == 0 && blockIdx.x == gridDim.x / 2 && tid == 0);
+    if (stamp) { a.stamps[rr * 5 + 0] = __builtin_amdgcn_s_memtime(); a.stamps[rr * 5 + 1] = a.stamps[rr * 5 + 0]; }
+    // ---- multiply kernel row rr: the k-steps (dx, 16 channels) of the row in one software-pipelined sequence -- the
+    // fragments of step i + 1 are requested from LDS before the MFMAs of step i are issued, so only the first read of a
+    // stage is exposed; the DMA requests for later stages go out behind the first MFMA group ----
+    const half_t* wl = wring + (size_t)(rr % 3) * wbuf_halves;
+    const half_t* halo = hbuf + (size_t)(s % c2.hbufs) * c2.hbuf_halves;
+    // (a slab with fewer than 32 real channels still runs both 16-deep k-steps: its LDS rows and the packed weights are
+    // zero-filled, and a fixed step count keeps the sequence below straight-line code -- with the steps behind run-time
+    // tests hipcc waits lgkmcnt(0) before every MFMA group, which also waits for the prefetch just issued)
+    (void)ksteps;
+    constexpr int NK = KW * 2;
+    const int tap0 = dy * HW;
+    auto frags = [&](int it, h8 (&A)[NTN], h8 (&B)[NTP]) {
+      const int dx = it >> 1, ks = it & 1;
+      const int cl = ks * 2 + h;
+      const half_t* wrow = wl + (size_t)(dx * BN + r) * ROW + ((cl ^ aswz) << 3);
+#pragma unroll
+      for (int i = 0; i < NTN; i++) A[i] = *reinterpret_cast<const h8*>(wrow + i * 32 * ROW);
+#pragma unroll
+      for (int j = 0; j < NTP; j++) {
+        const int p = pix[j] + tap0 + dx;
+        B[j] = *reinterpret_cast<const h8*>(halo + p * ROW + ((cl ^ ((p >> 2) & 3)) << 3));
+      }
+    };
+    auto mfmas = [&](const h8 (&A)[NTN], const h8 (&B)[NTP]) {
+#pragma unroll
+      for (int i = 0; i < NTN; i++)
+#pragma unroll
+        for (int j = 0; j < NTP; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[i], B[j], acc[i][j], 0, 0, 0);
+    };
+    // (sched_barrier: hipcc otherwise sinks every fragment read down to its first use and waits lgkmcnt(0) there)
+    h8 Af[2][NTN], Bf[2][NTP];
+    frags(0, Af[0], Bf[0]);
+    frags(1, Af[1], Bf[1]);
+    __builtin_amdgcn_sched_barrier(0);
+    mfmas(Af[0], Bf[0]);
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- requests for later stages (the buffers they overwrite were last read before the barrier this wave just passed) ----
+    if (rr + 2 < nrows) dma_wrow(rr + 2);
+    bool halo_now = false;
+    if (c2.hbufs == 2) { if (dy == 0 && s + 1 < nslab) { dma_halo(s + 1); halo_now = true; } }
+    (void)halo_now;
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int it = 1; it < NK; it++) {
+      if (it + 1 < NK) frags(it + 1, Af[(it + 1) & 1], Bf[(it + 1) & 1]);
+      __builtin_amdgcn_sched_barrier(0);
+      mfmas(Af[it & 1], Bf[it & 1]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (stamp) { a.stamps[rr * 5 + 2] = __builtin_amdgcn_s_memtime(); a.stamps[rr * 5 + 3] = a.stamps[rr * 5 + 2]; }
+    if (rr + 1 == nrows) break;
+    // ---- the next row's data must have landed: everything except the requests made in THIS iteration ----
+    const int ns = (rr + 1) / a.KH, ndy = (rr + 1) - ns * a.KH;
+    if (c2.hbufs == 1 && ndy == 0) {
+      // single halo buffer: every wave is done with the old tile only after the barrier; request and wait here (exposed)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      dma_halo(ns);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      continue;
+    }
+    // outstanding and allowed to stay in flight: row rr + 2 (nw instructions, if requested); the halo requested in this
+    // iteration is only needed KH rows later, but it was issued AFTER row rr + 2, so it may stay in flight as well
+    // (with one-row kernels the halo requested in this iteration is needed by the very next row: nothing may stay in flight)
+    const int keep = (halo_now && ndy == 0) ? 0 : (rr + 2 < nrows ? nw : 0) + (halo_now ? nh : 0);
+    // (a halo requested in an earlier iteration of this slab is older than row rr + 1's weights and therefore retired with them)
+    switch (keep) {
+      case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+      case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+      case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+      case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+      case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+      case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+      case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+      case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+      case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+      default: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+    }
+    if (stamp) a.stamps[rr * 5 + 3] = __builtin_amdgcn_s_memtime();
+    __builtin_amdgcn_s_barrier();
+    if (stamp) a.stamps[rr * 5 + 4] = __builtin_amdgcn_s_memtime();
+  }
+
+  if (kstamp) a.stamps[4003] = __builtin_amdgcn_s_memtime();
+  __builtin_amdgcn_s_barrier();   // every wave is done with the last stage's LDS (no DMA is in flight any more)
+  if (kstamp) a.stamps[4005] = __builtin_amdgcn_s_memtime();
+  store_tile16<NTN, NTP>(a, acc, reinterpret_cast<half_t*>(smem2) + (size_t)wid * epi_scratch_halves<NTN>(), lane, nb0, oys, oxs, go);
+  if (kstamp) a.stamps[4006] = __builtin_amdgcn_s_memtime();
+  if (kstamp) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); a.stamps[4004] = __builtin_amdgcn_s_memtime(); }
+}
+
+static const half_t* zero_page16() {   // per device: DMA source of padding (one allocation per process and device)
+  static const half_t* z[16] = {nullptr};
+  int dev = 0;
+  RT_HIP_CHECK(hipGetDevice(&dev));
+  if (dev < 0 || dev >= 16) throw RtError(8, "conv16: device index out of range");
+  if (!z[dev]) {
+    void* p = nullptr;
+    RT_HIP_CHECK(hipMalloc(&p, 256));
+    RT_HIP_CHECK(hipMemset(p, 0, 256));
+    z[dev] = (const half_t*)p;
+  }
+  return z[dev];
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// k_gemm16: a 1x1 convolution over a flat list of M pixels, Y[M][N] = X[M][K] . W^T, as a 256-pixel x (64 * NTN)-channel
+// tile per workgroup of 8 waves (2 over the channels x 4 over the pixels; a wave owns 32 * NTN channels x 64 pixels).
+// K is walked in stages of 64 channels: both operands of a stage go global -> LDS by DMA into one of two stage buffers
+// ([2 slabs][rows][32 halves], 64-byte rows, XOR-swizzled like k_conv16v2), the next stage is requested right behind the
+// first MFMA group of the current one and has the whole stage (32 MFMAs per wave) to land; one vmcnt(0) + barrier per
+// stage.  The four 16-deep k-steps of a stage are software-pipelined (fragments of step i + 1 requested before the MFMAs
+// of step i).  The packed weights and the DMA zero source pad K to whole stages.
+// ---------------------------------------------------------------------------------------------------------------------
+struct GemmArgs16 {
+  ConvArgs a;            // x, ldx, gin/gout (one flat image), Cin = K, w, N, Npad, y, ldy, coff, nzb, epi
+  const half_t* zeros;
+};
+
+template <int NTN>
+__global__ __launch_bounds__(512, 1) void k_gemm16(const GemmArgs16 g) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smemg[];
+  const ConvArgs& a = g.a;
+  constexpr int NTHR = 512, NTP = 2, BN = 64 * NTN, BP = 256, ROW = KS;
+  constexpr int XCH = 2 * BP * 4 / NTHR, WCH = 2 * BN * 4 / NTHR;          // DMA instructions per thread and stage: 4 and NTN
+  constexpr int XHALVES = 2 * BP * ROW, WHALVES = 2 * BN * ROW, STAGE = XHALVES + WHALVES;
+  const ImgGeom gi = a.gin[0], go = a.gout[0];
+  const long long M = go.W;
+  const int zb = blockIdx.x % a.nzb;
+  const long long m0 = (long long)(blockIdx.x / a.nzb) * BP;
+  if (m0 >= M) return;
+  const int nblk = zb * BN;
+  half_t* lds = reinterpret_cast<half_t*>(smemg);
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wn = wid & 1, wp = wid >> 1;
+  const int r = lane & 31, h = lane >> 5;
+  const int aswz = (r >> 2) & 3;
+  const int nb0 = nblk + wn * 32 * NTN;      // first channel of this wave
+
+  f32x16 acc[NTN][NTP];
+#pragma unroll
+  for (int i = 0; i < NTN; i++)
+#pragma unroll
+    for (int j = 0; j < NTP; j++)
+#pragma unroll
+      for (int e = 0; e < 16; e++) acc[i][j][e] = 0.f;
+
+  const int K = a.Cin, nslab = (K + KS - 1) / KS, nst = (nslab + 1) >> 1;
+  // per-thread DMA sources (slot e = tid + 512 i of an operand's stage image: slab e / (rows * 4), row, physical chunk)
+  const half_t* xsrc[XCH]; int xk[XCH];
+#pragma unroll
+  for (int i = 0; i < XCH; i++) {
+    const int e = tid + i * NTHR, slab = e / (BP * 4), rem = e - slab * (BP * 4), row = rem >> 2, cl = (rem & 3) ^ ((row >> 2) & 3);
+    xk[i] = slab * KS + cl * 8;
+    xsrc[i] = (m0 + row < M) ? a.x + (gi.off + m0 + row) * a.ldx + xk[i] : nullptr;
+  }
+  const half_t* wsrc[WCH]; int wslab[WCH];
+#pragma unroll
+  for (int i = 0; i < WCH; i++) {
+    const int e = tid + i * NTHR, slab = e / (BN * 4), rem = e - slab * (BN * 4), row = rem >> 2, cl = (rem & 3) ^ ((row >> 2) & 3);
+    wslab[i] = slab;
+    wsrc[i] = (nblk + row < a.Npad) ? a.w + ((size_t)slab * a.Npad + nblk + row) * KS + cl * 8 : nullptr;
+  }
+  const int wave_slot = wid * 64 * 8;
+  auto dma_stage = [&](int s) {
+    half_t* dst = lds + (size_t)(s & 1) * STAGE + wave_slot;
+    const int k0 = s * 2 * KS;
+#pragma unroll
+    for (int i = 0; i < XCH; i++) {
+      const half_t* src = (xsrc[i] && k0 + xk[i] < K) ? xsrc[i] + k0 : g.zeros;
+      RT_GLDS16(src, dst + (size_t)i * NTHR * 8);
+    }
+#pragma unroll
+    for (int i = 0; i < WCH; i++) {
+      const half_t* src = (wsrc[i] && s * 2 + wslab[i] < nslab) ? wsrc[i] + (size_t)s * 2 * a.Npad * KS : g.zeros;
+      RT_GLDS16(src, dst + XHALVES + (size_t)i * NTHR * 8);
+    }
+  };
+  dma_stage(0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+
+  for (int s = 0; s < nst; s++) {
+    const half_t* xb = lds + (size_t)(s & 1) * STAGE;
+    const half_t* wb = xb + XHALVES;
+    auto frags = [&](int it, h8 (&A)[NTN], h8 (&B)[NTP]) {
+      const int slab = it >> 1, cl = (it & 1) * 2 + h;
+      const int co = (cl ^ aswz) << 3;
+      const half_t* wrow = wb + (size_t)(slab * BN + wn * 32 * NTN + r) * ROW + co;
+      const half_t* xrow = xb + (size_t)(slab * BP + wp * 64 + r) * ROW + co;
+#pragma unroll
+      for (int j = 0; j < NTP; j++) B[j] = *reinterpret_cast<const h8*>(xrow + j * 32 * ROW);
+#pragma unroll
+      for (int i = 0; i < NTN; i++) A[i] = *reinterpret_cast<const h8*>(wrow + i * 32 * ROW);
+    };
+    auto mfmas = [&](const h8 (&A)[NTN], const h8 (&B)[NTP]) {
+#pragma unroll
+      for (int i = 0; i < NTN; i++)
+#pragma unroll
+        for (int j = 0; j < NTP; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[i], B[j], acc[i][j], 0, 0, 0);
+    };
+    h8 Af[2][NTN], Bf[2][NTP];
+    frags(0, Af[0], Bf[0]);
+    frags(1, Af[1], Bf[1]);
+    __builtin_amdgcn_sched_barrier(0);
+    mfmas(Af[0], Bf[0]);
+    __builtin_amdgcn_sched_barrier(0);
+    if (s + 1 < nst) dma_stage(s + 1);   // into the buffer every wave finished reading before the last barrier
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int it = 1; it < 4; it++) {
+      if (it + 1 < 4) frags(it + 1, Af[(it + 1) & 1], Bf[(it + 1) & 1]);
+      __builtin_amdgcn_sched_barrier(0);
+      mfmas(Af[it & 1], Bf[it & 1]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  }
+  // (the last barrier also says that every wave is done with the stage buffers: they become the transpose scratch)
+  int oys[NTP], oxs[NTP];
+#pragma unroll
+  for (int j = 0; j < NTP; j++) {
+    const long long m = m0 + wp * 64 + j * 32 + r;
+    oys[j] = m < M ? 0 : -1;
+    oxs[j] = (int)m;
+  }
+  store_tile16<NTN, NTP>(a, acc, lds + (size_t)wid * epi_scratch_halves<NTN>(), lane, nb0, oys, oxs, go);
+}
+
+template <int NTN>
+static void launch_gemm16(hipStream_t st, const GemmArgs16& g, long long mtiles) {
+  constexpr size_t lds = (size_t)2 * (2 * 256 * KS + 2 * 64 * NTN * KS) * 2;   // two stage buffers (>= the epilogue scratch)
+  static_assert(lds >= (size_t)8 * (32 * (32 * NTN + 8) + 128) * 2, "epilogue scratch must fit in the stage buffers");
+  static bool attr = false;
+  if (!attr) { RT_HIP_CHECK(hipFuncSetAttribute((const void*)k_gemm16<NTN>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr = true; }
+  RT_LAUNCH((k_gemm16<NTN>), dim3((unsigned)(mtiles * g.a.nzb)), dim3(512), lds, st, g);
+}
+
+bool conv16_dma(hipStream_t st, const ConvArgs& a0, int n_img, int maxHo, int maxWo) {
+  const int KH = a0.KH, KW = a0.KW, SH = a0.SH, SW = a0.SW, Npad = a0.Npad, Cin = a0.Cin;
+  // ---- 1x1 over one flat image: k_gemm16 when the channel blocks of 256 / 128 waste little ----
+  if (KH == 1 && KW == 1 && SH == 1 && SW == 1 && a0.PT == 0 && a0.PL == 0 && n_img == 1 && maxHo == 1 && Cin >= 64 && maxWo >= 4096) {
+    int bn = 0;
+    if (Npad % 256 == 0 || Npad >= 1024) bn = 256;
+    else if (Npad % 128 == 0) bn = 128;
+    if (bn) {
+      GemmArgs16 g;
+      g.a = a0; g.a.nzb = (Npad + bn - 1) / bn; g.zeros = zero_page16();
+      const long long mtiles = ((long long)maxWo + 255) / 256;
+      if (mtiles * g.a.nzb < (1ll << 31)) {
+        if (bn == 256) launch_gemm16<4>(st, g, mtiles); else launch_gemm16<2>(st, g, mtiles);
+        return true;
+      }
+    }
+    return false;
+  }
+  // ---- the 3x3-class layers ----
+  if (!(KH <= 3 && (KW == 1 || KW == 3) && KH * KW > 1 && Cin >= 32 && n_img <= RT_MAX_GRID_Y)) return false;
+  int bn2 = 32, best = 1 << 30;
+  for (int bn : {128, 96, 64, 32}) {
+    const int nb = (Npad + bn - 1) / bn, cost = nb * bn + 16 * nb;
+    if (cost < best) { best = cost; bn2 = bn; }
+  }
+  // 512-pixel tile: full-height tiles on short maps; the halo tile must fit V2_HMAX DMA instructions per thread
+  int th, tw;
+  if (maxHo >= 16) { const int ny = (maxHo + 15) / 16; th = maxHo >= 64 ? 16 : (maxHo + ny - 1) / ny; } else th = std::max(maxHo, 1);
+  tw = std::max(1, std::min(512 / th, maxWo));
+  auto hpix = [&](int t_h, int t_w) { return ((t_h - 1) * SH + KH) * ((t_w - 1) * SW + KW); };
+  while (hpix(th, tw) * 4 > V2_HMAX * 512 && tw > 8) tw--;
+  if (hpix(th, tw) * 4 > V2_HMAX * 512) return false;
+  ConvArgs2 c2;
+  c2.a = a0; c2.a.TH = th; c2.a.TW = tw; c2.a.lp = KS; c2.a.nzb = (Npad + bn2 - 1) / bn2;
+  c2.zeros = zero_page16();
+  c2.hbuf_halves = ((hpix(th, tw) * 4 + 511) & ~511) * 8;
+  const size_t wbytes = (size_t)((KW * bn2 * 4 + 511) & ~511) * 16 * 3;
+  c2.hbufs = (2 * (size_t)c2.hbuf_halves * 2 + wbytes <= 160 * 1024) ? 2 : 1;
+  const size_t lds2 = std::max((size_t)c2.hbufs * c2.hbuf_halves * 2 + wbytes, (size_t)8 * (32 * (bn2 + 8) + 128) * 2);  // main loop | epilogue scratch
+  const long long tiles2 = (long long)((maxWo + tw - 1) / tw) * ((maxHo + th - 1) / th);
+  dim3 grid2((unsigned)(tiles2 * c2.a.nzb), (unsigned)n_img);
+  static bool attr2 = false;
+  if (!attr2) {
+    for (const void* f : {(const void*)k_conv16v2<1, 1>, (const void*)k_conv16v2<2, 1>, (const void*)k_conv16v2<3, 1>, (const void*)k_conv16v2<4, 1>,
+                          (const void*)k_conv16v2<1, 3>, (const void*)k_conv16v2<2, 3>, (const void*)k_conv16v2<3, 3>, (const void*)k_conv16v2<4, 3>})
+      RT_HIP_CHECK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr2 = true;
+  }
+#define RT_V2_LAUNCH(NT) \
+  switch (KW) { case 1: RT_LAUNCH((k_conv16v2<NT, 1>), grid2, dim3(512), lds2, st, c2); break; \
+                default: RT_LAUNCH((k_conv16v2<NT, 3>), grid2, dim3(512), lds2, st, c2); break; }
+  switch (bn2 / 32) {
+    case 1: RT_V2_LAUNCH(1); break;
+    case 2: RT_V2_LAUNCH(2); break;
+    case 3: RT_V2_LAUNCH(3); break;
+    default: RT_V2_LAUNCH(4); break;
+  }
+#undef RT_V2_LAUNCH
+  return true;
+}
+
+}  // namespace nh
+}  // namespace rt

@@ -89,6 +89,10 @@ def _conv16(sess, x, w, b, sh, sw, act):
     (1, 80, 64, (2, 2), (1, 1), (16, 16), 1),       # 2.5 slabs
     (2, 96, 24, (3, 3), (1, 1), (40, 56), 0),       # mobile FPN 3x3
     (1, 1216, 512, (1, 1), (1, 1), (8, 20), 1),     # HG aggregation conv
+    (2, 896, 256, (1, 1), (1, 1), (50, 61), 1),     # HG aggregation conv on >= 4096 pixels: the LDS-DMA GEMM kernel, ragged last tile
+    (1, 1664, 768, (1, 1), (1, 1), (40, 120), 1),   # 3 channel blocks of 256, K = 52 slabs
+    (1, 72, 128, (1, 1), (1, 1), (64, 80), 2),      # K = 2.25 slabs (odd stage tail + partial slab), 128-channel blocks
+    (1, 2112, 1024, (1, 1), (1, 1), (30, 140), 0),  # largest aggregation conv (stage 4)
 ])
 def test_conv16_kernel(hip16, n, cin, cout, k, stride, hw, act):
     """fp16 inputs / weights, fp32 accumulation: against torch conv2d on the SAME fp16-rounded operands the only
