@@ -39,8 +39,9 @@ struct ConvArgs2 {
   const half_t* zeros;   // >= 16 zero bytes in device memory: DMA source of padding pixels / channels
   int hbuf_halves;       // size of one halo buffer (halves, multiple of 8)
   int hbufs;             // 2: next slab's halo prefetched; 1: single buffer (large halos)
+  int wslots;            // weight ring: 3 (row r + 2 requested while row r is multiplied) or 2 (row r + 1; the 9-tap rows)
 };
-constexpr int V2_HMAX = 6;   // DMA instructions per thread for one halo tile (6 * 512 * 16 B = 48 KB)
+constexpr int V2_HMAX = 8;   // DMA instructions per thread for one halo tile (8 * 512 * 16 B = 64 KB)
 
 template <int NTN, int KW>
 __global__ __launch_bounds__(512, 1) void k_conv16v2(const ConvArgs2 c2) {
@@ -103,9 +104,10 @@ __global__ __launch_bounds__(512, 1) void k_conv16v2(const ConvArgs2 c2) {
       if (iy >= 0 && iy < gi.H && ix >= 0 && ix < gi.W) hsrc[i] = ((hy * gi.W + hx) * a.ldx + cl * 8) | (cl << 28);
     }
   }
-  int wsrc[3];   // a kernel row: KW * BN * 4 <= 3 * 128 * 4 = 1536 chunks = 3 per thread
+  constexpr int WI = (KW * BN * 4 + NTHR - 1) / NTHR;   // DMA instructions per thread for a kernel row (3x3, BN 128: 3)
+  int wsrc[WI];
 #pragma unroll
-  for (int i = 0; i < 3; i++) {
+  for (int i = 0; i < WI; i++) {
     const int e = tid + i * NTHR;
     wsrc[i] = -1;
     if (e < wchunks) {
@@ -127,11 +129,12 @@ __global__ __launch_bounds__(512, 1) void k_conv16v2(const ConvArgs2 c2) {
       RT_GLDS16(src, dst + (size_t)i * NTHR * 8 + wave_slot);
     }
   };
-  auto dma_wrow = [&](int rr) {         // kernel row rr -> ring slot rr % 3
-    half_t* dst = wring + (size_t)(rr % 3) * wbuf_halves;
+  const int wslots = c2.wslots, D = wslots - 1;   // prefetch distance in rows
+  auto dma_wrow = [&](int rr) {         // kernel row rr -> ring slot rr % wslots
+    half_t* dst = wring + (size_t)(rr % wslots) * wbuf_halves;
     const half_t* wg = a.w + (size_t)rr * row_halves;
 #pragma unroll
-    for (int i = 0; i < 3; i++) {
+    for (int i = 0; i < WI; i++) {
       if (i * NTHR >= wchunks) break;   // (uniform)
       const half_t* src = wsrc[i] >= 0 ? wg + wsrc[i] : c2.zeros;
       RT_GLDS16(src, dst + (size_t)i * NTHR * 8 + wave_slot);
@@ -140,7 +143,7 @@ __global__ __launch_bounds__(512, 1) void k_conv16v2(const ConvArgs2 c2) {
   // prologue: halo 0, rows 0 and 1 (and halo 1 with two buffers) in flight; wait for everything once
   dma_halo(0);
   dma_wrow(0);
-  if (nrows > 1) dma_wrow(1);
+  if (D > 1 && nrows > 1) dma_wrow(1);
   if (kstamp) a.stamps[4001] = __builtin_amdgcn_s_memtime();
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
@@ -156,7 +159,7 @@ __global__ __launch_bounds__(512, 1) void k_conv16v2(const ConvArgs2 c2) {
     // ---- multiply kernel row rr: the k-steps (dx, 16 channels) of the row in one software-pipelined sequence -- the
     // fragments of step i + 1 are requested from LDS before the MFMAs of step i are issued, so only the first read of a
     // stage is exposed; the DMA requests for later stages go out behind the first MFMA group ----
-    const half_t* wl = wring + (size_t)(rr % 3) * wbuf_halves;
+    const half_t* wl = wring + (size_t)(rr % wslots) * wbuf_halves;
     const half_t* halo = hbuf + (size_t)(s % c2.hbufs) * c2.hbuf_halves;
     // (a slab with fewer than 32 real channels still runs both 16-deep k-steps: its LDS rows and the packed weights are
     // zero-filled, and a fixed step count keeps the sequence below straight-line code -- with the steps behind run-time
@@ -190,7 +193,7 @@ __global__ __launch_bounds__(512, 1) void k_conv16v2(const ConvArgs2 c2) {
     mfmas(Af[0], Bf[0]);
     __builtin_amdgcn_sched_barrier(0);
     // ---- requests for later stages (the buffers they overwrite were last read before the barrier this wave just passed) ----
-    if (rr + 2 < nrows) dma_wrow(rr + 2);
+    if (rr + D < nrows) dma_wrow(rr + D);
     bool halo_now = false;
     if (c2.hbufs == 2) { if (dy == 0 && s + 1 < nslab) { dma_halo(s + 1); halo_now = true; } }
     (void)halo_now;
@@ -218,7 +221,8 @@ __global__ __launch_bounds__(512, 1) void k_conv16v2(const ConvArgs2 c2) {
     // outstanding and allowed to stay in flight: row rr + 2 (nw instructions, if requested); the halo requested in this
     // iteration is only needed KH rows later, but it was issued AFTER row rr + 2, so it may stay in flight as well
     // (with one-row kernels the halo requested in this iteration is needed by the very next row: nothing may stay in flight)
-    const int keep = (halo_now && ndy == 0) ? 0 : (rr + 2 < nrows ? nw : 0) + (halo_now ? nh : 0);
+    // (ring of 2: row rr + 1 itself was requested in this iteration, before the halo: only that halo may stay in flight)
+    const int keep = (halo_now && ndy == 0) ? 0 : ((D > 1 && rr + 2 < nrows) ? nw : 0) + (halo_now ? nh : 0);
     // (a halo requested in an earlier iteration of this slab is older than row rr + 1's weights and therefore retired with them)
     switch (keep) {
       case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
@@ -412,7 +416,8 @@ bool conv16_dma(hipStream_t st, const ConvArgs& a0, int n_img, int maxHo, int ma
     return false;
   }
   // ---- the 3x3-class layers ----
-  if (!(KH <= 3 && (KW == 1 || KW == 3) && KH * KW > 1 && Cin >= 32 && n_img <= RT_MAX_GRID_Y)) return false;
+  const bool k9 = KH == 9 && KW == 9 && SH == 1 && SW == 1 && Npad == 64;   // LKPAN's 9x9 layers (256 -> 64, 64 -> 64)
+  if (!(((KH <= 3 && (KW == 1 || KW == 3) && KH * KW > 1) || k9) && Cin >= 32 && n_img <= RT_MAX_GRID_Y)) return false;
   int bn2 = 32, best = 1 << 30;
   for (int bn : {128, 96, 64, 32}) {
     const int nb = (Npad + bn - 1) / bn, cost = nb * bn + 16 * nb;
@@ -429,21 +434,25 @@ bool conv16_dma(hipStream_t st, const ConvArgs& a0, int n_img, int maxHo, int ma
   c2.a = a0; c2.a.TH = th; c2.a.TW = tw; c2.a.lp = KS; c2.a.nzb = (Npad + bn2 - 1) / bn2;
   c2.zeros = zero_page16();
   c2.hbuf_halves = ((hpix(th, tw) * 4 + 511) & ~511) * 8;
-  const size_t wbytes = (size_t)((KW * bn2 * 4 + 511) & ~511) * 16 * 3;
+  c2.wslots = k9 ? 2 : 3;
+  const size_t wbytes = (size_t)((KW * bn2 * 4 + 511) & ~511) * 16 * c2.wslots;
   c2.hbufs = (2 * (size_t)c2.hbuf_halves * 2 + wbytes <= 160 * 1024) ? 2 : 1;
+  if ((size_t)c2.hbufs * c2.hbuf_halves * 2 + wbytes > 160 * 1024) return false;
   const size_t lds2 = std::max((size_t)c2.hbufs * c2.hbuf_halves * 2 + wbytes, (size_t)8 * (32 * (bn2 + 8) + 128) * 2);  // main loop | epilogue scratch
   const long long tiles2 = (long long)((maxWo + tw - 1) / tw) * ((maxHo + th - 1) / th);
   dim3 grid2((unsigned)(tiles2 * c2.a.nzb), (unsigned)n_img);
   static bool attr2 = false;
   if (!attr2) {
     for (const void* f : {(const void*)k_conv16v2<1, 1>, (const void*)k_conv16v2<2, 1>, (const void*)k_conv16v2<3, 1>, (const void*)k_conv16v2<4, 1>,
-                          (const void*)k_conv16v2<1, 3>, (const void*)k_conv16v2<2, 3>, (const void*)k_conv16v2<3, 3>, (const void*)k_conv16v2<4, 3>})
+                          (const void*)k_conv16v2<1, 3>, (const void*)k_conv16v2<2, 3>, (const void*)k_conv16v2<3, 3>, (const void*)k_conv16v2<4, 3>,
+                          (const void*)k_conv16v2<2, 9>})
       RT_HIP_CHECK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr2 = true;
   }
 #define RT_V2_LAUNCH(NT) \
   switch (KW) { case 1: RT_LAUNCH((k_conv16v2<NT, 1>), grid2, dim3(512), lds2, st, c2); break; \
                 default: RT_LAUNCH((k_conv16v2<NT, 3>), grid2, dim3(512), lds2, st, c2); break; }
+  if (k9) { RT_LAUNCH((k_conv16v2<2, 9>), grid2, dim3(512), lds2, st, c2); return true; }
   switch (bn2 / 32) {
     case 1: RT_V2_LAUNCH(1); break;
     case 2: RT_V2_LAUNCH(2); break;
