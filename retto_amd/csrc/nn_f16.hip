@@ -4,6 +4,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <type_traits>
 
 namespace rt {
 namespace nh {
@@ -174,29 +175,42 @@ __global__ __launch_bounds__(64 * WN * WP, 2) void k_conv16(const ConvArgs a) {
   // ---- epilogue: lane = one pixel (column r of the tile), registers = channels (reg & 3) + 8 * (reg >> 2) + 4 * h ----
   const Epi16& e = a.epi;
   if (DOT) {
+    // (activation resolved once per workgroup, as in store_tile16: a run-time switch per element is a scalar branch each)
+    auto dot_epi = [&](auto actc) {
+      constexpr int ACT = decltype(actc)::value;
 #pragma unroll
-    for (int j = 0; j < NTP; j++) {
-      float sdot = 0.f;
+      for (int j = 0; j < NTP; j++) {
+        float sdot = 0.f;
 #pragma unroll
-      for (int i = 0; i < NTN; i++)
+        for (int i = 0; i < NTN; i++)
 #pragma unroll
-        for (int g = 0; g < 4; g++)
+          for (int g = 0; g < 4; g++) {
+            const int n = (wn * NTN + i) * 32 + 8 * g + 4 * h;
+            f32x4 v;
 #pragma unroll
-          for (int t = 0; t < 4; t++) {
-            const int n = (wn * NTN + i) * 32 + 8 * g + 4 * h + t;
-            float v = acc[i][j][4 * g + t] + (e.bias ? e.bias[n] : 0.f);
-            v = act_f(v, e.act);
-            sdot = fmaf(v, e.dot_w[n], sdot);  // dot_w is zero beyond N
+            for (int t = 0; t < 4; t++) v[t] = acc[i][j][4 * g + t];
+            if (e.bias) v += *reinterpret_cast<const f32x4*>(e.bias + n);
+            const f32x4 dw = *reinterpret_cast<const f32x4*>(e.dot_w + n);  // dot_w is zero beyond N
+#pragma unroll
+            for (int t = 0; t < 4; t++) sdot = fmaf(act_c<ACT>(v[t]), dw[t], sdot);
           }
-      sdot += __shfl_xor(sdot, 32);
-      if (h == 0 && oys[j] >= 0) {
-        const int oy = oys[j], ox = oxs[j];
-        if (oy < go.H && ox < go.W) {
-          const ImgGeom gm = e.gmap[blockIdx.y];
-          float* m = e.dot_map + gm.off + (long long)(2 * oy + e.dot_py) * gm.W + 2 * ox + e.dot_px;
-          *m = 0.5f * (*m + 1.f / (1.f + __expf(-(sdot + e.dot_b))));
+        sdot += __shfl_xor(sdot, 32);
+        if (h == 0 && oys[j] >= 0) {
+          const int oy = oys[j], ox = oxs[j];
+          if (oy < go.H && ox < go.W) {
+            const ImgGeom gm = e.gmap[blockIdx.y];
+            float* m = e.dot_map + gm.off + (long long)(2 * oy + e.dot_py) * gm.W + 2 * ox + e.dot_px;
+            *m = 0.5f * (*m + 1.f / (1.f + __expf(-(sdot + e.dot_b))));
+          }
         }
       }
+    };
+    switch (e.act) {
+      case ACT_RELU: dot_epi(std::integral_constant<int, ACT_RELU>{}); break;
+      case ACT_HSWISH: dot_epi(std::integral_constant<int, ACT_HSWISH>{}); break;
+      case ACT_SWISH: dot_epi(std::integral_constant<int, ACT_SWISH>{}); break;
+      case ACT_SIGMOID: dot_epi(std::integral_constant<int, ACT_SIGMOID>{}); break;
+      default: dot_epi(std::integral_constant<int, ACT_NONE>{}); break;
     }
     return;
   }

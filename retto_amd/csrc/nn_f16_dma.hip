@@ -3,6 +3,7 @@
 #include "nn_f16_dev.h"
 
 #include <algorithm>
+#include <cstdlib>
 
 namespace rt {
 namespace nh {
@@ -43,7 +44,8 @@ struct ConvArgs2 {
 };
 constexpr int V2_HMAX = 8;   // DMA instructions per thread for one halo tile (8 * 512 * 16 B = 64 KB)
 
-template <int NTN, int KW>
+// KW = taps per stage (RG kernel rows of KWR taps each: KW = RG * KWR); KWR = the real kernel width
+template <int NTN, int KW, int KWR>
 __global__ __launch_bounds__(512, 1) void k_conv16v2(const ConvArgs2 c2) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem2[];
   const ConvArgs& a = c2.a;
@@ -58,7 +60,10 @@ __global__ __launch_bounds__(512, 1) void k_conv16v2(const ConvArgs2 c2) {
   const ImgGeom gi = a.gin[blockIdx.y];
   const int ty0 = (tile / tiles_x) * TH, tx0 = (tile % tiles_x) * TW;
   const int nb0 = zb * BN;
-  const int HH = (TH - 1) * a.SH + a.KH, HW = (TW - 1) * a.SW + KW;
+  constexpr int RG = KW / KWR;   // kernel rows per stage
+  static_assert(RG * KWR == KW, "a stage is whole kernel rows");
+  const int HH = (TH - 1) * a.SH + a.KH, HW = (TW - 1) * a.SW + KWR;
+  const int SPS = a.KH / RG;    // stages per 32-channel slab
   half_t* hbuf = reinterpret_cast<half_t*>(smem2);
   half_t* wring = hbuf + (size_t)c2.hbufs * c2.hbuf_halves;
   constexpr int wbuf_halves = ((KW * BN * 4 + 511) & ~511) * 8;   // whole groups of 512 DMA slots
@@ -87,7 +92,7 @@ __global__ __launch_bounds__(512, 1) void k_conv16v2(const ConvArgs2 c2) {
       for (int e = 0; e < 16; e++) acc[i][j][e] = 0.f;
 
   const int iy0 = ty0 * a.SH - a.PT, ix0 = tx0 * a.SW - a.PL;
-  const int nslab = (a.Cin + KS - 1) / KS, nrows = nslab * a.KH;
+  const int nslab = (a.Cin + KS - 1) / KS, nrows = nslab * SPS;
   const int hchunks = HH * HW * 4; constexpr int wchunks = KW * BN * 4;
   const half_t* xtile = a.x + gi.off * a.ldx + ((long long)iy0 * gi.W + ix0) * a.ldx;
   // per-thread DMA sources, computed once: slot e = tid + 512 * i of a buffer holds (row e >> 2, physical chunk e & 3),
@@ -151,7 +156,7 @@ __global__ __launch_bounds__(512, 1) void k_conv16v2(const ConvArgs2 c2) {
   const int nw = (wchunks + NTHR - 1) / NTHR, nh = (hchunks + NTHR - 1) / NTHR;   // DMA instructions per row / per halo, per thread
 
   for (int rr = 0; rr < nrows; rr++) {
-    const int s = rr / a.KH, dy = rr - s * a.KH;
+    const int s = rr / SPS, dy = rr - s * SPS;
     const int cvalid = min(KS, a.Cin - s * KS);
     const int ksteps = (cvalid + 15) >> 4;
     const bool stamp = RT_STAMP_ON(a.stamps && blockIdx.y == 0 && blockIdx.x == gridDim.x / 2 && tid == 0);
@@ -166,7 +171,7 @@ __global__ __launch_bounds__(512, 1) void k_conv16v2(const ConvArgs2 c2) {
     // tests hipcc waits lgkmcnt(0) before every MFMA group, which also waits for the prefetch just issued)
     (void)ksteps;
     constexpr int NK = KW * 2;
-    const int tap0 = dy * HW;
+    const int tap0 = dy * RG * HW;
     auto frags = [&](int it, h8 (&A)[NTN], h8 (&B)[NTP]) {
       const int dx = it >> 1, ks = it & 1;
       const int cl = ks * 2 + h;
@@ -175,7 +180,7 @@ __global__ __launch_bounds__(512, 1) void k_conv16v2(const ConvArgs2 c2) {
       for (int i = 0; i < NTN; i++) A[i] = *reinterpret_cast<const h8*>(wrow + i * 32 * ROW);
 #pragma unroll
       for (int j = 0; j < NTP; j++) {
-        const int p = pix[j] + tap0 + dx;
+        const int p = pix[j] + tap0 + (RG == 1 ? dx : (dx / KWR) * HW + dx % KWR);
         B[j] = *reinterpret_cast<const h8*>(halo + p * ROW + ((cl ^ ((p >> 2) & 3)) << 3));
       }
     };
@@ -208,7 +213,7 @@ __global__ __launch_bounds__(512, 1) void k_conv16v2(const ConvArgs2 c2) {
     if (stamp) { a.stamps[rr * 5 + 2] = __builtin_amdgcn_s_memtime(); a.stamps[rr * 5 + 3] = a.stamps[rr * 5 + 2]; }
     if (rr + 1 == nrows) break;
     // ---- the next row's data must have landed: everything except the requests made in THIS iteration ----
-    const int ns = (rr + 1) / a.KH, ndy = (rr + 1) - ns * a.KH;
+    const int ns = (rr + 1) / SPS, ndy = (rr + 1) - ns * SPS;
     if (c2.hbufs == 1 && ndy == 0) {
       // single halo buffer: every wave is done with the old tile only after the barrier; request and wait here (exposed)
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -434,8 +439,16 @@ bool conv16_dma(hipStream_t st, const ConvArgs& a0, int n_img, int maxHo, int ma
   c2.a = a0; c2.a.TH = th; c2.a.TW = tw; c2.a.lp = KS; c2.a.nzb = (Npad + bn2 - 1) / bn2;
   c2.zeros = zero_page16();
   c2.hbuf_halves = ((hpix(th, tw) * 4 + 511) & ~511) * 8;
-  c2.wslots = k9 ? 2 : 3;
-  const size_t wbytes = (size_t)((KW * bn2 * 4 + 511) & ~511) * 16 * c2.wslots;
+  // 3x3: all nine taps of a slab as ONE stage on 64-channel blocks (72 MFMAs per wave between barriers, like the 9x9 rows)
+  // where the row-wise form would run 96- or 64-channel blocks anyway (N = 64, 160, 192); with 128-channel blocks
+  // (N = 128, 224: 48 MFMAs per row and wave, weights re-read per 128 instead of 64 channels) the row-wise form measured
+  // 10-15 % faster.  RT_CONV3_GROUP=0 / 2 forces row-wise / grouped (A/B runs).
+  static const int group3 = getenv("RT_CONV3_GROUP") ? atoi(getenv("RT_CONV3_GROUP")) : 1;
+  const bool g3 = KH == 3 && KW == 3 && Npad >= 64 && (group3 == 2 || (group3 == 1 && bn2 < 128));
+  if (g3) { bn2 = 64; c2.a.nzb = (Npad + 63) / 64; }
+  const int taps = g3 ? 9 : KW;
+  c2.wslots = (k9 || g3) ? 2 : 3;
+  const size_t wbytes = (size_t)((taps * bn2 * 4 + 511) & ~511) * 16 * c2.wslots;
   c2.hbufs = (2 * (size_t)c2.hbuf_halves * 2 + wbytes <= 160 * 1024) ? 2 : 1;
   if ((size_t)c2.hbufs * c2.hbuf_halves * 2 + wbytes > 160 * 1024) return false;
   const size_t lds2 = std::max((size_t)c2.hbufs * c2.hbuf_halves * 2 + wbytes, (size_t)8 * (32 * (bn2 + 8) + 128) * 2);  // main loop | epilogue scratch
@@ -443,16 +456,17 @@ bool conv16_dma(hipStream_t st, const ConvArgs& a0, int n_img, int maxHo, int ma
   dim3 grid2((unsigned)(tiles2 * c2.a.nzb), (unsigned)n_img);
   static bool attr2 = false;
   if (!attr2) {
-    for (const void* f : {(const void*)k_conv16v2<1, 1>, (const void*)k_conv16v2<2, 1>, (const void*)k_conv16v2<3, 1>, (const void*)k_conv16v2<4, 1>,
-                          (const void*)k_conv16v2<1, 3>, (const void*)k_conv16v2<2, 3>, (const void*)k_conv16v2<3, 3>, (const void*)k_conv16v2<4, 3>,
-                          (const void*)k_conv16v2<2, 9>})
+    for (const void* f : {(const void*)k_conv16v2<1, 1, 1>, (const void*)k_conv16v2<2, 1, 1>, (const void*)k_conv16v2<3, 1, 1>, (const void*)k_conv16v2<4, 1, 1>,
+                          (const void*)k_conv16v2<1, 3, 3>, (const void*)k_conv16v2<2, 3, 3>, (const void*)k_conv16v2<3, 3, 3>, (const void*)k_conv16v2<4, 3, 3>,
+                          (const void*)k_conv16v2<2, 9, 9>, (const void*)k_conv16v2<2, 9, 3>})
       RT_HIP_CHECK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr2 = true;
   }
 #define RT_V2_LAUNCH(NT) \
-  switch (KW) { case 1: RT_LAUNCH((k_conv16v2<NT, 1>), grid2, dim3(512), lds2, st, c2); break; \
-                default: RT_LAUNCH((k_conv16v2<NT, 3>), grid2, dim3(512), lds2, st, c2); break; }
-  if (k9) { RT_LAUNCH((k_conv16v2<2, 9>), grid2, dim3(512), lds2, st, c2); return true; }
+  switch (KW) { case 1: RT_LAUNCH((k_conv16v2<NT, 1, 1>), grid2, dim3(512), lds2, st, c2); break; \
+                default: RT_LAUNCH((k_conv16v2<NT, 3, 3>), grid2, dim3(512), lds2, st, c2); break; }
+  if (k9) { RT_LAUNCH((k_conv16v2<2, 9, 9>), grid2, dim3(512), lds2, st, c2); return true; }
+  if (g3) { RT_LAUNCH((k_conv16v2<2, 9, 3>), grid2, dim3(512), lds2, st, c2); return true; }
   switch (bn2 / 32) {
     case 1: RT_V2_LAUNCH(1); break;
     case 2: RT_V2_LAUNCH(2); break;
