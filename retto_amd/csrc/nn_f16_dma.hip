@@ -40,6 +40,7 @@ struct ConvArgs2 {
   const half_t* zeros;   // >= 16 zero bytes in device memory: DMA source of padding pixels / channels
   int hbuf_halves;       // size of one halo buffer (halves, multiple of 8)
   int hbufs;             // 2: next slab's halo prefetched; 1: single buffer (large halos)
+  unsigned hw_magic, tw_magic;   // ceil(2^32 / d) for d = halo width, tile width (0: d == 1): q = umulhi(p, magic), exact for p * d < 2^32
   int wslots;            // weight ring: 3 (row r + 2 requested while row r is multiplied) or 2 (row r + 1; the 9-tap rows)
 };
 constexpr int V2_HMAX = 8;   // DMA instructions per thread for one halo tile (8 * 512 * 16 B = 64 KB)
@@ -70,11 +71,70 @@ __global__ __launch_bounds__(512, 1) void k_conv16v2(const ConvArgs2 c2) {
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
 
+  const int iy0 = ty0 * a.SH - a.PT, ix0 = tx0 * a.SW - a.PL;
+  const int nslab = (a.Cin + KS - 1) / KS, nrows = nslab * SPS;
+  const int hchunks = HH * HW * 4; constexpr int wchunks = KW * BN * 4;
+  const half_t* xtile = a.x + gi.off * a.ldx + ((long long)iy0 * gi.W + ix0) * a.ldx;
+  constexpr int WI = (KW * BN * 4 + NTHR - 1) / NTHR;   // DMA instructions per thread for a kernel row (3x3, BN 128: 3)
+  int wsrc[WI];
+#pragma unroll
+  for (int i = 0; i < WI; i++) {
+    const int e = tid + i * NTHR;
+    wsrc[i] = -1;
+    if (e < wchunks) {
+      const int row = e >> 2, cl = (e & 3) ^ ((row >> 2) & 3);
+      const int dx = row / BN, n = row - dx * BN;
+      if (nb0 + n < a.Npad) wsrc[i] = (dx * a.Npad + nb0 + n) * KS + cl * 8;
+    }
+  }
+  const size_t row_halves = (size_t)KW * a.Npad * KS;
+  const int wave_slot = wid * 64 * 8;   // halves: this wave's 64 consecutive 16-byte slots inside a group of 512
+  const int wslots = c2.wslots, D = wslots - 1;   // prefetch distance in rows
+  auto dma_wrow = [&](int rr) {         // kernel row rr -> ring slot rr % wslots
+    half_t* dst = wring + (size_t)(rr % wslots) * wbuf_halves;
+    const half_t* wg = a.w + (size_t)rr * row_halves;
+#pragma unroll
+    for (int i = 0; i < WI; i++) {
+      if (i * NTHR >= wchunks) break;   // (uniform)
+      const half_t* src = wsrc[i] >= 0 ? wg + wsrc[i] : c2.zeros;
+      RT_GLDS16(src, dst + (size_t)i * NTHR * 8 + wave_slot);
+    }
+  };
+  // prologue, ordered so that the requests are in flight while the rest of the index arithmetic runs: weight rows first
+  // (their sources are ready), then the halo sources and the halo, then the fragment offsets and the accumulators
+  dma_wrow(0);
+  if (D > 1 && nrows > 1) dma_wrow(1);
+  // per-thread DMA sources, computed once: slot e = tid + 512 * i of a buffer holds (row e >> 2, physical chunk e & 3),
+  // i.e. the logical chunk (e & 3) ^ ((row >> 2) & 3) of that row
+  int hsrc[V2_HMAX];
+#pragma unroll
+  for (int i = 0; i < V2_HMAX; i++) {
+    const int e = tid + i * NTHR;
+    hsrc[i] = -1;
+    if (e < hchunks) {
+      const int p = e >> 2, cl = (e & 3) ^ ((p >> 2) & 3);
+      const int hy = c2.hw_magic ? (int)__umulhi((unsigned)p, c2.hw_magic) : p, hx = p - hy * HW;
+      const int iy = iy0 + hy, ix = ix0 + hx;
+      if (iy >= 0 && iy < gi.H && ix >= 0 && ix < gi.W) hsrc[i] = ((hy * gi.W + hx) * a.ldx + cl * 8) | (cl << 28);
+    }
+  }
+  auto dma_halo = [&](int s) {          // slab s -> halo buffer s % hbufs
+    half_t* dst = hbuf + (size_t)(s % c2.hbufs) * c2.hbuf_halves;
+    const int cvalid = min(KS, a.Cin - s * KS);
+#pragma unroll
+    for (int i = 0; i < V2_HMAX; i++) {
+      if (i * NTHR >= hchunks) break;   // (uniform)
+      const bool ok = hsrc[i] >= 0 && (hsrc[i] >> 28) * 8 < cvalid;
+      const half_t* src = ok ? xtile + (hsrc[i] & 0x0fffffff) + s * KS : c2.zeros;
+      RT_GLDS16(src, dst + (size_t)i * NTHR * 8 + wave_slot);
+    }
+  };
+  dma_halo(0);
   int pix[NTP], oys[NTP], oxs[NTP];
 #pragma unroll
   for (int j = 0; j < NTP; j++) {
     int q = (wid * NTP + j) * 32 + r;
-    int ty = q / TW, tx = q - ty * TW;
+    int ty = c2.tw_magic ? (int)__umulhi((unsigned)q, c2.tw_magic) : q, tx = q - ty * TW;
     const bool ok = ty < TH;
     if (!ok) { ty = 0; tx = 0; }
     pix[j] = ty * a.SH * HW + tx * a.SW;   // halo pixel of tap (0, 0)
@@ -91,64 +151,6 @@ __global__ __launch_bounds__(512, 1) void k_conv16v2(const ConvArgs2 c2) {
 #pragma unroll
       for (int e = 0; e < 16; e++) acc[i][j][e] = 0.f;
 
-  const int iy0 = ty0 * a.SH - a.PT, ix0 = tx0 * a.SW - a.PL;
-  const int nslab = (a.Cin + KS - 1) / KS, nrows = nslab * SPS;
-  const int hchunks = HH * HW * 4; constexpr int wchunks = KW * BN * 4;
-  const half_t* xtile = a.x + gi.off * a.ldx + ((long long)iy0 * gi.W + ix0) * a.ldx;
-  // per-thread DMA sources, computed once: slot e = tid + 512 * i of a buffer holds (row e >> 2, physical chunk e & 3),
-  // i.e. the logical chunk (e & 3) ^ ((row >> 2) & 3) of that row
-  int hsrc[V2_HMAX];
-#pragma unroll
-  for (int i = 0; i < V2_HMAX; i++) {
-    const int e = tid + i * NTHR;
-    hsrc[i] = -1;
-    if (e < hchunks) {
-      const int p = e >> 2, cl = (e & 3) ^ ((p >> 2) & 3);
-      const int hy = p / HW, hx = p - hy * HW;
-      const int iy = iy0 + hy, ix = ix0 + hx;
-      if (iy >= 0 && iy < gi.H && ix >= 0 && ix < gi.W) hsrc[i] = ((hy * gi.W + hx) * a.ldx + cl * 8) | (cl << 28);
-    }
-  }
-  constexpr int WI = (KW * BN * 4 + NTHR - 1) / NTHR;   // DMA instructions per thread for a kernel row (3x3, BN 128: 3)
-  int wsrc[WI];
-#pragma unroll
-  for (int i = 0; i < WI; i++) {
-    const int e = tid + i * NTHR;
-    wsrc[i] = -1;
-    if (e < wchunks) {
-      const int row = e >> 2, cl = (e & 3) ^ ((row >> 2) & 3);
-      const int dx = row / BN, n = row - dx * BN;
-      if (nb0 + n < a.Npad) wsrc[i] = (dx * a.Npad + nb0 + n) * KS + cl * 8;
-    }
-  }
-  const size_t row_halves = (size_t)KW * a.Npad * KS;
-  const int wave_slot = wid * 64 * 8;   // halves: this wave's 64 consecutive 16-byte slots inside a group of 512
-  auto dma_halo = [&](int s) {          // slab s -> halo buffer s % hbufs
-    half_t* dst = hbuf + (size_t)(s % c2.hbufs) * c2.hbuf_halves;
-    const int cvalid = min(KS, a.Cin - s * KS);
-#pragma unroll
-    for (int i = 0; i < V2_HMAX; i++) {
-      if (i * NTHR >= hchunks) break;   // (uniform)
-      const bool ok = hsrc[i] >= 0 && (hsrc[i] >> 28) * 8 < cvalid;
-      const half_t* src = ok ? xtile + (hsrc[i] & 0x0fffffff) + s * KS : c2.zeros;
-      RT_GLDS16(src, dst + (size_t)i * NTHR * 8 + wave_slot);
-    }
-  };
-  const int wslots = c2.wslots, D = wslots - 1;   // prefetch distance in rows
-  auto dma_wrow = [&](int rr) {         // kernel row rr -> ring slot rr % wslots
-    half_t* dst = wring + (size_t)(rr % wslots) * wbuf_halves;
-    const half_t* wg = a.w + (size_t)rr * row_halves;
-#pragma unroll
-    for (int i = 0; i < WI; i++) {
-      if (i * NTHR >= wchunks) break;   // (uniform)
-      const half_t* src = wsrc[i] >= 0 ? wg + wsrc[i] : c2.zeros;
-      RT_GLDS16(src, dst + (size_t)i * NTHR * 8 + wave_slot);
-    }
-  };
-  // prologue: halo 0, rows 0 and 1 (and halo 1 with two buffers) in flight; wait for everything once
-  dma_halo(0);
-  dma_wrow(0);
-  if (D > 1 && nrows > 1) dma_wrow(1);
   if (kstamp) a.stamps[4001] = __builtin_amdgcn_s_memtime();
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
@@ -438,6 +440,8 @@ bool conv16_dma(hipStream_t st, const ConvArgs& a0, int n_img, int maxHo, int ma
   ConvArgs2 c2;
   c2.a = a0; c2.a.TH = th; c2.a.TW = tw; c2.a.lp = KS; c2.a.nzb = (Npad + bn2 - 1) / bn2;
   c2.zeros = zero_page16();
+  auto magic = [](int d) { return d <= 1 ? 0u : (unsigned)((1ull << 32) / (unsigned)d + 1); };
+  c2.hw_magic = magic((tw - 1) * SW + KW); c2.tw_magic = magic(tw);
   c2.hbuf_halves = ((hpix(th, tw) * 4 + 511) & ~511) * 8;
   // 3x3: all nine taps of a slab as ONE stage on 64-channel blocks (72 MFMAs per wave between barriers, like the 9x9 rows)
   // where the row-wise form would run 96- or 64-channel blocks anyway (N = 64, 160, 192); with 128-channel blocks
