@@ -35,6 +35,24 @@ __device__ __forceinline__ void glds16(const void* g, void* l) {
 #pragma clang diagnostic pop
 #define RT_GLDS16(gp, lp) glds16((gp), (lp))
 
+// Fragment reads and their waits by hand (k_gemm16p): inside a loop whose body holds branches (the counted-vmcnt switch,
+// the conditional DMA request) hipcc falls back to lgkmcnt(0) before each MFMA group even for plain ds_reads, which waits
+// for the prefetch issued just before.  As inline asm the reads are invisible to its wait-count pass; lds_wait<N>() leaves
+// the newest N reads in flight and pins the order (sched_barrier: an MFMA has no memory operand, so a "memory" clobber
+// alone does not keep it behind the wait).
+__device__ __forceinline__ unsigned lds_addr(const void* p) { return (unsigned)(size_t)(__attribute__((address_space(3))) const char*)p; }
+__device__ __forceinline__ h8 lds_read16(unsigned byte_addr) {
+  h8 v;
+  asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(byte_addr));
+  return v;
+}
+template <int N>
+__device__ __forceinline__ void lds_wait() {
+  static_assert(N >= 0 && N <= 15, "lgkmcnt is a 4-bit counter");
+  asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
+  __builtin_amdgcn_sched_barrier(0);
+}
+
 struct ConvArgs2 {
   ConvArgs a;
   const half_t* zeros;   // >= 16 zero bytes in device memory: DMA source of padding pixels / channels
@@ -404,6 +422,150 @@ static void launch_gemm16(hipStream_t st, const GemmArgs16& g, long long mtiles)
   RT_LAUNCH((k_gemm16<NTN>), dim3((unsigned)(mtiles * g.a.nzb)), dim3(512), lds, st, g);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// k_gemm16p: the same tile as k_gemm16 with the K loop pipelined ACROSS the stage boundaries.  k_gemm16 ends every
+// 64-channel stage with vmcnt(0) + barrier and then starts the next one with exposed fragment reads: the MFMA stream
+// drains once per 32 MFMAs.  Here a stage is one 32-channel slab in a ring of R buffers and the one barrier of a stage
+// sits in its MIDDLE:
+//     stage s:   reads(s, step 1) | MFMAs(s, step 0) | vmcnt: slab s + 1 landed | BARRIER | request slab s + R - 1 |
+//                reads(s + 1, step 0) | MFMAs(s, step 1)
+//   * after the barrier every wave's part of slab s + 1 is visible, so its first fragments are read before the stage ends
+//     and the MFMAs of consecutive stages follow each other without a wait for LDS;
+//   * every wave that passed the barrier has its reads of slab s - 1 back in registers (they fed MFMAs issued before it),
+//     so that buffer is free for slab s + R - 1; R - 2 slabs stay in flight across the barrier (counted vmcnt).
+// ---------------------------------------------------------------------------------------------------------------------
+template <int NTN, int R>
+__global__ __launch_bounds__(512, 1) void k_gemm16p(const GemmArgs16 g) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smemp[];
+  const ConvArgs& a = g.a;
+  constexpr int NTHR = 512, NTP = 2, BN = 64 * NTN, BP = 256, ROW = KS;
+  constexpr int XCH = BP * 4 / NTHR, WCH = (BN * 4 + NTHR - 1) / NTHR, PER = XCH + WCH;   // DMA instructions per thread and slab
+  constexpr int XHALVES = BP * ROW, WSLOTS = WCH * NTHR, STAGE = XHALVES + WSLOTS * 8;
+  const ImgGeom gi = a.gin[0], go = a.gout[0];
+  const long long M = go.W;
+  const int zb = blockIdx.x % a.nzb;
+  const long long m0 = (long long)(blockIdx.x / a.nzb) * BP;
+  if (m0 >= M) return;
+  const int nblk = zb * BN;
+  half_t* lds = reinterpret_cast<half_t*>(smemp);
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wn = wid & 1, wp = wid >> 1;
+  const int r = lane & 31, h = lane >> 5;
+  const int aswz = (r >> 2) & 3;
+  const int nb0 = nblk + wn * 32 * NTN;
+
+  const int K = a.Cin, nst = (K + KS - 1) / KS;
+  const half_t* xsrc[XCH]; int xk[XCH];
+#pragma unroll
+  for (int i = 0; i < XCH; i++) {
+    const int e = tid + i * NTHR, row = e >> 2, cl = (e & 3) ^ ((row >> 2) & 3);
+    xk[i] = cl * 8;
+    xsrc[i] = (m0 + row < M) ? a.x + (gi.off + m0 + row) * a.ldx + xk[i] : nullptr;
+  }
+  const half_t* wsrc[WCH];
+#pragma unroll
+  for (int i = 0; i < WCH; i++) {
+    const int e = tid + i * NTHR, row = e >> 2, cl = (e & 3) ^ ((row >> 2) & 3);
+    wsrc[i] = (row < BN && nblk + row < a.Npad) ? a.w + ((size_t)nblk + row) * KS + cl * 8 : nullptr;
+  }
+  const int wave_slot = wid * 64 * 8;
+  auto dma_slab = [&](int s) {
+    half_t* dst = lds + (size_t)(s % R) * STAGE + wave_slot;
+    const int k0 = s * KS;
+#pragma unroll
+    for (int i = 0; i < XCH; i++) {
+      const half_t* src = (xsrc[i] && k0 + xk[i] < K) ? xsrc[i] + k0 : g.zeros;
+      RT_GLDS16(src, dst + (size_t)i * NTHR * 8);
+    }
+#pragma unroll
+    for (int i = 0; i < WCH; i++) {
+      const half_t* src = wsrc[i] ? wsrc[i] + (size_t)s * a.Npad * KS : g.zeros;
+      RT_GLDS16(src, dst + XHALVES + (size_t)i * NTHR * 8);
+    }
+  };
+  auto wait_keep = [&](int slabs) {   // leave the newest `slabs` slabs in flight
+    switch (slabs * PER) {
+      case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+      case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+      case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+      case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+      case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+      case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+      case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+      default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    }
+  };
+  // prologue: slabs 0 .. R - 2 requested, slab 0 landed and visible
+#pragma unroll
+  for (int s = 0; s < R - 1; s++)
+    if (s < nst) dma_slab(s);
+  f32x16 acc[NTN][NTP];
+#pragma unroll
+  for (int i = 0; i < NTN; i++)
+#pragma unroll
+    for (int j = 0; j < NTP; j++)
+#pragma unroll
+      for (int e = 0; e < 16; e++) acc[i][j][e] = 0.f;
+  wait_keep(max(0, min(nst - 1, R - 2)));
+  __builtin_amdgcn_s_barrier();
+
+  constexpr int NR = NTN + NTP;   // ds_read_b128 per k-step
+  const unsigned lds0 = lds_addr(lds);
+  const unsigned xoff = (unsigned)((wp * 64 + r) * ROW * 2), woff = (unsigned)((XHALVES + (wn * 32 * NTN + r) * ROW) * 2);
+  auto frags = [&](int s, int ks, h8 (&A)[NTN], h8 (&B)[NTP]) {
+    const unsigned base = lds0 + (unsigned)(s % R) * (STAGE * 2) + ((unsigned)((ks * 2 + h) ^ aswz) << 4);
+#pragma unroll
+    for (int j = 0; j < NTP; j++) B[j] = lds_read16(base + xoff + j * 32 * ROW * 2);
+#pragma unroll
+    for (int i = 0; i < NTN; i++) A[i] = lds_read16(base + woff + i * 32 * ROW * 2);
+  };
+  auto mfmas = [&](const h8 (&A)[NTN], const h8 (&B)[NTP]) {
+#pragma unroll
+    for (int i = 0; i < NTN; i++)
+#pragma unroll
+      for (int j = 0; j < NTP; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[i], B[j], acc[i][j], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  h8 A0[NTN], B0[NTP], A1[NTN], B1[NTP];
+  frags(0, 0, A0, B0);
+  for (int s = 0; s + 1 < nst; s++) {
+    frags(s, 1, A1, B1);
+    lds_wait<NR>();                                          // step 0's fragments are back, step 1's stay in flight
+    mfmas(A0, B0);
+    wait_keep(max(0, min(nst - 1, s + R - 2) - (s + 1)));   // slab s + 1 has landed (this wave's requests)
+    __builtin_amdgcn_s_barrier();                            // ... and everybody's; every wave is done with slab s - 1
+    if (s + R - 1 < nst) dma_slab(s + R - 1);
+    __builtin_amdgcn_sched_barrier(0);
+    frags(s + 1, 0, A0, B0);
+    lds_wait<NR>();
+    mfmas(A1, B1);
+  }
+  frags(nst - 1, 1, A1, B1);
+  lds_wait<NR>();
+  mfmas(A0, B0);
+  lds_wait<0>();
+  mfmas(A1, B1);
+  __builtin_amdgcn_s_barrier();   // every wave is done with the ring: it becomes the transpose scratch
+  int oys[NTP], oxs[NTP];
+#pragma unroll
+  for (int j = 0; j < NTP; j++) {
+    const long long m = m0 + wp * 64 + j * 32 + r;
+    oys[j] = m < M ? 0 : -1;
+    oxs[j] = (int)m;
+  }
+  store_tile16<NTN, NTP>(a, acc, lds + (size_t)wid * epi_scratch_halves<NTN>(), lane, nb0, oys, oxs, go);
+}
+
+template <int NTN, int R>
+static void launch_gemm16p(hipStream_t st, const GemmArgs16& g, long long mtiles) {
+  constexpr int WCH = (64 * NTN * 4 + 511) / 512;
+  constexpr size_t lds = (size_t)R * (256 * KS + WCH * 512 * 8) * 2;
+  static_assert(lds <= 160 * 1024 && lds >= (size_t)8 * (32 * (32 * NTN + 8) + 128) * 2, "ring within LDS, epilogue scratch within the ring");
+  static bool attr = false;
+  if (!attr) { RT_HIP_CHECK(hipFuncSetAttribute((const void*)k_gemm16p<NTN, R>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr = true; }
+  RT_LAUNCH((k_gemm16p<NTN, R>), dim3((unsigned)(mtiles * g.a.nzb)), dim3(512), lds, st, g);
+}
+
 bool conv16_dma(hipStream_t st, const ConvArgs& a0, int n_img, int maxHo, int maxWo) {
   const int KH = a0.KH, KW = a0.KW, SH = a0.SH, SW = a0.SW, Npad = a0.Npad, Cin = a0.Cin;
   // ---- 1x1 over one flat image: k_gemm16 when the channel blocks of 256 / 128 waste little ----
@@ -416,7 +578,10 @@ bool conv16_dma(hipStream_t st, const ConvArgs& a0, int n_img, int maxHo, int ma
       g.a = a0; g.a.nzb = (Npad + bn - 1) / bn; g.zeros = zero_page16();
       const long long mtiles = ((long long)maxWo + 255) / 256;
       if (mtiles * g.a.nzb < (1ll << 31)) {
-        if (bn == 256) launch_gemm16<4>(st, g, mtiles); else launch_gemm16<2>(st, g, mtiles);
+        static const int pipe = getenv("RT_GEMM16_PIPE") ? atoi(getenv("RT_GEMM16_PIPE")) : 4;   // 0: k_gemm16; 4 / 5: k_gemm16p ring depth
+        if (pipe == 0) { if (bn == 256) launch_gemm16<4>(st, g, mtiles); else launch_gemm16<2>(st, g, mtiles); }
+        else if (pipe == 4) { if (bn == 256) launch_gemm16p<4, 4>(st, g, mtiles); else launch_gemm16p<2, 4>(st, g, mtiles); }
+        else { if (bn == 256) launch_gemm16p<4, 5>(st, g, mtiles); else launch_gemm16p<2, 5>(st, g, mtiles); }
         return true;
       }
     }
