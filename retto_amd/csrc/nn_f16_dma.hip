@@ -64,6 +64,9 @@ struct ConvArgs2 {
 constexpr int V2_HMAX = 8;   // DMA instructions per thread for one halo tile (8 * 512 * 16 B = 64 KB)
 
 // KW = taps per stage (RG kernel rows of KWR taps each: KW = RG * KWR); KWR = the real kernel width
+// (The cross-stage pipelining of k_gemm16p -- barrier in the middle of a stage, the next stage's first fragments read before
+// the stage ends -- was built for the row-wise 3x3 form too and measured 4 % SLOWER (43.8 vs 41.9 ms per C5 step): the row
+// and halo requests then have one stage less to land than with the barrier at the end of the stage.)
 template <int NTN, int KW, int KWR>
 __global__ __launch_bounds__(512, 1) void k_conv16v2(const ConvArgs2 c2) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem2[];
