@@ -142,6 +142,8 @@ class OracleSession:
         boxes_after = boxes.copy()
         boxes_ori = np.stack([R.scale_and_clip(b, after_w, after_h, ori_w, ori_h) for b in boxes]) \
             if len(boxes) else boxes.reshape(0, 4, 2)
+        self._cls_margins = np.zeros(len(crops), np.float32)   # (a test may swap cls_process / rec_process for its own)
+        self._rec_margins = [0.0] * len(crops)
         labels, cscores = self.cls_process(crops, dims)
         toks, rscores, widths = self.rec_process(crops, dims)
         text = ["".join(self.dict[t] for t in tk) for tk in toks]
