@@ -21,6 +21,7 @@ python3 tools/pmc_summary.py $out/c3_fetch/f_counter_collection.csv $out/c3_writ
 python3 tools/pmc_summary.py $out/c5_fetch/f_counter_collection.csv $out/c5_write/w_counter_collection.csv $out/pmc_traffic_c5.json $out/c5_sq/s_counter_collection.csv '{"workload": "c5", "pages": 128, "size": 960, "lines": 32, "dtype": "f16", "models": "server"}' > $out/pmc_c5.txt
 RT_PROFILE_DETAIL=1 python3 tools/layer_profile.py 32 3 > $out/c3_layers.txt 2>&1
 RT_PROFILE_DETAIL=1 python3 tools/layer_profile.py 32 3 0 > $out/c3_det_layers.txt 2>&1
+WORKLOAD=c5 RT_PROFILE_DETAIL=1 python3 tools/layer_profile.py 32 3 > $out/c5_layers.txt 2>&1
 cp $out/c3_trace/t_kernel_stats.csv $out/c3_kernel_stats.csv 2>/dev/null
 cp $out/c5_trace/t_kernel_stats.csv $out/c5_kernel_stats.csv 2>/dev/null
 ls $out

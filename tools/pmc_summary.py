@@ -49,7 +49,11 @@ def agg_multi(path):
 LABELS = {"gemm_pw/k_gemm_wide<4,5,4,3>": "k_gemm_wide<4, 5, 4, 3, 0, 0, 0, 0, 0>",
           "gemm_pw/k_gemm_wide<2,5,4,3>+se": "k_gemm_wide<2, 5, 4, 3, 0, 0, 1, 0, 0>",
           "gemm_pw/k_gemm_wide<2,4,4,2>": "k_gemm_wide<2, 4, 4, 2, 0, 0, 0, 0, 0>",
-          "conv16_3x3": "k_conv16<4, 2, 1, 4, 0>", "gemm16": "k_conv16<4, 2, 1, 4, 0>"}
+          "conv16_3x3": "family:conv16_3x3", "gemm16": "family:gemm16", "conv16_9x9": "family:conv16_9x9"}
+# fp16 families that several template instances serve: their "family:<name>" entry is the launch-weighted mean over the
+# member kernels (traffic per launch) and the cycle-weighted MFMA utilisation.  (The 3x3 family's few register-staged
+# launches -- the 3-channel stems -- run k_conv16 instances shared with other families and are left out.)
+FAMILIES = {"conv16_3x3": r"k_conv16v2<\d, (3, 3|9, 3)>", "gemm16": r"k_gemm16p?<", "conv16_9x9": r"k_conv16v2<2, 9, 9>"}
 
 
 def main():
@@ -78,6 +82,25 @@ def main():
             "wave_wait_any_frac": round(avg.get("SQ_WAIT_ANY", 0.0) / max(avg.get("SQ_WAVE_CYCLES", 1.0), 1.0), 3),
             "wave_wait_inst_frac": round(avg.get("SQ_WAIT_INST_ANY", 0.0) / max(avg.get("SQ_WAVE_CYCLES", 1.0), 1.0), 3),
             "wave_active_inst_frac": round(avg.get("SQ_ACTIVE_INST_ANY", 0.0) / max(avg.get("SQ_WAVE_CYCLES", 1.0), 1.0), 3)}
+    for fam, pat in FAMILIES.items():
+        mem = {k: v for k, v in res.items() if re.match(pat, k)}
+        n = sum(v["launches"] for v in mem.values())
+        if not n:
+            continue
+        e = {"launches": n, "members": sorted(mem),
+             "fetch_bytes_per_launch": int(sum(v["fetch_bytes_per_launch"] * v["launches"] for v in mem.values()) / n),
+             "write_bytes_per_launch": int(sum(v["write_bytes_per_launch"] * v["launches"] for v in mem.values()) / n)}
+        sqm = [(k, v["sq"]) for k, v in mem.items() if "sq" in v]
+        if sqm:
+            # weights: each member's share of the family's GPU cycles (launches x cycles per launch of the SQ pass)
+            cyc = {}
+            for k0, ctrs in sq.items():
+                if short(k0) in mem and "GRBM_GUI_ACTIVE" in ctrs:
+                    cyc[short(k0)] = ctrs["GRBM_GUI_ACTIVE"][1]
+            tot = sum(cyc.get(k, 0.0) for k, _ in sqm) or 1.0
+            e["sq"] = {"mfma_util": round(sum(q["mfma_util"] * cyc.get(k, 0.0) for k, q in sqm) / tot, 4),
+                       "clock_ghz": round(sum(q["clock_ghz"] * cyc.get(k, 0.0) for k, q in sqm) / tot, 3)}
+        res["family:" + fam] = e
     top = dict(sorted(res.items(), key=lambda kv: -(kv[1]["fetch_bytes_per_launch"] + kv[1]["write_bytes_per_launch"]) * kv[1]["launches"])[:40])
     json.dump({"command": "bench.py --steps 2 --warmup 2 --no-cpu-baseline --lanes 1 (+ the workload flags below), separate --pmc FETCH_SIZE / --pmc WRITE_SIZE passes",
                "workload": wl, "csrc_digest": _lib.source_digest(), "labels": LABELS,
