@@ -256,6 +256,8 @@ def run_torch_server(det_b, cls_b, rec_b, dict_b, pages, maps, budget_s=20.0, de
     import torch
     from oracle import nets_torch as N
     from oracle.pipeline import OracleSession
+    cpus = host_cpus()
+    torch.set_num_threads(cpus)   # the CPUs this process may use (cgroup quota), not the 128+ threads torch picks from the host's count
     o = OracleSession(det_b, cls_b, rec_b, dict_b)
     o.det_worker = lambda t: N.sdet_forward(o.wd, torch.from_numpy(t)).numpy()
     o.rec_worker = lambda t: N.srec_forward(o.wr, torch.from_numpy(t)).numpy()
@@ -266,8 +268,9 @@ def run_torch_server(det_b, cls_b, rec_b, dict_b, pages, maps, budget_s=20.0, de
         i = len(rates) % len(pages)
         t1 = time.perf_counter(); o.run(pages[i], det_map_override=maps[i]); rates.append(1.0 / (time.perf_counter() - t1))
     return {"value": round(float(np.median(rates)), 4), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": "%s through oracle/pipeline.py on torch-CPU fp32 (server graphs of oracle/nets_torch.py, oneDNN, %d threads, one page at a "
-                      "time) + C++ pre/post: 1 warm-up page, %d timed page(s), median" % (describe, torch.get_num_threads(), len(rates)),
+            "sample": "%s through oracle/pipeline.py on torch-CPU fp32 (server graphs of oracle/nets_torch.py, oneDNN, %d threads = the CPUs "
+                      "this process may use (affinity mask capped by the cgroup quota), one page at a time) + C++ pre/post: 1 warm-up page, "
+                      "%d timed page(s), median" % (describe, torch.get_num_threads(), len(rates)),
             "nproc": os.cpu_count()}
 
 
