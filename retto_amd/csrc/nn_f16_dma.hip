@@ -573,18 +573,28 @@ bool conv16_dma(hipStream_t st, const ConvArgs& a0, int n_img, int maxHo, int ma
   const int KH = a0.KH, KW = a0.KW, SH = a0.SH, SW = a0.SW, Npad = a0.Npad, Cin = a0.Cin;
   // ---- 1x1 over one flat image: k_gemm16 when the channel blocks of 256 / 128 waste little ----
   if (KH == 1 && KW == 1 && SH == 1 && SW == 1 && a0.PT == 0 && a0.PL == 0 && n_img == 1 && maxHo == 1 && Cin >= 64 && maxWo >= 4096) {
-    int bn = 0;
-    if (Npad % 256 == 0 || Npad >= 1024) bn = 256;
-    else if (Npad % 128 == 0) bn = 128;
+    // channel block of 64 * NTN with the least padded work; taken when at most 10 % of the block columns are padding
+    // (N = 480 -> 2 x 256, 240 -> 256, 384 -> 2 x 192; 96 or 160 stay with k_conv16's 96 / 160-wide blocks)
+    int bn = 0, best = 1 << 30;
+    for (int cand : {256, 192, 128, 64}) {
+      const int cost = (Npad + cand - 1) / cand * cand;
+      if (cost < best) { best = cost; bn = cand; }
+    }
+    if (best * 10 > a0.N * 11) bn = 0;
     if (bn) {
       GemmArgs16 g;
       g.a = a0; g.a.nzb = (Npad + bn - 1) / bn; g.zeros = zero_page16();
       const long long mtiles = ((long long)maxWo + 255) / 256;
       if (mtiles * g.a.nzb < (1ll << 31)) {
-        static const int pipe = getenv("RT_GEMM16_PIPE") ? atoi(getenv("RT_GEMM16_PIPE")) : 4;   // 0: k_gemm16; 4 / 5: k_gemm16p ring depth
-        if (pipe == 0) { if (bn == 256) launch_gemm16<4>(st, g, mtiles); else launch_gemm16<2>(st, g, mtiles); }
-        else if (pipe == 4) { if (bn == 256) launch_gemm16p<4, 4>(st, g, mtiles); else launch_gemm16p<2, 4>(st, g, mtiles); }
-        else { if (bn == 256) launch_gemm16p<4, 5>(st, g, mtiles); else launch_gemm16p<2, 5>(st, g, mtiles); }
+        static const int pipe = getenv("RT_GEMM16_PIPE") ? atoi(getenv("RT_GEMM16_PIPE")) : 4;   // 0: k_gemm16 (64-deep stages, 256 / 128 only); 4 / 5: k_gemm16p ring depth
+        if (pipe == 0 && (bn == 256 || bn == 128)) { if (bn == 256) launch_gemm16<4>(st, g, mtiles); else launch_gemm16<2>(st, g, mtiles); }
+        else if (pipe == 5) {
+          switch (bn / 64) { case 4: launch_gemm16p<4, 5>(st, g, mtiles); break; case 3: launch_gemm16p<3, 5>(st, g, mtiles); break;
+                             case 2: launch_gemm16p<2, 5>(st, g, mtiles); break; default: launch_gemm16p<1, 5>(st, g, mtiles); break; }
+        } else {
+          switch (bn / 64) { case 4: launch_gemm16p<4, 4>(st, g, mtiles); break; case 3: launch_gemm16p<3, 4>(st, g, mtiles); break;
+                             case 2: launch_gemm16p<2, 4>(st, g, mtiles); break; default: launch_gemm16p<1, 4>(st, g, mtiles); break; }
+        }
         return true;
       }
     }
