@@ -97,6 +97,20 @@ __device__ __forceinline__ void store_tile16_t(const ConvArgs& a, const f32x16 (
   const bool has_lab = e.has_lab != 0;
   long long* ptab = reinterpret_cast<long long*>(scratch + 32 * PITCH);
   const bool has_bias = e.bias != nullptr;
+  // this lane's bias values, loaded once up front (all 4 * NTN loads in flight together; inside the element loops each load
+  // is waited for where it is used and the epilogue of a 512 x 128 tile doubles).  5-fragment tiles (k_conv16 only) have
+  // no registers left for them.
+  constexpr bool PRE = NTN <= 4;
+  f32x4 bv[PRE ? NTN : 1][4];
+  if (PRE) {
+#pragma unroll
+    for (int i = 0; i < NTN; i++)
+#pragma unroll
+      for (int g = 0; g < 4; g++) {
+        const int n = nb0 + i * 32 + 8 * g + 4 * h;
+        bv[PRE ? i : 0][g] = (has_bias && n < a.Npad) ? *reinterpret_cast<const f32x4*>(e.bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+  }
 #pragma unroll
   for (int j = 0; j < NTP; j++) {
     const int oy = oys[j], ox = oxs[j];
@@ -112,7 +126,8 @@ __device__ __forceinline__ void store_tile16_t(const ConvArgs& a, const f32x16 (
         f32x4 v;
 #pragma unroll
         for (int t = 0; t < 4; t++) v[t] = acc[i][j][4 * g + t];
-        if (has_bias && (!EDGE || n < a.Npad)) v += *reinterpret_cast<const f32x4*>(e.bias + n);
+        if (PRE) v += bv[PRE ? i : 0][g];
+        else if (has_bias && (!EDGE || n < a.Npad)) v += *reinterpret_cast<const f32x4*>(e.bias + n);
 #pragma unroll
         for (int t = 0; t < 4; t++) v[t] = act_c<ACT>(v[t]);
         if (has_lab) {   // (uniform; LAB follows an activation in the PPLCNet blocks only)
