@@ -173,48 +173,11 @@ __global__ __launch_bounds__(64 * WN * WP, 2) void k_conv16(const ConvArgs a) {
   }
 
   // ---- epilogue: lane = one pixel (column r of the tile), registers = channels (reg & 3) + 8 * (reg >> 2) + 4 * h ----
-  const Epi16& e = a.epi;
+  static_assert(WN == 1, "the epilogue assumes that a wave holds all BN channels of its pixels");
   if (DOT) {
-    // (activation resolved once per workgroup, as in store_tile16: a run-time switch per element is a scalar branch each)
-    auto dot_epi = [&](auto actc) {
-      constexpr int ACT = decltype(actc)::value;
-#pragma unroll
-      for (int j = 0; j < NTP; j++) {
-        float sdot = 0.f;
-#pragma unroll
-        for (int i = 0; i < NTN; i++)
-#pragma unroll
-          for (int g = 0; g < 4; g++) {
-            const int n = (wn * NTN + i) * 32 + 8 * g + 4 * h;
-            f32x4 v;
-#pragma unroll
-            for (int t = 0; t < 4; t++) v[t] = acc[i][j][4 * g + t];
-            if (e.bias) v += *reinterpret_cast<const f32x4*>(e.bias + n);
-            const f32x4 dw = *reinterpret_cast<const f32x4*>(e.dot_w + n);  // dot_w is zero beyond N
-#pragma unroll
-            for (int t = 0; t < 4; t++) sdot = fmaf(act_c<ACT>(v[t]), dw[t], sdot);
-          }
-        sdot += __shfl_xor(sdot, 32);
-        if (h == 0 && oys[j] >= 0) {
-          const int oy = oys[j], ox = oxs[j];
-          if (oy < go.H && ox < go.W) {
-            const ImgGeom gm = e.gmap[blockIdx.y];
-            float* m = e.dot_map + gm.off + (long long)(2 * oy + e.dot_py) * gm.W + 2 * ox + e.dot_px;
-            *m = 0.5f * (*m + 1.f / (1.f + __expf(-(sdot + e.dot_b))));
-          }
-        }
-      }
-    };
-    switch (e.act) {
-      case ACT_RELU: dot_epi(std::integral_constant<int, ACT_RELU>{}); break;
-      case ACT_HSWISH: dot_epi(std::integral_constant<int, ACT_HSWISH>{}); break;
-      case ACT_SWISH: dot_epi(std::integral_constant<int, ACT_SWISH>{}); break;
-      case ACT_SIGMOID: dot_epi(std::integral_constant<int, ACT_SIGMOID>{}); break;
-      default: dot_epi(std::integral_constant<int, ACT_NONE>{}); break;
-    }
+    dot_tile16<NTN, NTP>(a, acc, lane, oys, oxs, go, (int)blockIdx.y);
     return;
   }
-  static_assert(WN == 1, "the epilogue assumes that a wave holds all BN channels of its pixels");
   __syncthreads();   // every wave is done with the last stage's LDS: it becomes the waves' transpose scratch
   store_tile16<NTN, NTP>(a, acc, reinterpret_cast<half_t*>(smem) + (size_t)wid * epi_scratch_halves<NTN * WN>(), lane, nb0, oys, oxs, go);
 }
@@ -287,7 +250,7 @@ void conv16(hipStream_t st, const half_t* x, int ldx, const ImgGeom* gin, const 
   a.lp = round_up(std::min(Cin, KS), 16) + 8;  // whole 16-deep k-steps of real (zero-filled) data + one pad chunk
   const bool dot = epi.dot_w != nullptr;
   // ---- LDS-DMA kernels (nn_f16_dma.hip): the 3x3-class layers and the big 1x1 layers ----
-  if (g_conv16_v2 && !dot && conv16_dma(st, a, n_img, maxHo, maxWo)) return;
+  if (g_conv16_v2 && conv16_dma(st, a, n_img, maxHo, maxWo)) return;
   int bn = dot ? Npad : choose_bn(Npad);
   if (dot && Npad > 160) throw RtError(8, "conv16: the dot epilogue needs all output channels in one block (N <= 160)");
   choose_tile(maxHo, maxWo, &a.TH, &a.TW);

@@ -4,6 +4,8 @@
 #pragma once
 #include "nn_f16.h"
 
+#include <type_traits>
+
 namespace rt {
 namespace nh {
 
@@ -184,6 +186,52 @@ __device__ __forceinline__ void store_tile16(const ConvArgs& a, const f32x16 (&a
     case ACT_SWISH: store_tile16_a<NTN, NTP, ACT_SWISH>(a, acc, scratch, lane, nb0, oys, oxs, go); break;
     case ACT_SIGMOID: store_tile16_a<NTN, NTP, ACT_SIGMOID>(a, acc, scratch, lane, nb0, oys, oxs, go); break;
     default: store_tile16_a<NTN, NTP, ACT_NONE>(a, acc, scratch, lane, nb0, oys, oxs, go); break;
+  }
+}
+
+// DOT epilogue (PFHeadLocal): the 64 -> 1 conv over the activated channels of a pixel, sigmoid, and 0.5 * (map + .) into
+// the fp32 probability map at phase (dot_py, dot_px) of the 2x up-sampled grid.  The block holds ALL output channels.
+template <int NTN, int NTP>
+__device__ __forceinline__ void dot_tile16(const ConvArgs& a, const f32x16 (&acc)[NTN][NTP], int lane, const int (&oys)[NTP],
+                                           const int (&oxs)[NTP], const ImgGeom& go, int img) {
+  const Epi16& e = a.epi;
+  const int h = lane >> 5;
+  // (activation resolved once per workgroup, as in store_tile16: a run-time switch per element is a scalar branch each)
+  auto dot_epi = [&](auto actc) {
+    constexpr int ACT = decltype(actc)::value;
+#pragma unroll
+    for (int j = 0; j < NTP; j++) {
+      float sdot = 0.f;
+#pragma unroll
+      for (int i = 0; i < NTN; i++)
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+          const int n = i * 32 + 8 * g + 4 * h;
+          f32x4 v;
+#pragma unroll
+          for (int t = 0; t < 4; t++) v[t] = acc[i][j][4 * g + t];
+          if (e.bias) v += *reinterpret_cast<const f32x4*>(e.bias + n);
+          const f32x4 dw = *reinterpret_cast<const f32x4*>(e.dot_w + n);  // dot_w is zero beyond N
+#pragma unroll
+          for (int t = 0; t < 4; t++) sdot = fmaf(act_c<ACT>(v[t]), dw[t], sdot);
+        }
+      sdot += __shfl_xor(sdot, 32);
+      if (h == 0 && oys[j] >= 0) {
+        const int oy = oys[j], ox = oxs[j];
+        if (oy < go.H && ox < go.W) {
+          const ImgGeom gm = e.gmap[img];
+          float* m = e.dot_map + gm.off + (long long)(2 * oy + e.dot_py) * gm.W + 2 * ox + e.dot_px;
+          *m = 0.5f * (*m + 1.f / (1.f + __expf(-(sdot + e.dot_b))));
+        }
+      }
+    }
+  };
+  switch (e.act) {
+    case ACT_RELU: dot_epi(std::integral_constant<int, ACT_RELU>{}); break;
+    case ACT_HSWISH: dot_epi(std::integral_constant<int, ACT_HSWISH>{}); break;
+    case ACT_SWISH: dot_epi(std::integral_constant<int, ACT_SWISH>{}); break;
+    case ACT_SIGMOID: dot_epi(std::integral_constant<int, ACT_SIGMOID>{}); break;
+    default: dot_epi(std::integral_constant<int, ACT_NONE>{}); break;
   }
 }
 

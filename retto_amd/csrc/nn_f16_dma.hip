@@ -67,7 +67,7 @@ constexpr int V2_HMAX = 8;   // DMA instructions per thread for one halo tile (8
 // (The cross-stage pipelining of k_gemm16p -- barrier in the middle of a stage, the next stage's first fragments read before
 // the stage ends -- was built for the row-wise 3x3 form too and measured 4 % SLOWER (43.8 vs 41.9 ms per C5 step): the row
 // and halo requests then have one stage less to land than with the barrier at the end of the stage.)
-template <int NTN, int KW, int KWR>
+template <int NTN, int KW, int KWR, int DOT = 0>
 __global__ __launch_bounds__(512, 1) void k_conv16v2(const ConvArgs2 c2) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem2[];
   const ConvArgs& a = c2.a;
@@ -269,6 +269,10 @@ __global__ __launch_bounds__(512, 1) void k_conv16v2(const ConvArgs2 c2) {
     if (stamp) a.stamps[rr * 5 + 4] = __builtin_amdgcn_s_memtime();
   }
 
+  if (DOT) {   // PFHeadLocal's phase convs: the block holds all (64) channels, nothing goes through LDS
+    dot_tile16<NTN, NTP>(a, acc, lane, oys, oxs, go, (int)blockIdx.y);
+    return;
+  }
   if (kstamp) a.stamps[4003] = __builtin_amdgcn_s_memtime();
   __builtin_amdgcn_s_barrier();   // every wave is done with the last stage's LDS (no DMA is in flight any more)
   if (kstamp) a.stamps[4005] = __builtin_amdgcn_s_memtime();
@@ -572,7 +576,7 @@ static void launch_gemm16p(hipStream_t st, const GemmArgs16& g, long long mtiles
 bool conv16_dma(hipStream_t st, const ConvArgs& a0, int n_img, int maxHo, int maxWo) {
   const int KH = a0.KH, KW = a0.KW, SH = a0.SH, SW = a0.SW, Npad = a0.Npad, Cin = a0.Cin;
   // ---- 1x1 over one flat image: k_gemm16 when the channel blocks of 256 / 128 waste little ----
-  if (KH == 1 && KW == 1 && SH == 1 && SW == 1 && a0.PT == 0 && a0.PL == 0 && n_img == 1 && maxHo == 1 && Cin >= 64 && maxWo >= 4096) {
+  if (KH == 1 && KW == 1 && SH == 1 && SW == 1 && a0.PT == 0 && a0.PL == 0 && n_img == 1 && maxHo == 1 && Cin >= 64 && maxWo >= 4096 && !a0.epi.dot_w) {
     // channel block of 64 * NTN with the least padded work; taken when at most 10 % of the block columns are padding
     // (N = 480 -> 2 x 256, 240 -> 256, 384 -> 2 x 192; 96 or 160 stay with k_conv16's 96 / 160-wide blocks)
     int bn = 0, best = 1 << 30;
@@ -601,8 +605,11 @@ bool conv16_dma(hipStream_t st, const ConvArgs& a0, int n_img, int maxHo, int ma
     return false;
   }
   // ---- the 3x3-class layers ----
-  const bool k9 = KH == 9 && KW == 9 && SH == 1 && SW == 1 && Npad == 64;   // LKPAN's 9x9 layers (256 -> 64, 64 -> 64)
-  if (!(((KH <= 3 && (KW == 1 || KW == 3) && KH * KW > 1) || k9) && Cin >= 32 && n_img <= RT_MAX_GRID_Y)) return false;
+  const bool dot = a0.epi.dot_w != nullptr;
+  const bool k9 = !dot && KH == 9 && KW == 9 && SH == 1 && SW == 1 && Npad == 64;   // LKPAN's 9x9 layers (256 -> 64, 64 -> 64)
+  const bool k22 = dot && KH == 2 && KW == 2 && SH == 1 && SW == 1 && Npad == 64;   // PFHeadLocal's 2x2 phase convs with the dot epilogue
+  if (dot && !k22) return false;
+  if (!(((KH <= 3 && (KW == 1 || KW == 3) && KH * KW > 1) || k9 || k22) && Cin >= 32 && n_img <= RT_MAX_GRID_Y)) return false;
   int bn2 = 32, best = 1 << 30;
   for (int bn : {128, 96, 64, 32}) {
     const int nb = (Npad + bn - 1) / bn, cost = nb * bn + 16 * nb;
@@ -628,7 +635,7 @@ bool conv16_dma(hipStream_t st, const ConvArgs& a0, int n_img, int maxHo, int ma
   static const int group3 = getenv("RT_CONV3_GROUP") ? atoi(getenv("RT_CONV3_GROUP")) : 1;
   const bool g3 = KH == 3 && KW == 3 && Npad >= 64 && (group3 == 2 || (group3 == 1 && bn2 < 128));
   if (g3) { bn2 = 64; c2.a.nzb = (Npad + 63) / 64; }
-  const int taps = g3 ? 9 : KW;
+  const int taps = g3 ? 9 : (k22 ? 4 : KW);
   c2.wslots = (k9 || g3) ? 2 : 3;
   const size_t wbytes = (size_t)((taps * bn2 * 4 + 511) & ~511) * 16 * c2.wslots;
   c2.hbufs = (2 * (size_t)c2.hbuf_halves * 2 + wbytes <= 160 * 1024) ? 2 : 1;
@@ -640,7 +647,7 @@ bool conv16_dma(hipStream_t st, const ConvArgs& a0, int n_img, int maxHo, int ma
   if (!attr2) {
     for (const void* f : {(const void*)k_conv16v2<1, 1, 1>, (const void*)k_conv16v2<2, 1, 1>, (const void*)k_conv16v2<3, 1, 1>, (const void*)k_conv16v2<4, 1, 1>,
                           (const void*)k_conv16v2<1, 3, 3>, (const void*)k_conv16v2<2, 3, 3>, (const void*)k_conv16v2<3, 3, 3>, (const void*)k_conv16v2<4, 3, 3>,
-                          (const void*)k_conv16v2<2, 9, 9>, (const void*)k_conv16v2<2, 9, 3>})
+                          (const void*)k_conv16v2<2, 9, 9>, (const void*)k_conv16v2<2, 9, 3>, (const void*)k_conv16v2<2, 4, 2, 1>})
       RT_HIP_CHECK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr2 = true;
   }
@@ -649,6 +656,7 @@ bool conv16_dma(hipStream_t st, const ConvArgs& a0, int n_img, int maxHo, int ma
                 default: RT_LAUNCH((k_conv16v2<NT, 3, 3>), grid2, dim3(512), lds2, st, c2); break; }
   if (k9) { RT_LAUNCH((k_conv16v2<2, 9, 9>), grid2, dim3(512), lds2, st, c2); return true; }
   if (g3) { RT_LAUNCH((k_conv16v2<2, 9, 3>), grid2, dim3(512), lds2, st, c2); return true; }
+  if (k22) { RT_LAUNCH((k_conv16v2<2, 4, 2, 1>), grid2, dim3(512), lds2, st, c2); return true; }
   switch (bn2 / 32) {
     case 1: RT_V2_LAUNCH(1); break;
     case 2: RT_V2_LAUNCH(2); break;
