@@ -53,7 +53,7 @@ LABELS = {"gemm_pw/k_gemm_wide<4,5,4,3>": "k_gemm_wide<4, 5, 4, 3, 0, 0, 0, 0, 0
 # fp16 families that several template instances serve: their "family:<name>" entry is the launch-weighted mean over the
 # member kernels (traffic per launch) and the cycle-weighted MFMA utilisation.  (The 3x3 family's few register-staged
 # launches -- the 3-channel stems -- run k_conv16 instances shared with other families and are left out.)
-FAMILIES = {"conv16_3x3": r"k_conv16v2<\d, (3, 3|9, 3)>", "gemm16": r"k_gemm16p?<", "conv16_9x9": r"k_conv16v2<2, 9, 9>"}
+FAMILIES = {"conv16_3x3": r"k_conv16v2<\d, (3, 3|9, 3)(, 0)?>", "gemm16": r"k_gemm16p?<", "conv16_9x9": r"k_conv16v2<2, 9, 9(, 0)?>"}
 
 
 def main():
