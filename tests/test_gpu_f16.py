@@ -115,6 +115,32 @@ def test_conv16_kernel(hip16, n, cin, cout, k, stride, hw, act):
     assert (err <= tol).all(), f"max err {err.max()} at {np.unravel_index(err.argmax(), err.shape)} (ref {ref.flat[err.argmax()]})"
 
 
+@pytest.mark.parametrize("n,cin,cout,k,hw", [
+    (8, 128, 128, (3, 3), (120, 120)),     # row-wise LDS-DMA form: ring of 3 weight rows, two halo buffers, 57 tiles per image
+    (8, 192, 192, (3, 3), (60, 96)),       # nine-tap form on 64-channel blocks (ring of 2)
+    (4, 256, 64, (9, 9), (60, 60)),        # 9x9 rows, single halo buffer
+    (1, 1664, 768, (1, 1), (160, 240)),    # pipelined GEMM: 150 pixel tiles x 3 channel blocks, 52 slabs through the ring of 4
+    (1, 480, 240, (1, 1), (90, 333)),      # ragged last tile, 240 -> one 256-wide block
+])
+def test_conv16_dma_kernels_are_repeatable(hip16, n, cin, cout, k, hw):
+    """Race screen for the hand-counted vmcnt / lgkmcnt waits of the LDS-DMA kernels: a read that overtakes its DMA, or a DMA
+    that overwrites a buffer still being read, shows up as run-to-run differences long before it shows up against a tolerance.
+    Many tiles per CU, the same launch repeated: every run must be bit-identical, and right."""
+    rng = np.random.default_rng(cin + cout + k[0])
+    H, W = hw
+    x = rng.standard_normal((n, cin, H, W)).astype(np.float16).astype(np.float32)
+    w = (rng.standard_normal((cout, cin, k[0], k[1])) * np.sqrt(2.0 / (cin * k[0] * k[1]))).astype(np.float16).astype(np.float32)
+    b = (rng.standard_normal(cout) * 0.1).astype(np.float32)
+    first = _conv16(hip16, x, w, b, 1, 1, 1)
+    for rep in range(7):
+        again = _conv16(hip16, x, w, b, 1, 1, 1)
+        assert np.array_equal(first, again), f"run {rep + 2} differs from run 1 in {(first != again).sum()} values"
+    ref = F.relu(F.conv2d(torch.from_numpy(x[:1]).double(), torch.from_numpy(w).double(), torch.from_numpy(b).double(),
+                          padding=(k[0] // 2, k[1] // 2))).numpy()
+    err = np.abs(first[:1] - ref)
+    assert (err <= 2e-3 * np.abs(ref) + 2e-3).all(), f"max err {err.max()}"
+
+
 # ---------------------------------------------------------------- mobile networks in fp16 vs the fp32 oracle
 @pytest.mark.parametrize("n,h,w", [(1, 64, 96), (2, 160, 128), (1, 320, 320), (2, 960, 960)])
 def test_det_net_f16(hip16, oracle_session, n, h, w):
