@@ -431,8 +431,19 @@ __global__ __launch_bounds__(256) void k_pool_partial16(const half_t* __restrict
     float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (pl < PL && p0 < npix) {
       const long long pend = min(npix, p0 + POOL_PIX16);
-      for (long long p = p0 + pl; p < pend; p += PL) {
-        const h8 v = *reinterpret_cast<const h8*>(x + (g.off + p) * ldx + c8 * 8);
+      // four pixels per trip: four independent 16-byte loads in flight per thread (one load per trip kept the kernel at
+      // 3 TB/s with the waves parked on the load 93 % of their cycles), summed in a fixed order
+      const half_t* xp = x + (g.off + p0 + pl) * ldx + c8 * 8;
+      const long long step = (long long)PL * ldx;
+      long long p = p0 + pl;
+      for (; p + 3 * PL < pend; p += 4 * PL, xp += 4 * step) {
+        const h8 v0 = *reinterpret_cast<const h8*>(xp), v1 = *reinterpret_cast<const h8*>(xp + step);
+        const h8 v2 = *reinterpret_cast<const h8*>(xp + 2 * step), v3 = *reinterpret_cast<const h8*>(xp + 3 * step);
+#pragma unroll
+        for (int t = 0; t < 8; t++) s[t] += ((float)v0[t] + (float)v1[t]) + ((float)v2[t] + (float)v3[t]);
+      }
+      for (; p < pend; p += PL, xp += step) {
+        const h8 v = *reinterpret_cast<const h8*>(xp);
 #pragma unroll
         for (int t = 0; t < 8; t++) s[t] += (float)v[t];
       }
