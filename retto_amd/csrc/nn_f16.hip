@@ -247,6 +247,8 @@ void conv16(hipStream_t st, const half_t* x, int ldx, const ImgGeom* gin, const 
   a.x = x; a.ldx = ldx; a.gin = gin; a.gout = gout; a.Cin = Cin; a.KH = KH; a.KW = KW; a.SH = SH; a.SW = SW; a.PT = PT; a.PL = PL;
   a.w = Wp; a.N = N; a.Npad = Npad; a.y = y; a.ldy = ldy; a.coff = coff; a.epi = epi;
   a.stamps = g_conv_stamps;
+  static const int xcd_env = getenv("RT_XCD") ? atoi(getenv("RT_XCD")) : 1;   // 0: hardware block order (A/B)
+  a.xcd = xcd_env;
   a.lp = round_up(std::min(Cin, KS), 16) + 8;  // whole 16-deep k-steps of real (zero-filled) data + one pad chunk
   const bool dot = epi.dot_w != nullptr;
   // ---- LDS-DMA kernels (nn_f16_dma.hip): the 3x3-class layers and the big 1x1 layers ----

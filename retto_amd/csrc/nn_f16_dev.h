@@ -59,6 +59,7 @@ struct ConvArgs {
   half_t* y; int ldy, coff;
   int TH, TW, nzb;   // pixel tile, number of channel blocks (fastest block coordinate: neighbours share the input in L2)
   int lp;            // LDS row pitch in halves: min(Cin, 32) rounded up to 16, + 8
+  int xcd;           // 1: logical workgroup ids are remapped so that neighbours (the channel blocks of one pixel tile, adjacent tiles) run on ONE XCD and share its L2
   long long* stamps; // diagnostics (RT_CONV_STAMPS): s_memtime of wave 0 at 5 points of every stage of one workgroup, or null
   Epi16 epi;
 };
@@ -72,6 +73,13 @@ struct ConvArgs {
 // no residual (the residual form adds in fp32 before the one rounding, per lane, as before); same values either way.
 // scratch: wave-private, 32 * (BN + 8) halves + 32 long long; the caller has synchronised the workgroup after its last
 // main-loop LDS read.
+// Workgroups are dispatched round-robin over the 8 XCDs (hardware id mod 8), each with its own L2.  This maps hardware id ->
+// logical id so that XCD x works on one contiguous range of logical ids (bijective for any count).
+__device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nwg) {
+  const unsigned q = nwg >> 3, r = nwg & 7, xcd = bid & 7, local = bid >> 3;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
+}
+
 template <int NTN>
 __device__ __forceinline__ size_t epi_scratch_halves() { return (size_t)32 * (32 * NTN + 8) + 128; }
 

@@ -75,11 +75,17 @@ __global__ __launch_bounds__(512, 1) void k_conv16v2(const ConvArgs2 c2) {
   if (kstamp) a.stamps[4000] = __builtin_amdgcn_s_memtime();
   constexpr int NTHR = 512, NTP = 2, BN = 32 * NTN, ROW = KS;  // LDS row = 32 halves (64 bytes), un-padded
   const int TH = a.TH, TW = a.TW;
-  const ImgGeom go = a.gout[blockIdx.y];
+  // logical block coordinates (bx: tile x channel block, by: image)
+  unsigned bx = blockIdx.x, by = blockIdx.y;
+  if (a.xcd) {
+    const unsigned lin = xcd_remap(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
+    by = lin / gridDim.x; bx = lin - by * gridDim.x;
+  }
+  const ImgGeom go = a.gout[by];
   const int tiles_x = (go.W + TW - 1) / TW, tiles_y = (go.H + TH - 1) / TH;
-  const int zb = blockIdx.x % a.nzb, tile = blockIdx.x / a.nzb;
+  const int zb = bx % a.nzb, tile = bx / a.nzb;
   if (tile >= tiles_x * tiles_y) return;
-  const ImgGeom gi = a.gin[blockIdx.y];
+  const ImgGeom gi = a.gin[by];
   const int ty0 = (tile / tiles_x) * TH, tx0 = (tile % tiles_x) * TW;
   const int nb0 = zb * BN;
   constexpr int RG = KW / KWR;   // kernel rows per stage
@@ -270,7 +276,7 @@ __global__ __launch_bounds__(512, 1) void k_conv16v2(const ConvArgs2 c2) {
   }
 
   if (DOT) {   // PFHeadLocal's phase convs: the block holds all (64) channels, nothing goes through LDS
-    dot_tile16<NTN, NTP>(a, acc, lane, oys, oxs, go, (int)blockIdx.y);
+    dot_tile16<NTN, NTP>(a, acc, lane, oys, oxs, go, (int)by);
     return;
   }
   if (kstamp) a.stamps[4003] = __builtin_amdgcn_s_memtime();
@@ -450,8 +456,9 @@ __global__ __launch_bounds__(512, 1) void k_gemm16p(const GemmArgs16 g) {
   constexpr int XHALVES = BP * ROW, WSLOTS = WCH * NTHR, STAGE = XHALVES + WSLOTS * 8;
   const ImgGeom gi = a.gin[0], go = a.gout[0];
   const long long M = go.W;
-  const int zb = blockIdx.x % a.nzb;
-  const long long m0 = (long long)(blockIdx.x / a.nzb) * BP;
+  const unsigned bx = a.xcd ? xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x;
+  const int zb = bx % a.nzb;
+  const long long m0 = (long long)(bx / a.nzb) * BP;
   if (m0 >= M) return;
   const int nblk = zb * BN;
   half_t* lds = reinterpret_cast<half_t*>(smemp);
