@@ -4,6 +4,7 @@
 
 #include <algorithm>
 #include <cstdlib>
+#include <type_traits>
 
 namespace rt {
 namespace nh {
@@ -46,6 +47,20 @@ __device__ __forceinline__ h8 lds_read16(unsigned byte_addr) {
   asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(byte_addr));
   return v;
 }
+template <int OFF>
+__device__ __forceinline__ h8 lds_read16_imm(unsigned byte_addr) {   // address + compile-time offset in the instruction
+  static_assert(OFF >= 0 && OFF < 65536, "16-bit offset field");
+  h8 v;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(byte_addr), "n"(OFF));
+  return v;
+}
+// DMA request with the LDS address already in an SGPR (uniform by construction: no readfirstlane per request)
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+__device__ __forceinline__ void glds16_s(unsigned long long gaddr, unsigned lds_sgpr) {
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gaddr), "s"(lds_sgpr) : "memory", "m0");
+}
+#pragma clang diagnostic pop
 template <int N>
 __device__ __forceinline__ void lds_wait() {
   static_assert(N >= 0 && N <= 15, "lgkmcnt is a 4-bit counter");
@@ -454,6 +469,7 @@ __global__ __launch_bounds__(512, 1) void k_gemm16p(const GemmArgs16 g) {
   constexpr int NTHR = 512, NTP = 2, BN = 64 * NTN, BP = 256, ROW = KS;
   constexpr int XCH = BP * 4 / NTHR, WCH = (BN * 4 + NTHR - 1) / NTHR, PER = XCH + WCH;   // DMA instructions per thread and slab
   constexpr int XHALVES = BP * ROW, WSLOTS = WCH * NTHR, STAGE = XHALVES + WSLOTS * 8;
+  constexpr unsigned STAGE_B = STAGE * 2;
   const ImgGeom gi = a.gin[0], go = a.gout[0];
   const long long M = go.W;
   const unsigned bx = a.xcd ? xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x;
@@ -462,40 +478,55 @@ __global__ __launch_bounds__(512, 1) void k_gemm16p(const GemmArgs16 g) {
   if (m0 >= M) return;
   const int nblk = zb * BN;
   half_t* lds = reinterpret_cast<half_t*>(smemp);
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);   // (in an SGPR: everything derived from it stays scalar)
   const int wn = wid & 1, wp = wid >> 1;
   const int r = lane & 31, h = lane >> 5;
   const int aswz = (r >> 2) & 3;
   const int nb0 = nblk + wn * 32 * NTN;
 
-  const int K = a.Cin, nst = (K + KS - 1) / KS;
-  const half_t* xsrc[XCH]; int xk[XCH];
+  const int K = a.Cin, nst = (K + KS - 1) / KS, krem = K & (KS - 1);   // krem != 0: the last slab is partly beyond K
+  // ---- the stage loop is instruction-bound (stamps: ~2000 cycles of one wave's instruction stream per 512 cycles of its MFMAs),
+  // so everything per-stage is kept to one add: DMA sources are running 64-bit pointers with a per-thread step (0 for rows
+  // beyond M / Npad, which stay on the zero page), LDS addresses are scalar, fragment reads use the instruction's offset field
+  unsigned long long xcur[XCH], wcur[WCH];
+  unsigned xstep[XCH], wstep[WCH];
+  int xk[XCH];
+  const unsigned long long zaddr = (unsigned long long)g.zeros;
 #pragma unroll
   for (int i = 0; i < XCH; i++) {
     const int e = tid + i * NTHR, row = e >> 2, cl = (e & 3) ^ ((row >> 2) & 3);
+    const bool ok = m0 + row < M;
     xk[i] = cl * 8;
-    xsrc[i] = (m0 + row < M) ? a.x + (gi.off + m0 + row) * a.ldx + xk[i] : nullptr;
+    xcur[i] = ok ? (unsigned long long)(a.x + (gi.off + m0 + row) * a.ldx + cl * 8) : zaddr;
+    xstep[i] = ok ? KS * 2 : 0;
   }
-  const half_t* wsrc[WCH];
 #pragma unroll
   for (int i = 0; i < WCH; i++) {
     const int e = tid + i * NTHR, row = e >> 2, cl = (e & 3) ^ ((row >> 2) & 3);
-    wsrc[i] = (row < BN && nblk + row < a.Npad) ? a.w + ((size_t)nblk + row) * KS + cl * 8 : nullptr;
+    const bool ok = row < BN && nblk + row < a.Npad;
+    wcur[i] = ok ? (unsigned long long)(a.w + ((size_t)nblk + row) * KS + cl * 8) : zaddr;
+    wstep[i] = ok ? (unsigned)a.Npad * KS * 2 : 0;
   }
-  const int wave_slot = wid * 64 * 8;
-  auto dma_slab = [&](int s) {
-    half_t* dst = lds + (size_t)(s % R) * STAGE + wave_slot;
-    const int k0 = s * KS;
+  const unsigned lds_b = __builtin_amdgcn_readfirstlane(lds_addr(lds));
+  const unsigned slot_b = lds_b + (unsigned)wid * 1024;     // this wave's 64 16-byte slots inside a group of 512
+  unsigned issue_b = slot_b;                                  // ... of the ring buffer the next slab goes into
+  int issued = 0;
+  auto dma_slab = [&]() {   // requests slab `issued` (slabs are requested in order)
+    const bool tail = krem && issued == nst - 1;
 #pragma unroll
     for (int i = 0; i < XCH; i++) {
-      const half_t* src = (xsrc[i] && k0 + xk[i] < K) ? xsrc[i] + k0 : g.zeros;
-      RT_GLDS16(src, dst + (size_t)i * NTHR * 8);
+      glds16_s((tail && xk[i] >= krem) ? zaddr : xcur[i], issue_b + i * (NTHR * 16));
+      xcur[i] += xstep[i];
     }
 #pragma unroll
     for (int i = 0; i < WCH; i++) {
-      const half_t* src = wsrc[i] ? wsrc[i] + (size_t)s * a.Npad * KS : g.zeros;
-      RT_GLDS16(src, dst + XHALVES + (size_t)i * NTHR * 8);
+      glds16_s(wcur[i], issue_b + XHALVES * 2 + i * (NTHR * 16));
+      wcur[i] += wstep[i];
     }
+    issued++;
+    issue_b = (issue_b + STAGE_B == slot_b + R * STAGE_B) ? slot_b : issue_b + STAGE_B;
+    __builtin_amdgcn_sched_barrier(0);
   };
   auto wait_keep = [&](int slabs) {   // leave the newest `slabs` slabs in flight
     switch (slabs * PER) {
@@ -512,7 +543,7 @@ __global__ __launch_bounds__(512, 1) void k_gemm16p(const GemmArgs16 g) {
   // prologue: slabs 0 .. R - 2 requested, slab 0 landed and visible
 #pragma unroll
   for (int s = 0; s < R - 1; s++)
-    if (s < nst) dma_slab(s);
+    if (s < nst) dma_slab();
   f32x16 acc[NTN][NTP];
 #pragma unroll
   for (int i = 0; i < NTN; i++)
@@ -524,14 +555,20 @@ __global__ __launch_bounds__(512, 1) void k_gemm16p(const GemmArgs16 g) {
   __builtin_amdgcn_s_barrier();
 
   constexpr int NR = NTN + NTP;   // ds_read_b128 per k-step
-  const unsigned lds0 = lds_addr(lds);
-  const unsigned xoff = (unsigned)((wp * 64 + r) * ROW * 2), woff = (unsigned)((XHALVES + (wn * 32 * NTN + r) * ROW) * 2);
-  auto frags = [&](int s, int ks, h8 (&A)[NTN], h8 (&B)[NTP]) {
-    const unsigned base = lds0 + (unsigned)(s % R) * (STAGE * 2) + ((unsigned)((ks * 2 + h) ^ aswz) << 4);
-#pragma unroll
-    for (int j = 0; j < NTP; j++) B[j] = lds_read16(base + xoff + j * 32 * ROW * 2);
-#pragma unroll
-    for (int i = 0; i < NTN; i++) A[i] = lds_read16(base + woff + i * 32 * ROW * 2);
+  // per-lane byte offsets inside a stage buffer, by k-step: pixel rows (B operand) and weight rows (A operand)
+  const unsigned xo0 = (unsigned)((wp * 64 + r) * ROW * 2) + ((unsigned)((0 + h) ^ aswz) << 4);
+  const unsigned xo1 = (unsigned)((wp * 64 + r) * ROW * 2) + ((unsigned)((2 + h) ^ aswz) << 4);
+  const unsigned wo0 = (unsigned)((XHALVES + (wn * 32 * NTN + r) * ROW) * 2) + ((unsigned)((0 + h) ^ aswz) << 4);
+  const unsigned wo1 = (unsigned)((XHALVES + (wn * 32 * NTN + r) * ROW) * 2) + ((unsigned)((2 + h) ^ aswz) << 4);
+  constexpr int FR = 32 * ROW * 2;   // bytes between fragments (32 rows)
+  auto frags = [&](unsigned buf_b, int ks, h8 (&A)[NTN], h8 (&B)[NTP]) {
+    const unsigned xa = buf_b + (ks ? xo1 : xo0), wa = buf_b + (ks ? wo1 : wo0);
+    B[0] = lds_read16_imm<0>(xa);
+    B[1] = lds_read16_imm<FR>(xa);
+    A[0] = lds_read16_imm<0>(wa);
+    if (NTN > 1) A[NTN > 1 ? 1 : 0] = lds_read16_imm<FR>(wa);
+    if (NTN > 2) A[NTN > 2 ? 2 : 0] = lds_read16_imm<2 * FR>(wa);
+    if (NTN > 3) A[NTN > 3 ? 3 : 0] = lds_read16_imm<3 * FR>(wa);
   };
   auto mfmas = [&](const h8 (&A)[NTN], const h8 (&B)[NTP]) {
 #pragma unroll
@@ -541,20 +578,36 @@ __global__ __launch_bounds__(512, 1) void k_gemm16p(const GemmArgs16 g) {
     __builtin_amdgcn_sched_barrier(0);
   };
   h8 A0[NTN], B0[NTP], A1[NTN], B1[NTP];
-  frags(0, 0, A0, B0);
-  for (int s = 0; s + 1 < nst; s++) {
-    frags(s, 1, A1, B1);
+  unsigned cur_b = lds_b;   // buffer of the slab being multiplied
+  frags(cur_b, 0, A0, B0);
+  // one stage; STEADY: slab s + R - 1 exists (a constant number of requests stays in flight across the barrier)
+  auto stage = [&](int s, auto steady) {
+    constexpr bool STEADY = decltype(steady)::value;
+    const unsigned nxt_b = (cur_b + STAGE_B == lds_b + R * STAGE_B) ? lds_b : cur_b + STAGE_B;
+    frags(cur_b, 1, A1, B1);
     lds_wait<NR>();                                          // step 0's fragments are back, step 1's stay in flight
     mfmas(A0, B0);
-    wait_keep(max(0, min(nst - 1, s + R - 2) - (s + 1)));   // slab s + 1 has landed (this wave's requests)
+    if (STEADY) {
+      if (PER * (R - 3) == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else if (PER * (R - 3) == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+      else if (PER * (R - 3) == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else if (PER * (R - 3) == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+      wait_keep(max(0, min(nst - 1, s + R - 2) - (s + 1)));   // slab s + 1 has landed (this wave's requests)
+    }
     __builtin_amdgcn_s_barrier();                            // ... and everybody's; every wave is done with slab s - 1
-    if (s + R - 1 < nst) dma_slab(s + R - 1);
+    if (STEADY) dma_slab();
     __builtin_amdgcn_sched_barrier(0);
-    frags(s + 1, 0, A0, B0);
+    frags(nxt_b, 0, A0, B0);
     lds_wait<NR>();
     mfmas(A1, B1);
-  }
-  frags(nst - 1, 1, A1, B1);
+    cur_b = nxt_b;
+  };
+  int s = 0;
+  for (; s + R - 1 < nst; s++) stage(s, std::true_type{});
+  for (; s + 1 < nst; s++) stage(s, std::false_type{});
+  frags(cur_b, 1, A1, B1);
   lds_wait<NR>();
   mfmas(A0, B0);
   lds_wait<0>();
