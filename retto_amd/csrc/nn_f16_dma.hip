@@ -4,6 +4,7 @@
 
 #include <algorithm>
 #include <cstdlib>
+#include <mutex>
 #include <type_traits>
 
 namespace rt {
@@ -304,9 +305,11 @@ __global__ __launch_bounds__(512, 1) void k_conv16v2(const ConvArgs2 c2) {
 
 static const half_t* zero_page16() {   // per device: DMA source of padding (one allocation per process and device)
   static const half_t* z[16] = {nullptr};
+  static std::mutex mu;   // (the lanes of a session reach this concurrently on their first conv)
   int dev = 0;
   RT_HIP_CHECK(hipGetDevice(&dev));
   if (dev < 0 || dev >= 16) throw RtError(8, "conv16: device index out of range");
+  std::lock_guard<std::mutex> lk(mu);
   if (!z[dev]) {
     void* p = nullptr;
     RT_HIP_CHECK(hipMalloc(&p, 256));
@@ -445,8 +448,8 @@ template <int NTN>
 static void launch_gemm16(hipStream_t st, const GemmArgs16& g, long long mtiles) {
   constexpr size_t lds = (size_t)2 * (2 * 256 * KS + 2 * 64 * NTN * KS) * 2;   // two stage buffers (>= the epilogue scratch)
   static_assert(lds >= (size_t)8 * (32 * (32 * NTN + 8) + 128) * 2, "epilogue scratch must fit in the stage buffers");
-  static bool attr = false;
-  if (!attr) { RT_HIP_CHECK(hipFuncSetAttribute((const void*)k_gemm16<NTN>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr = true; }
+  static const bool once = [] { RT_HIP_CHECK(hipFuncSetAttribute((const void*)k_gemm16<NTN>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); return true; }();
+  (void)once;   // (thread-safe: the lanes of a session launch concurrently)
   RT_LAUNCH((k_gemm16<NTN>), dim3((unsigned)(mtiles * g.a.nzb)), dim3(512), lds, st, g);
 }
 
@@ -628,8 +631,8 @@ static void launch_gemm16p(hipStream_t st, const GemmArgs16& g, long long mtiles
   constexpr int WCH = (64 * NTN * 4 + 511) / 512;
   constexpr size_t lds = (size_t)R * (256 * KS + WCH * 512 * 8) * 2;
   static_assert(lds <= 160 * 1024 && lds >= (size_t)8 * (32 * (32 * NTN + 8) + 128) * 2, "ring within LDS, epilogue scratch within the ring");
-  static bool attr = false;
-  if (!attr) { RT_HIP_CHECK(hipFuncSetAttribute((const void*)k_gemm16p<NTN, R>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr = true; }
+  static const bool once = [] { RT_HIP_CHECK(hipFuncSetAttribute((const void*)k_gemm16p<NTN, R>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); return true; }();
+  (void)once;
   RT_LAUNCH((k_gemm16p<NTN, R>), dim3((unsigned)(mtiles * g.a.nzb)), dim3(512), lds, st, g);
 }
 
@@ -703,14 +706,14 @@ bool conv16_dma(hipStream_t st, const ConvArgs& a0, int n_img, int maxHo, int ma
   const size_t lds2 = std::max((size_t)c2.hbufs * c2.hbuf_halves * 2 + wbytes, (size_t)8 * (32 * (bn2 + 8) + 128) * 2);  // main loop | epilogue scratch
   const long long tiles2 = (long long)((maxWo + tw - 1) / tw) * ((maxHo + th - 1) / th);
   dim3 grid2((unsigned)(tiles2 * c2.a.nzb), (unsigned)n_img);
-  static bool attr2 = false;
-  if (!attr2) {
+  static const bool once2 = [] {
     for (const void* f : {(const void*)k_conv16v2<1, 1, 1>, (const void*)k_conv16v2<2, 1, 1>, (const void*)k_conv16v2<3, 1, 1>, (const void*)k_conv16v2<4, 1, 1>,
                           (const void*)k_conv16v2<1, 3, 3>, (const void*)k_conv16v2<2, 3, 3>, (const void*)k_conv16v2<3, 3, 3>, (const void*)k_conv16v2<4, 3, 3>,
                           (const void*)k_conv16v2<2, 9, 9>, (const void*)k_conv16v2<2, 9, 3>, (const void*)k_conv16v2<2, 4, 2, 1>})
       RT_HIP_CHECK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr2 = true;
-  }
+    return true;
+  }();
+  (void)once2;
 #define RT_V2_LAUNCH(NT) \
   switch (KW) { case 1: RT_LAUNCH((k_conv16v2<NT, 1, 1>), grid2, dim3(512), lds2, st, c2); break; \
                 default: RT_LAUNCH((k_conv16v2<NT, 3, 3>), grid2, dim3(512), lds2, st, c2); break; }
