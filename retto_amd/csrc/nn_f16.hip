@@ -800,34 +800,45 @@ void pixel_shuffle16(hipStream_t st, const half_t* src, int lds, const ImgGeom* 
   RT_LAUNCH(k_pixel_shuffle16, dim3((unsigned)((total + 255) / 256), n_img), dim3(256), 0, st, src, lds, gsrc, gdst, C, dst, ldd, coff);
 }
 
-// thread = one pixel of f (half resolution): 4 outputs
+// 8 lanes = one pixel of f (half resolution), lane g of the group takes the channels 8g .. 8g+7 (+64, ...): a pixel's channels are
+// read as one contiguous run (one thread per pixel walking its own row touched 64 cache lines per load: 7x over-fetch by PMC);
+// the four partial sums are combined by three xor-shuffles (fixed order) and lanes 0-3 of the group store one output each
 __global__ __launch_bounds__(256) void k_deconv_to_map16(const half_t* __restrict__ f, int ldf, const ImgGeom* __restrict__ gf,
                                                          const ImgGeom* __restrict__ gmap, int C, const float* __restrict__ w, float b,
                                                          float* __restrict__ map) {
   const ImgGeom F = gf[blockIdx.y], M = gmap[blockIdx.y];
-  const long long p = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (p >= (long long)F.H * F.W) return;
-  const int y = (int)(p / F.W), x = (int)(p - (long long)y * F.W);
-  float s[4] = {b, b, b, b};
-  const half_t* src = f + (F.off + p) * ldf;
-  for (int c = 0; c < C; c += 8) {
-    const h8 v = *reinterpret_cast<const h8*>(src + c);
+  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  const long long p = t >> 3;
+  const int g = (int)(t & 7);
+  const bool live = p < (long long)F.H * F.W;     // (whole groups are live or not: no divergence inside a shuffle group)
+  float s[4] = {0.f, 0.f, 0.f, 0.f};
+  if (live) {
+    const half_t* src = f + (F.off + p) * ldf;
+    for (int c = g * 8; c < C; c += 64) {
+      const h8 v = *reinterpret_cast<const h8*>(src + c);
 #pragma unroll
-    for (int t = 0; t < 8; t++) {
-      const f32x4 wv = *reinterpret_cast<const f32x4*>(w + (size_t)(c + t) * 4);
+      for (int k = 0; k < 8; k++) {
+        const f32x4 wv = *reinterpret_cast<const f32x4*>(w + (size_t)(c + k) * 4);
 #pragma unroll
-      for (int q = 0; q < 4; q++) s[q] = fmaf((float)v[t], wv[q], s[q]);
+        for (int q = 0; q < 4; q++) s[q] = fmaf((float)v[k], wv[q], s[q]);
+      }
     }
   }
 #pragma unroll
-  for (int q = 0; q < 4; q++)
-    map[M.off + (long long)(2 * y + (q >> 1)) * M.W + 2 * x + (q & 1)] = 1.f / (1.f + __expf(-s[q]));
+  for (int d = 1; d < 8; d <<= 1)
+#pragma unroll
+    for (int q = 0; q < 4; q++) s[q] += __shfl_xor(s[q], d);
+  if (live && g < 4) {
+    const int y = (int)(p / F.W), x = (int)(p - (long long)y * F.W);
+    const float v = g == 0 ? s[0] : g == 1 ? s[1] : g == 2 ? s[2] : s[3];
+    map[M.off + (long long)(2 * y + (g >> 1)) * M.W + 2 * x + (g & 1)] = 1.f / (1.f + __expf(-(v + b)));
+  }
 }
 void deconv_to_map16(hipStream_t st, const half_t* f, int ldf, const ImgGeom* gf, const ImgGeom* gmap, int n_img, long long max_pix,
                      int C, const float* w, float b, float* map) {
   if (n_img <= 0) return;
   if (C % 8) throw RtError(8, "deconv_to_map16: C must be a multiple of 8");
-  RT_LAUNCH(k_deconv_to_map16, dim3((unsigned)((max_pix + 255) / 256), n_img), dim3(256), 0, st, f, ldf, gf, gmap, C, w, b, map);
+  RT_LAUNCH(k_deconv_to_map16, dim3((unsigned)((max_pix * 8 + 255) / 256), n_img), dim3(256), 0, st, f, ldf, gf, gmap, C, w, b, map);
 }
 
 __global__ __launch_bounds__(256) void k_map_window16(const float* __restrict__ map, const ImgGeom* __restrict__ gmap,
