@@ -1,5 +1,8 @@
-"""Diagnostics: per-stage time stamps of one workgroup of the fp16 conv kernel (RT_CONV_STAMPS=1).
-    RT_CONV_STAMPS=1 python tools/conv16_stamps.py [n cin cout k h w]"""
+"""Diagnostics for one fp16 conv / 1x1 GEMM launch through rt_debug_conv16:
+    RT_CONV_STAMPS=1 python tools/conv16_stamps.py [n cin cout k h w]
+prints the time of the launch (HIP events, 5th of 5 repetitions) and, when the library was built with `make STAMPS=1`
+(retto_amd/csrc: in-kernel s_memtime stamps, a diagnostic build that de-pipelines the loops -- never ship or time it as the
+product), the per-stage stamps of one workgroup.  A production build prints the launch time only."""
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
