@@ -93,6 +93,10 @@ def _conv16(sess, x, w, b, sh, sw, act):
     (1, 1664, 768, (1, 1), (1, 1), (40, 120), 1),   # 3 channel blocks of 256, K = 52 slabs
     (1, 72, 128, (1, 1), (1, 1), (64, 80), 2),      # K = 2.25 slabs (odd stage tail + partial slab), 128-channel blocks
     (1, 2112, 1024, (1, 1), (1, 1), (30, 140), 0),  # largest aggregation conv (stage 4)
+    (1, 384, 192, (1, 1), (1, 1), (64, 100), 1),    # GEMM kernel with one 192-wide channel block (3 fragments per wave)
+    (1, 128, 64, (1, 1), (1, 1), (80, 83), 2),      # ... with a 64-wide block, ragged pixel tail
+    (1, 480, 480, (1, 1), (1, 1), (72, 100), 2),    # mobile rec 1x1: 480 -> two 256-wide blocks, the second with 32 pad columns
+    (1, 200, 240, (1, 1), (1, 1), (96, 64), 0),     # K = 6.25 slabs (partial last slab), N = 240 in one 256-wide block
 ])
 def test_conv16_kernel(hip16, n, cin, cout, k, stride, hw, act):
     """fp16 inputs / weights, fp32 accumulation: against torch conv2d on the SAME fp16-rounded operands the only
