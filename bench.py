@@ -73,6 +73,11 @@ def parse():
                     help="weight broadcast: torch.distributed (default) or libretto_hip's own RCCL entry point rt_broadcast_blobs")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the CPU baseline leg")
     ap.add_argument("--profile-all", action="store_true", help="print the per-family table to stderr")
+    ap.add_argument("--dry-run", action="store_true", help="rank plumbing only (no GPU needed): launch / rendezvous / weight broadcast / gather, then one JSON line")
+    ap.add_argument("--no-c5", action="store_true", help="skip the C5 leg (server graphs, fp16) that the default C3 run appends as `c5`")
+    ap.add_argument("--c5-pages", type=int, default=32)
+    ap.add_argument("--c5-steps", type=int, default=5)
+    ap.add_argument("--repeat", type=int, default=2, help="extra repetitions of the K timed steps after the timed region (spread, reported in `repeat`)")
     a = ap.parse_args()
     if a.workload == "c5":
         a.dtype = a.dtype or "f16"; a.models = a.models or "server"
@@ -100,13 +105,65 @@ def page_digest(lib, r, i):
     return hsh.hexdigest()[:16], n
 
 
+def launch_ranks(n):
+    """`python bench.py --gpus N` without a launcher: N child interpreters with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set
+    (what torch.distributed.run would export), rank 0's stdout relayed as this process's stdout (the ONE JSON line), the other
+    ranks' stdout sent to stderr.  Returns the first non-zero exit code (0 if all ranks succeed)."""
+    import socket
+    sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else sys.stderr))
+    rc = 0
+    deadline = time.time() + float(os.environ.get("RT_BENCH_RANK_TIMEOUT", "3600"))
+    for pr in procs:
+        try:
+            code = pr.wait(timeout=max(1.0, deadline - time.time()))
+        except subprocess.TimeoutExpired:   # a rank that never returns (a peer died before a collective): end the job
+            for q in procs:
+                if q.poll() is None:
+                    q.kill()
+            code = 124
+        rc = rc or code
+    return rc
+
+
+def c5_leg(a):
+    """BASELINE config 5 on this GPU, driver-visible: a short `--workload c5` run of this script in a child process after the
+    C3 measurement (32 pages per step so that it stays well inside the default run's minutes), its line condensed."""
+    cmd = [sys.executable, os.path.abspath(__file__), "--workload", "c5", "--pages", str(a.c5_pages), "--steps", str(a.c5_steps),
+           "--warmup", "3", "--no-cpu-baseline", "--no-c5"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE")}
+    t0 = time.perf_counter()
+    try:
+        pr = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    except subprocess.TimeoutExpired:
+        return {"error": "c5 leg timed out"}
+    lines = [ln for ln in pr.stdout.splitlines() if ln.startswith("{")]
+    if pr.returncode != 0 or not lines:
+        return {"error": "c5 leg failed (rc %d): %s" % (pr.returncode, pr.stderr[-400:])}
+    j = json.loads(lines[-1])
+    return {"value": j["value"], "unit": j["unit"], "ms_per_step": j["ms_per_step"], "steps": j["steps"], "warmup": j["warmup"],
+            "dtype": j["dtype"], "workload": j["config"]["workload"], "pages_per_step": j["config"]["pages_per_gpu_per_step"],
+            "roofline": j["roofline"], "networks": j["networks"], "selfcheck": j["selfcheck"], "repeat": j.get("repeat"),
+            "leg_wall_s": round(time.perf_counter() - t0, 1),
+            "note": "same script, `--workload c5`, run as a child process after the C3 timed region; the headline fields above stay C3"}
+
+
 def main():
     a = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != a.gpus and world == 1 and a.gpus > 1:
-        print("bench.py: --gpus %d needs torch.distributed.run with %d ranks" % (a.gpus, a.gpus), file=sys.stderr)
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        # not under torch.distributed.run: start the N ranks ourselves, one fresh child process per GPU.  Nothing in THIS
+        # process has touched HIP or torch yet (children are started, never exec'ed over a GPU-initialised process).
+        sys.exit(launch_ranks(a.gpus))
+    if world != a.gpus:
+        print("bench.py: --gpus %d but WORLD_SIZE=%d" % (a.gpus, world), file=sys.stderr)
         sys.exit(2)
     import torch
     import torch.distributed as dist
@@ -123,13 +180,14 @@ def main():
 
     import retto_amd
     from retto_amd import synth, workload, workmodel
-    from retto_amd.dist import broadcast_blobs, shard_pages
+    from retto_amd.dist import broadcast_blobs, shard_pages, process_shard, run_global_batch
 
     # ---- weights: generated on rank 0, RCCL-broadcast once -------------------------------
     if rank == 0:
         blobs = list(synth.synth_server_models(0) if a.models == "server" else synth.synth_models(0))
     else:
         blobs = [None] * 4
+    t_bc = time.perf_counter()
     if dist_on and a.bcast == "cabi":   # the C-ABI hook a Rust / C++ host would use: RCCL id from rank 0, shared out of band
         from retto_amd.dist import broadcast_blobs_cabi, rccl_unique_id
         box = [rccl_unique_id() if rank == 0 else None]
@@ -137,6 +195,20 @@ def main():
         blobs = broadcast_blobs_cabi(blobs, 4, rank, world, device, box[0])
     elif dist_on:
         blobs = broadcast_blobs(blobs, 4, rank, device=tdev)  # RCCL over xGMI, once
+    bcast_ms = 1000.0 * (time.perf_counter() - t_bc) if dist_on else None
+    rccl_ranks = dist.get_world_size() if dist_on else 1   # (the size of the communicator the weights went over)
+    if a.dry_run:   # CPU-side check of the multi-rank plumbing (tests/test_dist_gloo.py): everything up to the session
+        from retto_amd.dist import digest
+        sizes = [C4_SIZES[(7 * i) % len(C4_SIZES)] for i in range(19)]
+        res = run_global_batch(sizes, rank, world if dist_on else 1, lambda ids: ["%d:%s" % (i, digest(blobs)[:8]) for i in ids],
+                               est_lines=[a.lines] * len(sizes), chunk=4)
+        if dist_on:
+            dist.barrier()
+            dist.destroy_process_group()
+        if rank == 0:
+            print(json.dumps({"dry_run": True, "n_gpus": world, "rccl_ranks": rccl_ranks, "bcast_ms": None if bcast_ms is None else round(bcast_ms, 2),
+                              "backend": a.backend, "blob_digest": digest(blobs)[:16], "gathered": res}), flush=True)
+        return
     det_b, cls_b, rec_b, dict_b = blobs
     cfg = retto_amd.RettoSessionConfig()
     cfg.det_sub_batch = a.det_sub_batch
@@ -191,20 +263,28 @@ def main():
     hs = [p.shape[0] for p in pages]; ws = [p.shape[1] for p in pages]
     h_pages = [p.ctypes.data for p in pages]   # host-resident variant (pinned by the library's own staging)
     chunk = a.pages if global_mode else n_my   # a step of the global mode walks the shard in calls of --pages pages
+    local = {gid: k for k, gid in enumerate(my_ids)}   # page id -> index into this rank's resident pages
+
+    def run_ids(ids, on_host=False, want="free"):
+        """One rt_run_batch over the pages `ids` (ids of this rank).  want: "free" -> [None] * n, "digest" -> [(digest, lines)],
+        "raw" -> [(results handle, n)] (caller frees)."""
+        ks = [local[i] for i in ids]
+        if on_host:
+            r = sess.run_batch_raw([h_pages[k] for k in ks], [hs[k] for k in ks], [ws[k] for k in ks], retto_amd.RT_MEM_HOST,
+                                   [maps[k].ctypes.data for k in ks])
+        else:
+            r = sess.run_batch_raw([d_pages[k] for k in ks], [hs[k] for k in ks], [ws[k] for k in ks], retto_amd.RT_MEM_DEVICE,
+                                   [d_maps[k] for k in ks])
+        if want == "raw":
+            return [(r, len(ks))] + [None] * (len(ks) - 1)
+        out = [page_digest(lib, r, j) for j in range(len(ks))] if want == "digest" else [None] * len(ks)
+        lib.rt_results_free(r)
+        return out
 
     def step(on_host=False, keep=False):
-        outs = []
-        for c0 in range(0, n_my, chunk):
-            c1 = min(n_my, c0 + chunk)
-            if on_host:
-                r = sess.run_batch_raw(h_pages[c0:c1], hs[c0:c1], ws[c0:c1], retto_amd.RT_MEM_HOST, [m.ctypes.data for m in maps[c0:c1]])
-            else:
-                r = sess.run_batch_raw(d_pages[c0:c1], hs[c0:c1], ws[c0:c1], retto_amd.RT_MEM_DEVICE, d_maps[c0:c1])
-            if keep:
-                outs.append((r, c1 - c0))
-            else:
-                lib.rt_results_free(r)
-        return outs
+        # (the per-rank half of retto_amd.dist.run_global_batch: the shard in calls of `chunk` pages, no collective)
+        res = process_shard(my_ids, lambda ids: run_ids(ids, on_host, "raw" if keep else "free"), chunk)
+        return [x for _i, x in res if x is not None] if keep else []
 
     def barrier():
         lib.rt_synchronize(h)
@@ -230,6 +310,15 @@ def main():
         step(on_host)
     barrier()
     elapsed = time.perf_counter() - t0
+    # spread: the same K steps again, `--repeat` more times (each bracketed like the timed region); `value` stays the FIRST region
+    rep_ms = [1000.0 * elapsed / a.steps]
+    for _ in range(max(0, a.repeat)):
+        barrier()
+        tr = time.perf_counter()
+        for _ in range(a.steps):
+            step(on_host)
+        barrier()
+        rep_ms.append(1000.0 * (time.perf_counter() - tr) / a.steps)
     # the same steps with the pages starting in host memory (PCIe inside the timed region): reported beside `value`, never as it
     other_rate = None
     if not global_mode:
@@ -243,21 +332,10 @@ def main():
         other_rate = n_my * k2 / (time.perf_counter() - t2)
     # ---- global mode: gather every page's digest in INPUT order; rank invariance is checked on rank 0 below -------
     gathered = None
-    if global_mode:
-        outs = step(keep=True)
-        mine = []
-        k = 0
-        for r, n in outs:
-            for i in range(n):
-                mine.append((my_ids[k], ) + page_digest(lib, r, i)); k += 1
-            lib.rt_results_free(r)
-        if dist_on:
-            lst = [None] * world
-            dist.all_gather_object(lst, mine)
-            gathered = sorted(x for part in lst for x in part)
-        else:
-            gathered = sorted(mine)
-        assert [g[0] for g in gathered] == list(range(a.global_batch)), "gather lost or duplicated pages"
+    if global_mode:   # every rank ends with every page's digest in input order (retto_amd.dist.run_global_batch)
+        digs = run_global_batch(all_sizes, rank, world if dist_on else 1, lambda ids: run_ids(ids, False, "digest"),
+                                est_lines=[a.lines] * a.global_batch, chunk=chunk)
+        gathered = [(gid,) + tuple(d) for gid, d in enumerate(digs)]
     # ---- roofline pass (rank 0 only): the same K steps strictly serial on one stream with HIP
     # events around every launch.  Concurrent lanes share the GPU and stretch each other's
     # kernels, so a kernel's own duration can only be read from a serial pass.
@@ -495,6 +573,14 @@ def main():
         "networks": networks,
         "selfcheck": selfcheck,
     }
+    out["repeat"] = {"ms_per_step": [round(x, 3) for x in rep_ms], "min": round(min(rep_ms), 3), "median": round(float(np.median(rep_ms)), 3),
+                     "note": "the timed region (first entry, = ms_per_step) and %d more regions of %d steps on this rank" % (len(rep_ms) - 1, a.steps)}
+    if dist_on:
+        out["rccl_ranks"] = rccl_ranks
+        out["bcast_ms"] = round(bcast_ms, 2)
+    if a.workload == "c3" and world == 1 and not a.no_c5 and a.dtype == "f32" and a.models == "mobile":
+        sess.close(); sess = None
+        out["c5"] = c5_leg(a)
     if other_rate is not None:
         out["pages_on_host" if not on_host else "pages_on_hbm"] = {
             "value": round(other_rate * (world if not global_mode else 1), 3), "unit": "images/s",
@@ -503,7 +589,8 @@ def main():
         out["c2"] = c2
     if rank_invariance:
         out["rank_invariance"] = rank_invariance
-    sess.close()
+    if sess is not None:
+        sess.close()
     if dist_on:
         dist.destroy_process_group()
     _flush_c_stdio()

@@ -74,6 +74,9 @@ typedef struct rt_model_source {
 /* RettoSessionConfig + Det/Cls/RecProcessorConfig defaults (session.rs:28-39,
  * det_processor.rs:75-93, cls_processor.rs:27-36, rec_processor.rs:111-136). */
 typedef struct rt_config {
+  uint32_t struct_size;      /* sizeof(rt_config) of the header the caller was compiled against: set by rt_config_default,
+                                checked by rt_create (a host built against an older, shorter struct gets RT_ERR_INVALID instead
+                                of having fields read past the end of its struct) */
   int32_t device_id;         /* HIP device ordinal (RettoOrtWorkerDevice::Cuda(id) analogue) */
   rt_model_source det, cls, rec, dict;
   int32_t max_side_len;      /* 2000 */

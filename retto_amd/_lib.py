@@ -25,7 +25,7 @@ class ModelSource(C.Structure):
 
 class Config(C.Structure):
     _fields_ = [
-        ("device_id", C.c_int32),
+        ("struct_size", C.c_uint32), ("device_id", C.c_int32),
         ("det", ModelSource), ("cls", ModelSource), ("rec", ModelSource), ("dict", ModelSource),
         ("max_side_len", C.c_int32), ("min_side_len", C.c_int32),
         ("det_limit_side_len", C.c_int32), ("det_limit_type", C.c_int32),

@@ -60,6 +60,7 @@ extern "C" {
 void rt_config_default(rt_config* c) {
   if (!c) return;
   memset(c, 0, sizeof(*c));
+  c->struct_size = (uint32_t)sizeof(rt_config);
   c->device_id = 0;
   c->max_side_len = 2000; c->min_side_len = 30;
   c->det_limit_side_len = 736; c->det_limit_type = 0;
@@ -77,6 +78,8 @@ void rt_config_default(rt_config* c) {
 int rt_create(const rt_config* cfg, rt_session** out) {
   RT_REQUIRE(cfg && out, (rt_session*)nullptr, "rt_create: null argument");
   *out = nullptr;
+  RT_REQUIRE(cfg->struct_size == sizeof(rt_config), (rt_session*)nullptr,
+             "rt_config.struct_size does not match this library's rt_config: fill the struct with rt_config_default() of the same header");
   RT_REQUIRE(cfg->rec_batch_num > 0 && cfg->cls_batch_num > 0, (rt_session*)nullptr, "batch_num must be positive");
   RT_REQUIRE(cfg->cls_image_shape[0] == 3 && cfg->rec_image_shape[0] == 3 && cfg->rec_image_shape[1] == 48 &&
                  cfg->cls_image_shape[1] == 48 && cfg->cls_image_shape[2] == 192,
@@ -451,35 +454,41 @@ RT_API int rt_bench_gemm(rt_session* s, long long M, int K, int N, int variant, 
   RT_REQUIRE(s && ms_out, s, "rt_bench_gemm: null argument");
   return guarded(s, [&] {
     RT_HIP_CHECK(hipSetDevice(s->device));
-    const int Kp = round_up(K, 4), Np = round_up(N, 16), ldc = round_up(N, 4), nkc = (Kp + nn::KC - 1) / nn::KC;
-    std::vector<float> ha((size_t)M * Kp), hw((size_t)nkc * Np * nn::KC, 0.f), hb(Np, 0.1f);
+    // operand pitches as the networks have them (chan_pitch: 240 -> 256), padding channels zero
+    const int Kp = round_up(K, 4), lda = chan_pitch(K), Np = round_up(N, 16), ldc = chan_pitch(N), nkc = (Kp + nn::KC - 1) / nn::KC;
+    std::vector<float> ha((size_t)M * lda, 0.f), hw((size_t)nkc * Np * nn::KC, 0.f), hb(Np, 0.1f);
     uint32_t st = 12345;
     auto rnd = [&]() { st = st * 1664525u + 1013904223u; return ((st >> 8) & 0xffff) / 32768.0f - 1.0f; };
-    for (auto& v : ha) v = rnd();
+    for (long long m = 0; m < M; m++) for (int k = 0; k < K; k++) ha[(size_t)m * lda + k] = rnd();
     for (int k = 0; k < K; k++) for (int n = 0; n < N; n++) hw[((size_t)(k / nn::KC) * Np + n) * nn::KC + k % nn::KC] = rnd() * 0.1f;
     float *dA, *dW, *dB, *dC, *dC0;
     RT_HIP_CHECK(hipMalloc((void**)&dA, ha.size() * 4)); RT_HIP_CHECK(hipMalloc((void**)&dW, hw.size() * 4));
     RT_HIP_CHECK(hipMalloc((void**)&dB, hb.size() * 4)); RT_HIP_CHECK(hipMalloc((void**)&dC, (size_t)M * ldc * 4));
     RT_HIP_CHECK(hipMalloc((void**)&dC0, (size_t)M * ldc * 4));
+    RT_HIP_CHECK(hipMemset(dC, 0, (size_t)M * ldc * 4)); RT_HIP_CHECK(hipMemset(dC0, 0, (size_t)M * ldc * 4));
     RT_HIP_CHECK(hipMemcpy(dA, ha.data(), ha.size() * 4, hipMemcpyHostToDevice));
     RT_HIP_CHECK(hipMemcpy(dW, hw.data(), hw.size() * 4, hipMemcpyHostToDevice));
     RT_HIP_CHECK(hipMemcpy(dB, hb.data(), hb.size() * 4, hipMemcpyHostToDevice));
     Epilogue e{dB, ACT_HSWISH, 1, 1.01f, 0.02f, nullptr, 0};
-    nn::g_gemm_variant = 1; nn::gemm(s->st, dA, Kp, M, Kp, dW, N, Np, dC0, ldc, 0, e);
+    nn::g_gemm_variant = 1; nn::gemm(s->st, dA, lda, M, Kp, dW, N, Np, dC0, ldc, 0, e);
     nn::g_gemm_variant = variant;
-    nn::gemm(s->st, dA, Kp, M, Kp, dW, N, Np, dC, ldc, 0, e);
+    nn::gemm(s->st, dA, lda, M, Kp, dW, N, Np, dC, ldc, 0, e);
     hipEvent_t a, b; RT_HIP_CHECK(hipEventCreate(&a)); RT_HIP_CHECK(hipEventCreate(&b));
     RT_HIP_CHECK(hipEventRecord(a, s->st));
-    for (int i = 0; i < iters; i++) nn::gemm(s->st, dA, Kp, M, Kp, dW, N, Np, dC, ldc, 0, e);
+    for (int i = 0; i < iters; i++) nn::gemm(s->st, dA, lda, M, Kp, dW, N, Np, dC, ldc, 0, e);
     RT_HIP_CHECK(hipEventRecord(b, s->st));
     RT_HIP_CHECK(hipStreamSynchronize(s->st));
     nn::g_gemm_variant = 0;
     float ms = 0; RT_HIP_CHECK(hipEventElapsedTime(&ms, a, b)); *ms_out = ms / iters;
     if (maxdiff_out) {
-      size_t cnt = std::min<size_t>((size_t)M * ldc, (size_t)1 << 22);
+      // the first and the last 4 M elements (the last row block is the partial one)
+      const size_t total = (size_t)M * ldc, cnt = std::min<size_t>(total, (size_t)1 << 22);
       std::vector<float> c0(cnt), c1(cnt);
-      RT_HIP_CHECK(hipMemcpy(c0.data(), dC0, cnt * 4, hipMemcpyDeviceToHost)); RT_HIP_CHECK(hipMemcpy(c1.data(), dC, cnt * 4, hipMemcpyDeviceToHost));
-      float md = 0; for (size_t i = 0; i < cnt; i++) md = std::max(md, std::fabs(c0[i] - c1[i]));
+      float md = 0;
+      for (size_t off : {(size_t)0, total - cnt}) {
+        RT_HIP_CHECK(hipMemcpy(c0.data(), dC0 + off, cnt * 4, hipMemcpyDeviceToHost)); RT_HIP_CHECK(hipMemcpy(c1.data(), dC + off, cnt * 4, hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < cnt; i++) { const float d = std::fabs(c0[i] - c1[i]); md = (d > md || d != d) ? (d != d ? INFINITY : d) : md; }
+      }
       *maxdiff_out = md;
     }
     (void)hipEventDestroy(a); (void)hipEventDestroy(b);

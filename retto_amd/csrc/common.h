@@ -63,6 +63,10 @@ struct RtError : std::runtime_error {
       throw ::rt::RtError(4, std::string("kernel launch rejected: " #kernel ": ") + hipGetErrorString(le__) + \
                                  " (" __FILE__ ":" + std::to_string(__LINE__) + ")");                        \
   } while (0)
+// hipFuncAttributeMaxDynamicSharedMemorySize is kept PER DEVICE and applies to the current device only: a process-wide
+// "set once" flag leaves a session created later on another GPU launching > 64 KB of dynamic LDS without it (the launch is
+// then rejected).  allow_big_lds(f, bytes) sets it once per (device, kernel); thread-safe (a session's lanes launch concurrently).
+void allow_big_lds(const void* kernel, int bytes);
 constexpr int RT_MAX_GRID_Y = 65535;  // HIP limit of gridDim.y / gridDim.z
 
 static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }

@@ -13,10 +13,16 @@ constexpr int KC = 32;  // K-chunk of the MFMA GEMM / conv kernels (weights are 
 void gemm(hipStream_t st, const float* A, int lda, long long M, int K, const float* Wp, int N, int Npad16, float* C,
           int ldc, int coff, const Epilogue& epi);
 const char* gemm_pw_label(long long M, int Npad16, bool a_scale = false);
+// Persistent LDS-DMA form of the 256 x 240 tile (nn_gemm_dma.hip): N a multiple of 240, K whole 16-deep groups, plain
+// bias / activation / LAB epilogue.  gemm() takes it for the large 240- / 480-channel layers.
+bool gemm_dma_supported(int lda, long long M, int K, int N, int Npad16, const Epilogue& epi);
+void gemm_dma(hipStream_t st, const float* A, int lda, long long M, int K, const float* Wp, int N, int Npad16, float* C,
+              int ldc, int coff, const Epilogue& epi);
 void set_dw_xcd(int v);  // A/B: XCD-aware block order of the depthwise kernel (default on)
 extern int g_dw_wide_slab_min, g_dw_wide3_min, g_dw_wide_lp;
 extern int g_dw_variant;    // same for dwconv
 extern int g_gemm_variant;  // kernel micro-benchmark hook (0 = production dispatch)
+extern int g_gemm_dma;      // A/B: persistent LDS-DMA wide GEMM on (default) / off
 
 // Dense stride-1 "same" convolution, kernel (KH,KW) in {(3,3),(1,3)}; W packed as
 // [ceil(Cin/KC)][KH*KW][Npad16][KC].

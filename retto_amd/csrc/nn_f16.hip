@@ -197,12 +197,7 @@ bool conv_stamps_compiled() {
 template <int NTN, int DOT>
 static void launch_conv16(hipStream_t st, const ConvArgs& a, dim3 grid, size_t lds) {
   auto kfn = k_conv16<NTN, 2, 1, 4, DOT>;
-  // once per instantiation; a function-local static's initialiser is thread-safe (the three lanes of a session launch concurrently)
-  static const bool once = [&] {
-    RT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024)));
-    return true;
-  }();
-  (void)once;
+  allow_big_lds(reinterpret_cast<const void*>(kfn), 160 * 1024);   // once per (device, instantiation)
   RT_LAUNCH(kfn, grid, dim3(256), lds, st, a);
 }
 
@@ -545,11 +540,7 @@ void se_scale16(hipStream_t st, const half_t* x, int ldx, const ImgGeom* geom, i
     RT_LAUNCH(k_pool_partial16, dim3(chunks, ny), dim3(256), 0, st, x, ldx, geom + y0, Cp, chunks, partial + (size_t)y0 * chunks * Cp);
   }
   const size_t lds = (size_t)SE_IPB * (Cp + Cr + 4) * sizeof(float);
-  static const bool once = [] {
-    RT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_se_fc16), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
-    return true;
-  }();
-  (void)once;
+  allow_big_lds(reinterpret_cast<const void*>(k_se_fc16), 96 * 1024);
   RT_LAUNCH(k_se_fc16, dim3((n_img + SE_IPB - 1) / SE_IPB), dim3(256), lds, st, partial, geom, n_img, chunks, C, Cp, w1t, b1, w2t,
             b2, Cr, slope, residual, scale);
 }

@@ -448,8 +448,7 @@ template <int NTN>
 static void launch_gemm16(hipStream_t st, const GemmArgs16& g, long long mtiles) {
   constexpr size_t lds = (size_t)2 * (2 * 256 * KS + 2 * 64 * NTN * KS) * 2;   // two stage buffers (>= the epilogue scratch)
   static_assert(lds >= (size_t)8 * (32 * (32 * NTN + 8) + 128) * 2, "epilogue scratch must fit in the stage buffers");
-  static const bool once = [] { RT_HIP_CHECK(hipFuncSetAttribute((const void*)k_gemm16<NTN>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); return true; }();
-  (void)once;   // (thread-safe: the lanes of a session launch concurrently)
+  allow_big_lds((const void*)k_gemm16<NTN>, 160 * 1024);
   RT_LAUNCH((k_gemm16<NTN>), dim3((unsigned)(mtiles * g.a.nzb)), dim3(512), lds, st, g);
 }
 
@@ -631,8 +630,7 @@ static void launch_gemm16p(hipStream_t st, const GemmArgs16& g, long long mtiles
   constexpr int WCH = (64 * NTN * 4 + 511) / 512;
   constexpr size_t lds = (size_t)R * (256 * KS + WCH * 512 * 8) * 2;
   static_assert(lds <= 160 * 1024 && lds >= (size_t)8 * (32 * (32 * NTN + 8) + 128) * 2, "ring within LDS, epilogue scratch within the ring");
-  static const bool once = [] { RT_HIP_CHECK(hipFuncSetAttribute((const void*)k_gemm16p<NTN, R>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); return true; }();
-  (void)once;
+  allow_big_lds((const void*)k_gemm16p<NTN, R>, 160 * 1024);
   RT_LAUNCH((k_gemm16p<NTN, R>), dim3((unsigned)(mtiles * g.a.nzb)), dim3(512), lds, st, g);
 }
 
@@ -706,14 +704,10 @@ bool conv16_dma(hipStream_t st, const ConvArgs& a0, int n_img, int maxHo, int ma
   const size_t lds2 = std::max((size_t)c2.hbufs * c2.hbuf_halves * 2 + wbytes, (size_t)8 * (32 * (bn2 + 8) + 128) * 2);  // main loop | epilogue scratch
   const long long tiles2 = (long long)((maxWo + tw - 1) / tw) * ((maxHo + th - 1) / th);
   dim3 grid2((unsigned)(tiles2 * c2.a.nzb), (unsigned)n_img);
-  static const bool once2 = [] {
-    for (const void* f : {(const void*)k_conv16v2<1, 1, 1>, (const void*)k_conv16v2<2, 1, 1>, (const void*)k_conv16v2<3, 1, 1>, (const void*)k_conv16v2<4, 1, 1>,
-                          (const void*)k_conv16v2<1, 3, 3>, (const void*)k_conv16v2<2, 3, 3>, (const void*)k_conv16v2<3, 3, 3>, (const void*)k_conv16v2<4, 3, 3>,
-                          (const void*)k_conv16v2<2, 9, 9>, (const void*)k_conv16v2<2, 9, 3>, (const void*)k_conv16v2<2, 4, 2, 1>})
-      RT_HIP_CHECK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    return true;
-  }();
-  (void)once2;
+  for (const void* f : {(const void*)k_conv16v2<1, 1, 1>, (const void*)k_conv16v2<2, 1, 1>, (const void*)k_conv16v2<3, 1, 1>, (const void*)k_conv16v2<4, 1, 1>,
+                        (const void*)k_conv16v2<1, 3, 3>, (const void*)k_conv16v2<2, 3, 3>, (const void*)k_conv16v2<3, 3, 3>, (const void*)k_conv16v2<4, 3, 3>,
+                        (const void*)k_conv16v2<2, 9, 9>, (const void*)k_conv16v2<2, 9, 3>, (const void*)k_conv16v2<2, 4, 2, 1>})
+    allow_big_lds(f, 160 * 1024);
 #define RT_V2_LAUNCH(NT) \
   switch (KW) { case 1: RT_LAUNCH((k_conv16v2<NT, 1, 1>), grid2, dim3(512), lds2, st, c2); break; \
                 default: RT_LAUNCH((k_conv16v2<NT, 3, 3>), grid2, dim3(512), lds2, st, c2); break; }

@@ -6,54 +6,13 @@
 // The networks these serve replace ONNX Runtime's Session::run in
 // /root/reference/retto-core/src/worker/ort_worker.rs:189-220.
 #include "nn.h"
+#include "nn_dev.h"
 
 #include <algorithm>
 #include <cstdlib>
 
 namespace rt {
 namespace nn {
-
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-// `act` is uniform per launch.  Every case is a handful of VALU ops: no IEEE division (the
-// x/6 of hardswish is a multiply, swish/sigmoid use v_exp + v_rcp), so the fused epilogues stay
-// cheap next to the MFMA / load work.  Differences to the exact forms are <= 2 ulp.
-__device__ __forceinline__ float act_apply(float v, int act) {
-  if (act == ACT_HSWISH) return v * fminf(fmaxf(v + 3.0f, 0.0f), 6.0f) * 0.16666667f;
-  if (act == ACT_RELU) return fmaxf(v, 0.0f);
-  if (act == ACT_NONE) return v;
-  const float s = __builtin_amdgcn_rcpf(1.0f + __expf(-v));
-  return act == ACT_SWISH ? v * s : s;
-}
-
-// The epilogues resolve (activation, LAB) ONCE per kernel instead of per element: with the runtime
-// `act` inside the element loops hipcc emits a branch ladder per output value (the 256 x 240 GEMM tile
-// spent ~16 us of its ~80 us there).  act_dispatch calls f with compile-time tags for the combinations
-// the networks use and with (-1, -1) = "decide per element" for anything else.  Same expressions, same
-// rounding as act_apply.
-template <int V> struct IntTag { static constexpr int value = V; };
-template <int ACT, int LAB>
-__device__ __forceinline__ float epi_val(float v, int act, int has_lab, float lab_a, float lab_c) {
-  float t;
-  if (ACT == ACT_HSWISH) t = v * fminf(fmaxf(v + 3.0f, 0.0f), 6.0f) * 0.16666667f;
-  else if (ACT == ACT_RELU) t = fmaxf(v, 0.0f);
-  else if (ACT == ACT_NONE) t = v;
-  else if (ACT == ACT_SWISH) t = v * __builtin_amdgcn_rcpf(1.0f + __expf(-v));
-  else t = act_apply(v, act);
-  if (LAB == 1 || (LAB < 0 && has_lab)) t = fmaf(t, lab_a, lab_c);
-  return t;
-}
-template <class F>
-__device__ __forceinline__ void act_dispatch(int act, int has_lab, bool has_res, F&& f) {
-  // f(activation tag, LAB tag, residual tag); (-1, -1, 1) = everything decided per element
-  if (has_res) f(IntTag<-1>{}, IntTag<-1>{}, IntTag<1>{});
-  else if (act == ACT_HSWISH && has_lab) f(IntTag<ACT_HSWISH>{}, IntTag<1>{}, IntTag<0>{});
-  else if (act == ACT_HSWISH) f(IntTag<ACT_HSWISH>{}, IntTag<0>{}, IntTag<0>{});
-  else if (act == ACT_NONE && !has_lab) f(IntTag<ACT_NONE>{}, IntTag<0>{}, IntTag<0>{});
-  else if (act == ACT_RELU && !has_lab) f(IntTag<ACT_RELU>{}, IntTag<0>{}, IntTag<0>{});
-  else if (act == ACT_SWISH && !has_lab) f(IntTag<ACT_SWISH>{}, IntTag<0>{}, IntTag<0>{});
-  else f(IntTag<-1>{}, IntTag<-1>{}, IntTag<0>{});
-}
 
 // ---------------------------------------------------------------------------
 // MFMA micro-kernel shared by gemm and conv_sp.
@@ -724,6 +683,7 @@ void lc_thin(hipStream_t st, int sh, int sw, const float* x, const ImgGeom* gin,
 }
 
 int g_gemm_variant = 0;  // 0 = production choice; others are forced by the kernel micro-benchmark
+int g_gemm_dma = getenv("RT_GEMM_DMA") ? atoi(getenv("RT_GEMM_DMA")) : 1;   // A/B: 0 keeps the register-staged 256 x 240 tile
 
 // production dispatch (tools/bench_gemm.py): wide tiles once N and M are large; 0 = narrow k_gemm<NT>
 static int gemm_dispatch(long long M, int Npad16) {
@@ -738,7 +698,7 @@ static int gemm_dispatch(long long M, int Npad16) {
 const char* gemm_pw_label(long long M, int Npad16, bool a_scale) {
   if (a_scale && !g_gemm_variant) return gemm_dispatch(M, Npad16) == 0 ? "gemm_pw/k_gemm_wide<2,4,4,2>+se" : "gemm_pw/k_gemm_wide<2,5,4,3>+se";
   switch (g_gemm_variant ? -1 : gemm_dispatch(M, Npad16)) {
-    case 15: return "gemm_pw/k_gemm_wide<4,5,4,3>";
+    case 15: return g_gemm_dma ? "gemm_pw/k_gemm32p" : "gemm_pw/k_gemm_wide<4,5,4,3>";
     case 10: return "gemm_pw/k_gemm_wide<2,5,4,3>";
     case 0: return "gemm_pw/thin";  // k_gemm_stream (K, N <= 64) or k_gemm<NT>
     default: return "gemm_pw/variant";
@@ -796,6 +756,12 @@ void gemm(hipStream_t st, const float* A, int lda, long long M, int K, const flo
     }
     return;
   }
+  // persistent LDS-DMA form of the 256 x 240 tile (variant 30; production for the large N = 240 / 480 layers)
+  if ((v == 30 || (v == 15 && !g_gemm_variant && g_gemm_dma)) && gemm_dma_supported(lda, M, K, N, Npad16, epi)) {
+    gemm_dma(st, A, lda, M, K, Wp, N, Npad16, C, ldc, coff, epi);
+    return;
+  }
+  if (v == 30) v = 15;
   if (epi.a_scale) {  // squeeze-excite scale folded into the A staging: wide tiles only (gemm_tile_rows)
     if (K > 512 || !epi.a_tab) throw RtError(8, "gemm: a_scale needs K <= 512 and a row-tile table");
     if (v == 15) v = 10;  // the 256-row tile has no registers to spare for the scaling (spills): 128 x 240 measured faster

@@ -27,7 +27,10 @@ Rccl* rccl() {
   static bool tried = false;
   if (!tried) {
     tried = true;
-    r.h = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
+    // an RCCL the process already holds (e.g. the copy torch loaded) is reused instead of loading a second one beside it
+    for (const char* name : {"librccl.so", "librccl.so.1"})
+      if (!r.h) r.h = dlopen(name, RTLD_NOW | RTLD_LOCAL | RTLD_NOLOAD);
+    if (!r.h) r.h = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
     if (!r.h) r.h = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
     if (r.h) {
       r.GetUniqueId = (decltype(r.GetUniqueId))dlsym(r.h, "ncclGetUniqueId");
@@ -61,12 +64,19 @@ int rt_broadcast_blobs(const void* id, int rank, int world, int device_id, int r
   }
   Rccl* r = rccl();
   if (!r) { set_err(err, err_cap, "librccl.so could not be loaded"); return RT_ERR_BACKEND; }
+  // No timeout: like every RCCL collective this call blocks until all `world` ranks have entered it.  A rank that fails before
+  // its ncclBroadcast (hipMalloc, a bad device) leaves the others waiting -- hosts run it under their own watchdog and restart
+  // the job (bench.py's launcher kills all ranks after RT_BENCH_RANK_TIMEOUT; examples/retto_dir.cpp exits non-zero when a
+  // child does).
   void* comm = nullptr;
   hipStream_t st = nullptr;
   void* dbuf = nullptr;
   std::vector<void*> mine;  // buffers this call allocated (released on failure)
+  int prev_dev = -1;
+  (void)hipGetDevice(&prev_dev);   // the caller's current device is restored on every exit path
   auto fail = [&](const std::string& m) {
     set_err(err, err_cap, m);
+    if (prev_dev >= 0) (void)hipSetDevice(prev_dev);
     for (void* p : mine) free(p);
     if (rank != root) for (int i = 0; i < n_blobs; i++) data[i] = nullptr;
     if (dbuf) (void)hipFree(dbuf);
@@ -109,6 +119,7 @@ int rt_broadcast_blobs(const void* id, int rank, int world, int device_id, int r
   (void)hipFree(dbuf);
   (void)hipStreamDestroy(st);
   r->CommDestroy(comm);
+  if (prev_dev >= 0) (void)hipSetDevice(prev_dev);
   return RT_OK;
 }
 

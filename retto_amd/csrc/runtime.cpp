@@ -5,8 +5,22 @@
 
 #include <cstdio>
 #include <cstring>
+#include <mutex>
+#include <set>
+#include <utility>
 
 namespace rt {
+
+void allow_big_lds(const void* kernel, int bytes) {
+  static std::mutex mu;
+  static std::set<std::pair<int, const void*>> done;
+  int dev = 0;
+  RT_HIP_CHECK(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> lk(mu);
+  if (done.count({dev, kernel})) return;
+  RT_HIP_CHECK(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+  done.insert({dev, kernel});
+}
 
 // ---- sources / blob ---------------------------------------------------------------
 std::vector<uint8_t> read_source_bytes(const char* path, const void* data, size_t len, const char* what) {

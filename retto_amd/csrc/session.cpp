@@ -1,4 +1,6 @@
 #include "session.h"
+
+#include <charconv>
 #include "onnx_import.h"
 
 #include <algorithm>
@@ -416,12 +418,12 @@ std::string json_escape(const std::string& s) {
 std::string fnum(float v) {
   if (v != v || std::isinf(v)) return "null";  // serde_json writes non-finite floats as null
   if (v == 0.0f) return std::signbit(v) ? "-0.0" : "0.0";
-  char b[40];
-  int prec = 0;
-  for (; prec < 9; prec++) {  // shortest digit string that round-trips
-    snprintf(b, sizeof b, "%.*e", prec, (double)v);
-    if (strtof(b, nullptr) == v) break;
-  }
+  // std::to_chars (scientific, no precision) yields exactly the shortest digit string that round-trips, and -- unlike
+  // snprintf / strtof -- does not depend on LC_NUMERIC (a host that called setlocale() with a comma-decimal locale would
+  // otherwise get invalid JSON)
+  char b[48];
+  const std::to_chars_result tr = std::to_chars(b, b + sizeof b - 1, v, std::chars_format::scientific);
+  *tr.ptr = 0;
   std::string digits; int exp10 = 0; bool neg = false;
   {
     const char* p = b;

@@ -56,22 +56,30 @@ def digest(blobs: Sequence[bytes]) -> str:
     return h.hexdigest()
 
 
+def process_shard(mine: Sequence[int], process, chunk: int = 32) -> list:
+    """Runs ``process(page_ids) -> list of per-page results`` over this rank's shard in calls of at most ``chunk`` pages (input
+    order inside the shard); returns [(page id, result)].  The per-rank half of ``run_global_batch``: bench.py's timed steps
+    call it directly (no collective in the data path), the gather below is only taken when every rank needs all results."""
+    out = []
+    for c0 in range(0, len(mine), chunk):
+        ids = list(mine[c0:c0 + chunk])
+        res = process(ids)
+        if len(res) != len(ids):
+            raise RuntimeError("process() must return one result per page")
+        out += list(zip(ids, res))
+    return out
+
+
 def run_global_batch(sizes: Sequence[Tuple[int, int]], rank: int, world: int, process, est_lines: Optional[Sequence[int]] = None,
                      chunk: int = 32) -> list:
     """The sharded form of retto-cli's loop over files (/root/reference/retto-cli/src/main.rs:80-86) for ONE list of pages:
     every rank takes its LPT shard (``shard_pages``), runs ``process(page_ids) -> list of per-page results`` over it in calls
     of at most ``chunk`` pages (input order inside the shard), and the per-page results of all ranks are gathered and returned
     in INPUT order on every rank (``torch.distributed.all_gather_object`` of small result records; no tensor collective)."""
-    import torch.distributed as dist
     mine = sorted(shard_pages(sizes, world, rank, est_lines))
-    out = []
-    for c0 in range(0, len(mine), chunk):
-        ids = mine[c0:c0 + chunk]
-        res = process(ids)
-        if len(res) != len(ids):
-            raise RuntimeError("process() must return one result per page")
-        out += list(zip(ids, res))
+    out = process_shard(mine, process, chunk)
     if world > 1:
+        import torch.distributed as dist
         parts = [None] * world
         dist.all_gather_object(parts, out)
         out = [x for part in parts for x in part]

@@ -6,6 +6,8 @@ roofline line in bench.py can price the dominant kernel.  Pure arithmetic; no GP
 """
 from __future__ import annotations
 
+import os
+
 from collections import defaultdict
 from typing import Dict, Iterable, Tuple
 
@@ -26,8 +28,8 @@ def gemm_pw_label(M: int, N: int, se: bool = False) -> str:
     npad = (N + 15) // 16 * 16
     if se and M >= 8192 and npad >= 128:
         return "gemm_pw/k_gemm_wide<2,5,4,3>+se" if npad % 240 == 0 and M >= 16384 else "gemm_pw/k_gemm_wide<2,4,4,2>+se"
-    if npad % 240 == 0 and M >= 131072:
-        return "gemm_pw/k_gemm_wide<4,5,4,3>"
+    if npad % 240 == 0 and M >= 131072:   # (the persistent LDS-DMA form unless RT_GEMM_DMA=0 keeps the register-staged tile)
+        return "gemm_pw/k_gemm32p" if os.environ.get("RT_GEMM_DMA", "1") != "0" else "gemm_pw/k_gemm_wide<4,5,4,3>"
     if npad % 240 == 0 and M >= 16384:
         return "gemm_pw/k_gemm_wide<2,5,4,3>"
     return "gemm_pw/thin"

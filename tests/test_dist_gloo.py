@@ -97,3 +97,28 @@ def test_global_batch_gather_is_in_input_order_and_world_invariant():
         assert all(len(c) <= 8 for c in calls) and all(c == sorted(c) for c in calls)
     ids0 = [i for c in res[0][2] for i in c]; ids1 = [i for c in res[1][2] for i in c]
     assert sorted(ids0 + ids1) == list(range(37)) and not set(ids0) & set(ids1)
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` without torch.distributed.run: bench.py starts the two ranks itself (fresh child processes,
+    RANK / WORLD_SIZE / MASTER_* in their environment), the weights go rank 0 -> rank 1 over the process group (gloo here, RCCL
+    on the GPU box), a global page list is sharded and gathered in input order, and rank 0's ONE JSON line is relayed."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    pr = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--dry-run"],
+                        env=env, capture_output=True, text=True, timeout=600)
+    assert pr.returncode == 0, pr.stderr[-2000:]
+    lines = [ln for ln in pr.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, pr.stdout
+    j = json.loads(lines[0])
+    assert j["dry_run"] and j["n_gpus"] == 2 and j["rccl_ranks"] == 2 and j["bcast_ms"] is not None
+    dig = j["blob_digest"][:8]
+    assert j["gathered"] == ["%d:%s" % (i, dig) for i in range(19)]   # every page once, input order, same weights on both ranks
+    # one rank: same line, no process group
+    pr1 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--dry-run"], env=env, capture_output=True, text=True, timeout=600)
+    assert pr1.returncode == 0, pr1.stderr[-2000:]
+    j1 = json.loads([ln for ln in pr1.stdout.splitlines() if ln.startswith("{")][0])
+    assert j1["gathered"] == j["gathered"] and j1["rccl_ranks"] == 1

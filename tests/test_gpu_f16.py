@@ -23,6 +23,7 @@ DET_MEAN_F16 = 3e-3
 CLS_ATOL_F16 = 2e-2
 REC_ATOL_F16 = 3e-2       # per-class softmax probabilities
 REC_MARGIN_F16 = 6e-2     # token ids must agree wherever the fp32 top-2 margin exceeds this
+REC_EQUAL_FLOOR_F16 = 0.9  # ... and overall on at least this fraction of the time steps (measured: 0.99-1.0)
 
 
 @pytest.fixture(scope="module")
@@ -188,7 +189,7 @@ def test_rec_net_f16(hip16, oracle_session, n, w):
     ref = N.rec_forward(oracle_session.wr, torch.from_numpy(x)).numpy()
     frac_decisive, frac_equal = _check_rec(got, ref, REC_ATOL_F16, REC_MARGIN_F16)
     print(f"rec f16 n={n} w={w}: decisive {frac_decisive:.3f}, argmax equal {frac_equal:.3f}")
-    assert frac_equal > 0.9
+    assert frac_equal > REC_EQUAL_FLOOR_F16
 
 
 # ---------------------------------------------------------------- server networks (config 5) vs the fp32 oracle
@@ -215,6 +216,9 @@ def test_server_rec_net(hip_server, server_models, n, w):
     ref = N.srec_forward(wr, torch.from_numpy(x)).numpy()
     frac_decisive, frac_equal = _check_rec(got, ref, REC_ATOL_F16, REC_MARGIN_F16)
     print(f"server rec n={n} w={w}: decisive {frac_decisive:.3f}, argmax equal {frac_equal:.3f}")
+    # C5 is a TOLERANCE configuration: token ids are only required equal where the fp32 margin exceeds REC_MARGIN_F16;
+    # the floor below is what the fp16 arithmetic keeps of the fp32 argmax overall on these weights
+    assert frac_equal > REC_EQUAL_FLOOR_F16
 
 
 # ---------------------------------------------------------------- whole pipeline in fp16: discrete stages stay bit-exact
@@ -238,3 +242,95 @@ def test_pipeline_f16_teacher_forced(hip16, hip_server, models, server_models, w
     assert [c.label.label for c in got.cls_result] == list(ref.cls_labels)
     for g, t in zip(got.rec_result, ref.rec_tokens):
         assert np.array_equal(g.tokens, t)
+
+
+# ---------------------------------------------------------------- BASELINE config 5 at its real size
+def test_server_det_net_full_page(hip_server, server_models):
+    """The server det net on one full 960 x 960 page (the C5 page size: the LDS-DMA kernels pick their tile shapes,
+    ring depths and the XCD remap from the launch size) against the fp32 torch oracle, same tolerances as the small cases."""
+    wd = N.read_blob(server_models[0])
+    x = np.random.default_rng(960).uniform(-1, 1, (1, 3, 960, 960)).astype(np.float32)
+    got = hip_server.worker.det(x)
+    ref = N.sdet_forward(wd, torch.from_numpy(x)).numpy()
+    assert got.shape == ref.shape == (1, 1, 960, 960) and np.isfinite(got).all()
+    err = np.abs(got - ref)
+    print(f"server det 1x960x960: max err {err.max():.4f}, mean {err.mean():.5f}")
+    assert err.max() <= DET_ATOL_F16 and err.mean() <= DET_MEAN_F16
+    far = np.abs(ref - 0.3) > DET_ATOL_F16
+    assert ((got > 0.3) == (ref > 0.3))[far].all()
+
+
+def test_server_rec_net_full_batch(hip_server, server_models):
+    """The server rec net at a full line group (24 lines x 640: the GEMM / conv shapes of a C5 step) against the oracle."""
+    wr = N.read_blob(server_models[2])
+    n, w = 24, 640
+    x = np.random.default_rng(2464).uniform(-1, 1, (n, 3, 48, w)).astype(np.float32)
+    for i in range(n):
+        x[i, :, :, 320 + 13 * i:] = 0.0   # ragged zero padding like resize_norm_image
+    got = hip_server.worker.rec(x)
+    ref = N.srec_forward(wr, torch.from_numpy(x)).numpy()
+    frac_decisive, frac_equal = _check_rec(got, ref, REC_ATOL_F16, REC_MARGIN_F16)
+    print(f"server rec n={n} w={w}: decisive {frac_decisive:.3f}, argmax equal {frac_equal:.3f}")
+    assert frac_equal > REC_EQUAL_FLOOR_F16
+
+
+def test_c5_full_size_properties(hip_server, models, server_models):
+    """BASELINE config 5 at its per-GPU size (32 pages of 960 x 960, 32 planted lines each, PP-OCRv4 server graphs in fp16,
+    3 lanes) through size-independent properties, the fp16 counterpart of test_c3_full_size_properties:
+    (1) batch / lane / order composition does not change a page's discrete results -- the batch equals the same pages
+        shuffled and pages run alone: boxes, box scores, cls labels and token ids bit for bit; line / label scores equal to the
+        fp16 tolerance (a page alone runs other kernel shapes: tile sizes follow the launch size);
+    (2) two pages of the batch equal the oracle pipeline teacher-forced by the fp16 worker in the reference's batches of 6;
+    (3) the planted lines come back: 32 boxes per page, each inside its planted rectangle grown by the unclip offset."""
+    n = 32
+    pages, maps, rects = [], [], []
+    for i in range(n):
+        page, rc = workload.planted_page(960, 960, 32, seed=100 + i)
+        pages.append(page); rects.append(rc)
+        maps.append(workload.planted_map(960, 960, 960, 960, rc))
+    full = hip_server.run_batch(pages, det_map_override=maps)
+    assert np.isfinite(hip_server.last_det_checksum)
+
+    def same(a, b, strict):
+        assert len(a.det_result) == len(b.det_result) == 32
+        assert np.array_equal(np.stack([d.boxes.as_array() for d in a.det_result]), np.stack([d.boxes.as_array() for d in b.det_result]))
+        assert [d.score for d in a.det_result] == [d.score for d in b.det_result]
+        assert [c.label.label for c in a.cls_result] == [c.label.label for c in b.cls_result]
+        for x, y in zip(a.rec_result, b.rec_result):
+            assert np.array_equal(x.tokens, y.tokens) and x.text == y.text
+        sa, sb = np.array([x.score for x in a.rec_result]), np.array([y.score for y in b.rec_result])
+        ca, cb = np.array([c.label.score for c in a.cls_result]), np.array([c.label.score for c in b.cls_result])
+        if strict:
+            assert np.array_equal(sa, sb, equal_nan=True) and np.array_equal(ca, cb)
+        else:
+            np.testing.assert_allclose(sa, sb, atol=REC_ATOL_F16, equal_nan=True)
+            np.testing.assert_allclose(ca, cb, atol=CLS_ATOL_F16)
+
+    from oracle.pipeline import OracleSession
+    o = OracleSession(*(models[:3] + (server_models[3],)))   # the oracle's own nets are unused: all three workers are replaced
+    o.det_worker, o.cls_worker, o.rec_worker = hip_server.worker.det, hip_server.worker.cls, hip_server.worker.rec
+    for j in (0, 21):
+        ref = o.run(pages[j], det_map_override=maps[j])
+        assert len(ref.det_boxes) == 32
+        assert np.array_equal(np.stack([d.boxes.as_array() for d in full[j].det_result]), ref.det_boxes)
+        assert [c.label.label for c in full[j].cls_result] == list(ref.cls_labels)
+        for g, t in zip(full[j].rec_result, ref.rec_tokens):
+            assert np.array_equal(g.tokens, t)
+        np.testing.assert_allclose([g.score for g in full[j].rec_result], ref.rec_scores, atol=REC_ATOL_F16, equal_nan=True)
+
+    perm = np.random.default_rng(5).permutation(n)
+    shuffled = hip_server.run_batch([pages[j] for j in perm], det_map_override=[maps[j] for j in perm])
+    for k, j in enumerate(perm):
+        same(shuffled[k], full[j], strict=False)
+    again = hip_server.run_batch(pages, det_map_override=maps)      # the same call twice: bit-identical (no races in the LDS-DMA kernels)
+    for a, b in zip(again, full):
+        same(a, b, strict=True)
+    for j in (0, 9, 31):
+        alone = hip_server.run_batch([pages[j]], det_map_override=[maps[j]])[0]
+        same(alone, full[j], strict=False)
+    for r, rc in zip(full, rects):
+        got = np.stack([d.boxes.as_array() for d in r.det_result]).reshape(-1, 4, 2)
+        for x0, y0, x1, y1 in rc:
+            inside = [(b[:, 0].min() >= x0 - 12 and b[:, 0].max() <= x1 + 12 and b[:, 1].min() >= y0 - 12 and b[:, 1].max() <= y1 + 12)
+                      for b in got]
+            assert sum(inside) == 1, (x0, y0, x1, y1)

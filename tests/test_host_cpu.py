@@ -222,3 +222,39 @@ def test_json_numbers_are_shortest_round_trip_like_serde_json():
         assert len(digits) <= 9
         if len(digits) > 1:                                           # no shorter digit string round-trips
             assert np.float32(float("%.*e" % (len(digits) - 2, float(v)))) != v, (v, s)
+
+
+def test_rt_create_rejects_a_config_of_another_size():
+    """rt_config carries its own size (set by rt_config_default): a host compiled against another version of the header gets
+    RT_ERR_INVALID from rt_create instead of fields read past the end of its struct.  (Checked before any device is touched.)"""
+    lib = _lib.load()
+    c = _lib.Config(); lib.rt_config_default(C.byref(c))
+    assert c.struct_size == C.sizeof(_lib.Config)
+    c.struct_size -= 4
+    out = C.c_void_p()
+    lib.rt_create.argtypes = [C.POINTER(_lib.Config), C.POINTER(C.c_void_p)]
+    assert lib.rt_create(C.byref(c), C.byref(out)) == 8 and not out.value   # RT_ERR_INVALID
+
+
+def test_format_f32_ignores_the_locale():
+    """rt_format_f32 (the f32 -> JSON text of rt_results_json) must not depend on LC_NUMERIC."""
+    import locale
+    lib = _lib.load()
+    lib.rt_format_f32.restype = C.c_int
+    lib.rt_format_f32.argtypes = [C.c_float, C.c_char_p, C.c_size_t]
+
+    def fmt(v):
+        b = C.create_string_buffer(64); lib.rt_format_f32(v, b, 64); return b.value.decode()
+    want = {0.9: "0.9", 123.0: "123.0", 1.234e-7: "1.234e-7", 1e30: "1e30", 0.00001234: "0.00001234", -2.5: "-2.5"}
+    assert {v: fmt(v) for v in want} == want
+    old = locale.setlocale(locale.LC_NUMERIC)
+    try:
+        for name in ("de_DE.UTF-8", "fr_FR.UTF-8", "de_DE", "fr_FR"):
+            try:
+                locale.setlocale(locale.LC_NUMERIC, name)
+                break
+            except locale.Error:
+                continue
+        assert {v: fmt(v) for v in want} == want
+    finally:
+        locale.setlocale(locale.LC_NUMERIC, old)
