@@ -100,7 +100,7 @@ typedef struct rt_config {
   int32_t rec_image_shape[3]; /* 3,48,320 */
   int32_t rec_batch_num;      /* 6 */
   /* backend knobs (no reference counterpart) */
-  int32_t max_boxes_per_page; /* capacity of the per-page box list; 0 = default 4096 */
+  int32_t max_boxes_per_page; /* capacity of the per-page box list (the reference's list is unbounded); 0 = default 8192, at most 65536 */
   int32_t det_sub_batch;      /* pages per det launch group; 0 = default */
   int32_t lanes;              /* concurrent page streams inside rt_run_batch (1..4); 0 = default 3 */
   int32_t dtype;              /* rt_dtype: arithmetic of the three networks.  RT_DTYPE_F32 (default) = what the reference's

@@ -86,8 +86,8 @@ int rt_create(const rt_config* cfg, rt_session** out) {
              (rt_session*)nullptr, "unsupported cls/rec image_shape for the PP-OCRv4 mobile graphs");
   RT_REQUIRE(cfg->lanes >= 0 && cfg->lanes <= 4, (rt_session*)nullptr, "lanes must be in [0, 4]");
   RT_REQUIRE(cfg->dtype == RT_DTYPE_F32 || cfg->dtype == RT_DTYPE_F16, (rt_session*)nullptr, "dtype must be RT_DTYPE_F32 or RT_DTYPE_F16");
-  RT_REQUIRE(cfg->max_boxes_per_page >= 0 && cfg->max_boxes_per_page <= 4096, (rt_session*)nullptr,
-             "max_boxes_per_page must be in [0, 4096]");
+  RT_REQUIRE(cfg->max_boxes_per_page >= 0 && cfg->max_boxes_per_page <= 65536, (rt_session*)nullptr,
+             "max_boxes_per_page must be in [0, 65536]");
   return guarded(nullptr, [&] { *out = rt_session_create(cfg); });
 }
 void rt_destroy(rt_session* s) {

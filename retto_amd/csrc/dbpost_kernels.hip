@@ -23,6 +23,8 @@ struct DbWs {
   int *rowmin, *rowmax; int row_cap;
   int2* hull; int hull_cap;
   DbBox* cand; int cand_cap;
+  unsigned *sort_a, *sort_b;   // index runs of the reading-order sort when a page has more candidates than fit in LDS
+  float *sort_cx, *sort_cy;
 };
 struct DbPage {
   const float* pred; int H, W, ori_h, ori_w;
@@ -47,6 +49,8 @@ static DbWs carve(void* base, int H, int W, int max_boxes, size_t* total) {
   ws.hull = (int2*)take((size_t)ws.hull_cap * sizeof(int2));
   ws.cand_cap = max_boxes;
   ws.cand = (DbBox*)take((size_t)max_boxes * sizeof(DbBox));
+  ws.sort_a = (unsigned*)take((size_t)max_boxes * 4); ws.sort_b = (unsigned*)take((size_t)max_boxes * 4);
+  ws.sort_cx = (float*)take((size_t)max_boxes * 4); ws.sort_cy = (float*)take((size_t)max_boxes * 4);
   *total = o;
   return ws;
 }
@@ -242,35 +246,66 @@ struct DP { double x, y; };
 
 // imageproc geometry::rotating_calipers on a hull of >= 3 points.
 // get(i) returns hull point i as doubles.  out: 4 corners TL,TR,BR,BL, floor()ed.
+// One wavefront runs this (every lane with the same n / get): the edges are dealt over the 64 lanes -- each lane does the
+// atan2 / sin / cos and the projection loop of ITS edge, which is where the time goes (serially ~8 k cycles per edge, 35
+// edges on a text line's hull) -- and the sequential "first edge with the smallest area" is recovered by an argmin over
+// (area, edge index).  Vec::dedup drops an angle equal to its predecessor's; an element of a run of equal angles differs
+// from the last KEPT one exactly when it differs from its immediate predecessor, so each lane decides that from edge e - 1
+// alone.  Same f64 operations per edge as the sequential form: bit-identical.
+__device__ __forceinline__ double shfl_f64(double v, int src_lane) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __shfl(lo, src_lane); hi = __shfl(hi, src_lane);
+  return __hiloint2double(hi, lo);
+}
 template <typename Get>
 __device__ void rotating_calipers(int n, Get get, double* out8) {
   const double PI = 3.14159265358979323846264338327950288;
-  double min_area = 1.7976931348623157e308;
+  const double BIG = 1.7976931348623157e308;
+  const int lane = threadIdx.x & 63;
+  double min_area = BIG;
   DP res[4] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};
-  double prev_angle = 0.0;
-  for (int e = 0; e + 1 < n; e++) {  // points.windows(2): the closing edge is not visited
+  auto edge_angle = [&](int e) {
     DP a = get(e), b = get(e + 1);
-    double ex = b.x - a.x, ey = b.y - a.y;
-    double angle = fabs(fmod(atan2(ey, ex) + PI, PI / 2.0));
-    if (e > 0 && angle == prev_angle) continue;  // Vec::dedup
-    prev_angle = angle;
-    double s = sin(angle), c = cos(angle);
-    double min_x = 1.7976931348623157e308, max_x = -1.7976931348623157e308;
-    double min_y = 1.7976931348623157e308, max_y = -1.7976931348623157e308;
-    for (int i = 0; i < n; i++) {
-      DP p = get(i);
-      double rx = p.x * c + p.y * s;
-      double ry = p.y * c - p.x * s;
-      min_x = fmin(min_x, rx); max_x = fmax(max_x, rx);
-      min_y = fmin(min_y, ry); max_y = fmax(max_y, ry);
+    return fabs(fmod(atan2(b.y - a.y, b.x - a.x) + PI, PI / 2.0));
+  };
+  for (int e0 = 0; e0 + 1 < n; e0 += 64) {  // points.windows(2): the closing edge is not visited
+    const int e = e0 + lane;
+    double area = BIG;
+    DP r4[4] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};
+    if (e + 1 < n) {
+      const double angle = edge_angle(e);
+      const bool kept = e == 0 || !(angle == edge_angle(e - 1));  // Vec::dedup
+      if (kept) {
+        double s = sin(angle), c = cos(angle);
+        double min_x = BIG, max_x = -BIG, min_y = BIG, max_y = -BIG;
+        for (int i = 0; i < n; i++) {
+          DP p = get(i);
+          double rx = p.x * c + p.y * s;
+          double ry = p.y * c - p.x * s;
+          min_x = fmin(min_x, rx); max_x = fmax(max_x, rx);
+          min_y = fmin(min_y, ry); max_y = fmax(max_y, ry);
+        }
+        area = (max_x - min_x) * (max_y - min_y);
+        r4[0] = DP{max_x * c - min_y * s, min_y * c + max_x * s};
+        r4[1] = DP{min_x * c - min_y * s, min_y * c + min_x * s};
+        r4[2] = DP{min_x * c - max_y * s, max_y * c + min_x * s};
+        r4[3] = DP{max_x * c - max_y * s, max_y * c + max_x * s};
+      }
     }
-    double area = (max_x - min_x) * (max_y - min_y);
-    if (area < min_area) {
-      min_area = area;
-      res[0] = DP{max_x * c - min_y * s, min_y * c + max_x * s};
-      res[1] = DP{min_x * c - min_y * s, min_y * c + min_x * s};
-      res[2] = DP{min_x * c - max_y * s, max_y * c + min_x * s};
-      res[3] = DP{max_x * c - max_y * s, max_y * c + max_x * s};
+    // lowest lane among those with the smallest area that is < everything seen so far (NaN areas never win: `<` is false)
+    const bool cand = area < min_area;
+    double barea = cand ? area : BIG;
+    int blane = cand ? lane : 64;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const double oa = shfl_f64(barea, (lane ^ d));
+      const int ol = __shfl(blane, lane ^ d);
+      if (ol < 64 && (blane >= 64 || oa < barea || (oa == barea && ol < blane))) { barea = oa; blane = ol; }
+    }
+    if (blane < 64) {
+      min_area = barea;
+#pragma unroll
+      for (int k = 0; k < 4; k++) { res[k].x = shfl_f64(r4[k].x, blane); res[k].y = shfl_f64(r4[k].y, blane); }
     }
   }
   // stable sort of 4 by x (insertion sort)
@@ -434,13 +469,16 @@ __device__ float box_score_fast(const float* pred, int H, int W, const int* box)
       if (x <= hi)
         for (int k = 0; k < rc.n; k++) in = in || (x >= rc.lo[k] && x <= rc.hi[k]);
       const float v = in ? prow[x] : 0.0f;
-      unsigned long long m = __ballot(in);
+      const unsigned long long m = __ballot(in);
+      if (m == 0) continue;   // (wave-uniform)
       count += (unsigned long long)__popcll(m);
-      while (m) {
-        const int l = __ffsll((long long)m) - 1;
-        sum = sum + __shfl(v, l);
-        m &= m - 1;
-      }
+      // Sequential fold in pixel order, one v_readlane + one add per lane.  Masked lanes contribute +0.0f, which leaves
+      // a sum that is never -0.0 (it starts at +0.0 and probabilities are >= 0) bit for bit unchanged -- so the loop needs
+      // no per-pixel bit scan (the earlier ffs / shuffle / mask-update loop was ~50 cycles per pixel, most of this
+      // kernel's 320 us; this form is ~8).
+      const int vb = __float_as_int(v);
+#pragma unroll
+      for (int l = 0; l < 64; l++) sum = sum + __int_as_float(__builtin_amdgcn_readlane(vb, l));
     }
   }
   return count > 0 ? sum / (float)count : 0.0f;
@@ -650,47 +688,93 @@ __global__ __launch_bounds__(64) void k_contour_boxes(const DbPage* __restrict__
 // For the strict weak orders of the contract every stable sort gives this result; for the
 // comparator's non-transitive inputs this exact algorithm is the defined
 // behaviour and the oracle uses the same one.  Sorting works on indices + centres in LDS.
-#define RT_SORT_MAX 4096
+// Parallel form: (1) the discovery order is the order of the (unique) keys -- rank by counting for pages whose
+// candidates fit in LDS, through a bitmap of the key pixels + a prefix sum of its population counts otherwise (the
+// O(n^2) count would take seconds at 50 k candidates); (2) every merge pass runs its pairs of runs on different threads,
+// each pair merged sequentially by one thread exactly as above -- merge-path splitting of a pair is NOT used: its binary
+// search assumes a transitive comparator, and on non-transitive inputs it can take another path than the sequential
+// merge that defines the result.  The last passes have fewer pairs than threads (2 * width sequential steps each):
+// O(n) steps in all instead of O(n log n) on one thread.  Pages of up to RT_SORT_LDS candidates sort in LDS, larger
+// ones in the page's workspace (the reference's list is unbounded, det_processor.rs:279-335: no fixed cap here either,
+// only the configured max_boxes_per_page).
+#define RT_SORT_LDS 3072
 __global__ __launch_bounds__(256) void k_sort_boxes(const DbPage* __restrict__ pages) {
   const DbPage pg = pages[blockIdx.x];
   const DbWs& ws = pg.ws;
   DbBox* out = pg.boxes_out;
-  __shared__ float cx[RT_SORT_MAX], cy[RT_SORT_MAX];
-  __shared__ unsigned short ia[RT_SORT_MAX], ib[RT_SORT_MAX];
-  int n = min(min(ws.counters[3], ws.cand_cap), RT_SORT_MAX);
-  for (int i = threadIdx.x; i < n; i += 256) {
-    int key = ws.cand[i].key, rank = 0;
-    for (int j = 0; j < n; j++) rank += ws.cand[j].key < key;
-    ia[rank] = (unsigned short)i;
+  __shared__ float l_cx[RT_SORT_LDS], l_cy[RT_SORT_LDS];
+  __shared__ unsigned l_a[RT_SORT_LDS], l_b[RT_SORT_LDS];
+  __shared__ int part[256];
+  const int n = min(ws.counters[3], ws.cand_cap);
+  const bool small = n <= RT_SORT_LDS;
+  float* cx = small ? l_cx : ws.sort_cx;
+  float* cy = small ? l_cy : ws.sort_cy;
+  unsigned* ia = small ? l_a : ws.sort_a;
+  unsigned* ib = small ? l_b : ws.sort_b;
+  const int tid = threadIdx.x;
+  if (small) {
+    int* keys = reinterpret_cast<int*>(l_b);   // (free until the first merge pass)
+    for (int i = tid; i < n; i += 256) keys[i] = ws.cand[i].key;
+    __syncthreads();
+    for (int i = tid; i < n; i += 256) {
+      const int key = keys[i];
+      int rank = 0;
+      for (int j = 0; j < n; j++) rank += keys[j] < key;
+      ia[rank] = (unsigned)i;
+    }
+  } else {
+    // keys are pixel indices (unique per contour): bitmap in ws.parent, per-word exclusive prefix of the set bits in ws.ymin
+    const int N = pg.H * pg.W, nw = (N + 32) / 32 + 1;   // (hole contours carry root - 1 >= -1: keys are shifted by one)
+    unsigned* bits = reinterpret_cast<unsigned*>(ws.parent);
+    int* pref = ws.ymin;
+    for (int w = tid; w < nw; w += 256) bits[w] = 0u;
+    __syncthreads();
+    for (int i = tid; i < n; i += 256) { const int k = ws.cand[i].key + 1; atomicOr(&bits[k >> 5], 1u << (k & 31)); }
+    __syncthreads();
+    const int per = (nw + 255) / 256, w0 = tid * per, w1 = min(nw, w0 + per);
+    int local = 0;
+    for (int w = w0; w < w1; w++) { pref[w] = local; local += __popc(bits[w]); }
+    part[tid] = local;
+    __syncthreads();
+    if (tid == 0) { int run = 0; for (int t = 0; t < 256; t++) { const int v = part[t]; part[t] = run; run += v; } }
+    __syncthreads();
+    for (int w = w0; w < w1; w++) pref[w] += part[tid];
+    __syncthreads();
+    for (int i = tid; i < n; i += 256) {
+      const int k = ws.cand[i].key + 1;
+      ia[pref[k >> 5] + __popc(bits[k >> 5] & ((1u << (k & 31)) - 1u))] = (unsigned)i;
+    }
+  }
+  for (int i = tid; i < n; i += 256) {
     cx[i] = (ws.cand[i].pts[0] + ws.cand[i].pts[4]) / 2.0f;
     cy[i] = (ws.cand[i].pts[1] + ws.cand[i].pts[5]) / 2.0f;
   }
   __syncthreads();
-  if (threadIdx.x == 0) {
-    auto less = [&](int a, int b) {
-      if (fabsf(cy[a] - cy[b]) < 10.0f) return cx[a] < cx[b];
-      return cy[a] < cy[b];
-    };
-    unsigned short* src = ia; unsigned short* dst = ib;
-    for (int width = 1; width < n; width *= 2) {
-      for (int lo = 0; lo < n; lo += 2 * width) {
-        int mid = min(lo + width, n), hi = min(lo + 2 * width, n);
-        int i = lo, j = mid, k = lo;
-        while (i < mid && j < hi) {
-          if (less(src[j], src[i])) dst[k++] = src[j++];
-          else dst[k++] = src[i++];
-        }
-        while (i < mid) dst[k++] = src[i++];
-        while (j < hi) dst[k++] = src[j++];
+  auto less = [&](unsigned a, unsigned b) {
+    if (fabsf(cy[a] - cy[b]) < 10.0f) return cx[a] < cx[b];
+    return cy[a] < cy[b];
+  };
+  unsigned* src = ia; unsigned* dst = ib;
+  for (int width = 1; width < n; width *= 2) {
+    const int pairs = (n + 2 * width - 1) / (2 * width);
+    for (int pr = tid; pr < pairs; pr += 256) {
+      const int lo = pr * 2 * width, mid = min(lo + width, n), hi = min(lo + 2 * width, n);
+      int i = lo, j = mid, k = lo;
+      while (i < mid && j < hi) {
+        if (less(src[j], src[i])) dst[k++] = src[j++];
+        else dst[k++] = src[i++];
       }
-      unsigned short* t = src; src = dst; dst = t;
+      while (i < mid) dst[k++] = src[i++];
+      while (j < hi) dst[k++] = src[j++];
     }
-    if (src != ia) for (int i = 0; i < n; i++) ia[i] = src[i];
-    pg.count_out[0] = n;
-    pg.count_out[1] = ws.counters[4] | (ws.counters[3] > RT_SORT_MAX ? 1 : 0);
+    __syncthreads();
+    unsigned* t = src; src = dst; dst = t;
   }
-  __syncthreads();
-  for (int i = threadIdx.x; i < n; i += 256) out[i] = ws.cand[ia[i]];
+  if (tid == 0) {
+    pg.count_out[0] = n;
+    pg.count_out[1] = ws.counters[4];
+  }
+  for (int i = tid; i < n; i += 256) out[i] = ws.cand[src[i]];
 }
 
 void db_postprocess_batch(hipStream_t st, int n, const DbPageIn* in, const DbParams& p, void* const* workspaces,

@@ -955,7 +955,12 @@ void conv_sp(hipStream_t st, int KH, int KW, const float* x, int ldx, const ImgG
 // instead of re-reading HBM.  Accumulation order per output: bias, then taps in (dy, dx) order.
 // 128 VGPRs (4 waves/SIMD): +15 % over 3 waves at C = 480.  Measured and rejected: lane groups
 // spanning whole pixels with all the weights in LDS (1.2-1.5x slower), one-row-ahead register
-// prefetch (hipcc hoists every load: spills).
+// prefetch (hipcc hoists every load: spills).  Round 3, measured and rejected: a column-sweep form (k_dwconv_sweep: a thread
+// owns a 4-pixel x 4-channel column of the whole 12-row map and streams the input rows once through a rotating window of
+// K accumulator rows -- every input row fetched once, bit-identical): 80 accumulator + 32 input registers need the
+// 168-register budget (3 waves / SIMD) and the kernel ran 0.674 vs 0.611 ms on the 1.23 M-pixel 256-channel maps.  The
+// 1.63x over-fetch of this kernel (PMC) is served by the Infinity Cache; what bounds it is the latency of the one input
+// row a wave keeps in flight (waves parked on loads 55 % of the cycles), so occupancy beats fewer bytes.
 __device__ int g_dw_xcd_dev = 1;  // XCD-aware block order of k_dwconv_rows (A/B: set_dw_xcd)
 template <int K, int R, int SH, int SW, int POOL, int LP = 8>  // LP lanes (16 bytes each) side by side on a pixel: 32- or 64-channel slabs
 __global__ __launch_bounds__(256, 4) void k_dwconv_rows(const float* __restrict__ x, const ImgGeom* __restrict__ gin,

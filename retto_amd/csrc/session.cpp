@@ -268,7 +268,7 @@ static pp::DbParams db_params(const rt_config& c) {
   p.min_size = c.det_min_mini_box_size; p.dilate = c.det_dilation;
   return p;
 }
-static int max_boxes_of(const rt_config& c) { return c.max_boxes_per_page > 0 ? c.max_boxes_per_page : 4096; }
+static int max_boxes_of(const rt_config& c) { return c.max_boxes_per_page > 0 ? c.max_boxes_per_page : 8192; }
 
 void rt_session::det_postprocess(const float* pred, int h, int w, int ori_h, int ori_w, float* boxes, float* scores,
                                  int max_out, int* n_out) {

@@ -328,6 +328,36 @@ def test_det_postprocess_noise_full_page(hip_session):
     assert np.array_equal(gb, rb) and np.array_equal(gs.view(np.uint32), rs.view(np.uint32))
 
 
+def test_det_postprocess_more_boxes_than_the_old_cap(hip_session):
+    """The reference's box list is unbounded (det_processor.rs:279-335).  A page of 5 329 small blobs (more than the 4 096
+    the sort kernel used to hold in LDS, and more than fit its LDS path now) must come back complete, in the oracle's reading
+    order, instead of RT_ERR_CAPACITY; with max_boxes_per_page = 16 384 a denser page (11 k boxes) takes the workspace sort."""
+    pred = np.full((960, 960), 0.02, np.float32)
+    for gy in range(73):
+        for gx in range(73):
+            y0, x0 = 4 + 13 * gy, 4 + 13 * gx
+            pred[y0:y0 + 8, x0:x0 + 8] = 0.85 + 0.001 * ((gx * 7 + gy * 3) % 50)
+    gb, gs = hip_session.det_postprocess(pred, 960, 960)
+    rb, rs = R.det_postprocess(pred, 960, 960)
+    assert len(rb) == 73 * 73 and len(gb) == len(rb)
+    assert np.array_equal(gb, rb) and np.array_equal(gs.view(np.uint32), rs.view(np.uint32))
+    cfg = retto_amd.synthetic_session_config(0)
+    cfg.max_boxes_per_page = 16384
+    s = retto_amd.RettoSession(cfg)
+    try:
+        pred = np.full((1280, 1280), 0.02, np.float32)
+        for gy in range(105):
+            for gx in range(105):
+                y0, x0 = 3 + 12 * gy, 3 + 12 * gx
+                pred[y0:y0 + 7, x0:x0 + 7] = 0.8 + 0.001 * ((gx * 5 + gy * 11) % 90)
+        gb, gs = s.det_postprocess(pred, 1280, 1280)
+        rb, rs = R.det_postprocess(pred, 1280, 1280)
+        assert len(rb) == 105 * 105 and len(gb) == len(rb)
+        assert np.array_equal(gb, rb) and np.array_equal(gs.view(np.uint32), rs.view(np.uint32))
+    finally:
+        s.close()
+
+
 def test_det_postprocess_sparse_noise(hip_session):
     rng = np.random.default_rng(100)
     pred = (rng.uniform(0, 1, (480, 640)) > 0.93).astype(np.float32) * 0.9 + 0.01   # many tiny blobs
