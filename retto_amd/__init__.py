@@ -488,7 +488,7 @@ class RettoSession:
         self._hd.close()
 
 
-MODEL_DET, MODEL_CLS, MODEL_REC = 0, 1, 2
+MODEL_DET, MODEL_CLS, MODEL_REC, MODEL_SDET, MODEL_SREC = 0, 1, 2, 3, 4   # (DET / REC sources also take the server .onnx files)
 
 
 def onnx_to_rtwb(which: int, onnx_bytes: bytes) -> bytes:

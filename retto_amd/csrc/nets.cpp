@@ -690,6 +690,69 @@ std::vector<ManifestEntry> model_manifest(int which) {
     }
     mf_conv(m, "cls.conv2", 200, cin, 1, 1);
     mf_linear(m, "cls.head.fc", 200, 2);
+  } else if (which == MODEL_SDET || which == MODEL_SREC) {
+    // PP-OCRv4 server graphs (nets_f16.cpp: DetServerH / RecServerH; layer names as retto_amd/synth.py writes them), in the
+    // forward order of the PaddleOCR modules: PPHGNet_small (stem, then per stage the depthwise down-sample, per block the six
+    // 3x3 layers, the 1x1 aggregation and the ESE gate's 1x1), LKPAN with IntraCL blocks, PFHeadLocal.
+    const bool det = which == MODEL_SDET;
+    const std::string pre = det ? "sdet" : "srec";
+    const int stem[3] = {64, 64, 128};
+    int cin = 3;
+    for (int i = 0; i < 3; i++) { mf_conv(m, pre + ".stem" + std::to_string(i), stem[i], cin, 3, 3); cin = stem[i]; }
+    struct St { const char* name; int cin, mid, cout, blocks; bool down; };
+    const St stages[4] = {{"st1", 128, 128, 256, 1, !det}, {"st2", 256, 160, 512, 1, true}, {"st3", 512, 192, 768, 2, true}, {"st4", 768, 224, 1024, 1, true}};
+    for (const St& st : stages) {
+      const std::string p = pre + "." + st.name;
+      if (st.down) mf_conv(m, p + ".ds", st.cin, 1, 3, 3);
+      for (int b = 0; b < st.blocks; b++) {
+        const int bin = b == 0 ? st.cin : st.cout;
+        int c = bin;
+        const std::string pb = p + ".b" + std::to_string(b);
+        for (int l = 0; l < 6; l++) { mf_conv(m, pb + ".l" + std::to_string(l), st.mid, c, 3, 3); c = st.mid; }
+        mf_conv(m, pb + ".agg", st.cout, bin + 6 * st.mid, 1, 1);
+        mf_conv(m, pb + ".ese", st.cout, st.cout, 1, 1);
+      }
+    }
+    if (det) {
+      const int C = 256, Q = 64, R = 32, outs[4] = {256, 512, 768, 1024};
+      for (int j = 3; j >= 0; j--) mf_conv(m, "sdet.neck.ins" + std::to_string(j), C, outs[j], 1, 1, false);
+      for (int j = 3; j >= 0; j--) mf_conv(m, "sdet.neck.inp" + std::to_string(j), Q, C, 9, 9, false);
+      for (int j = 0; j < 3; j++) mf_conv(m, "sdet.neck.panhead" + std::to_string(j), Q, Q, 3, 3, false);
+      for (int j = 0; j < 4; j++) mf_conv(m, "sdet.neck.panlat" + std::to_string(j), Q, Q, 9, 9, false);
+      for (int j = 4; j >= 1; j--) {
+        const std::string p = "sdet.neck.incl" + std::to_string(j);
+        mf_conv(m, p + ".reduce", R, Q, 1, 1);
+        for (int k : {7, 5, 3}) {
+          mf_conv(m, p + ".c" + std::to_string(k), R, R, k, k);
+          mf_conv(m, p + ".v" + std::to_string(k), R, R, k, 1);
+          mf_conv(m, p + ".q" + std::to_string(k), R, R, 1, k);
+        }
+        mf_conv(m, p + ".ret", Q, R, 1, 1);
+      }
+      mf_conv(m, "sdet.head.conv1", Q, C, 3, 3);
+      m.push_back({"sdet.head.deconv1.w", {Q, Q, 2, 2}}); m.push_back({"sdet.head.deconv1.b", {Q}});
+      m.push_back({"sdet.head.deconv2.w", {Q, 1, 2, 2}}); m.push_back({"sdet.head.deconv2.b", {1}});
+      mf_conv(m, "sdet.head.local3", Q, Q + 1, 3, 3);
+      mf_conv(m, "sdet.head.local1", 1, Q, 1, 1);
+    } else {
+      const int C = 1024, D = 120;
+      mf_conv(m, "srec.neck.conv1", C / 8, C, 1, 3);
+      mf_conv(m, "srec.neck.conv2", D, C / 8, 1, 1);
+      for (int i = 0; i < 2; i++) {
+        const std::string p = "srec.neck.blk" + std::to_string(i);
+        mf_linear(m, p + ".qkv", D, 3 * D);
+        mf_linear(m, p + ".proj", D, D);
+        mf_ln(m, p + ".norm1", D);
+        mf_linear(m, p + ".fc1", D, 2 * D);
+        mf_linear(m, p + ".fc2", 2 * D, D);
+        mf_ln(m, p + ".norm2", D);
+      }
+      mf_ln(m, "srec.neck.norm", D);
+      mf_conv(m, "srec.neck.conv3", C, D, 1, 1);
+      mf_conv(m, "srec.neck.conv4", C / 8, 2 * C, 1, 3);
+      mf_conv(m, "srec.neck.conv1x1", D, C / 8, 1, 1);
+      m.push_back({"srec.head.fc.w", {D, -1}}); m.push_back({"srec.head.fc.b", {-1}});
+    }
   } else {
     throw RtError(8, "model_manifest: unknown model kind");
   }

@@ -268,6 +268,13 @@ bool looks_like_rtwb(const std::vector<uint8_t>& bytes) { return bytes.size() >=
 std::vector<uint8_t> onnx_to_rtwb(int which, const uint8_t* data, size_t len) {
   const Graph g = parse_model(data, len);
   std::vector<Event> ev = extract_events(g);
+  // the server graphs come through the same det / rec sources: told apart by the stem (PP-LCNetV3: 3 -> 16, PPHGNet_small: 3 -> 64)
+  if (which == MODEL_DET || which == MODEL_REC)
+    for (const Event& e : ev)
+      if (e.kind == EV_CONV) {
+        if (e.dims.size() == 4 && e.dims[0] == 64 && e.dims[1] == 3) which = which == MODEL_DET ? MODEL_SDET : MODEL_SREC;
+        break;
+      }
   const std::vector<ManifestEntry> mf = model_manifest(which);
   std::vector<OutTensor> out;
 

@@ -21,7 +21,9 @@ struct ManifestEntry {
   std::string name;        // RTWB tensor name, e.g. "det.s2.0.dw.w"
   std::vector<int> dims;   // -1 = taken from the file (rec.head.fc: the class count)
 };
-enum ModelKind { MODEL_DET = 0, MODEL_CLS = 1, MODEL_REC = 2 };
+// MODEL_DET / MODEL_REC also accept the PP-OCRv4 SERVER graphs (ch_PP-OCRv4_server_{det,rec}_infer.onnx, BASELINE.json
+// config 5): a file whose first convolution is PPHGNet's 3 -> 64 stem is matched against the MODEL_SDET / MODEL_SREC manifest.
+enum ModelKind { MODEL_DET = 0, MODEL_CLS = 1, MODEL_REC = 2, MODEL_SDET = 3, MODEL_SREC = 4 };
 
 // RTWB tensor list of a network in forward order (nets.cpp keeps it next to the layer tables).
 std::vector<ManifestEntry> model_manifest(int which);

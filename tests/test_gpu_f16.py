@@ -334,3 +334,55 @@ def test_c5_full_size_properties(hip_server, models, server_models):
             inside = [(b[:, 0].min() >= x0 - 12 and b[:, 0].max() <= x1 + 12 and b[:, 1].min() >= y0 - 12 and b[:, 1].max() <= y1 + 12)
                       for b in got]
             assert sum(inside) == 1, (x0, y0, x1, y1)
+
+
+def test_server_session_from_onnx_files(hip_server, server_models):
+    """rt_create takes the server .onnx files themselves through the det / rec sources (ort_worker.rs:120-135: give it an
+    .onnx, it runs).  The files are written with UN-FOLDED parameters (Conv + BatchNormalization statistics, bias as a
+    separate Add in style 1); the session built from them must agree with (a) a torch evaluation of what the files say --
+    conv -> BN with the file's epsilon -- within the fp16 tolerances and (b) the session built from the RTWB blobs to fp16
+    rounding of the re-folded weights."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(__file__))
+    from onnx_writer import build_model_onnx
+    tens = [synth.sdet_tensors(4), synth.cls_tensors(3), synth.srec_tensors(5)]
+    assert synth.pack_blob(tens[0]) == server_models[0] and synth.pack_blob(tens[2]) == server_models[2]
+    unf = [{}, {}, {}]
+    kinds = [retto_amd.MODEL_SDET, retto_amd.MODEL_CLS, retto_amd.MODEL_SREC]
+    onnx = [build_model_onnx(retto_amd.model_manifest(k), t, seed=50 + i, style=i % 2 * 1, unfolded=u) for i, (k, t, u) in enumerate(zip(kinds, tens, unf))]
+    S = retto_amd.RettoWorkerModelSource
+    cfg = retto_amd.synthetic_session_config(0, server=True, dtype="f16")
+    cfg.worker_config.models = retto_amd.RettoWorkerModelProvider(det=S.Blob(onnx[0]), rec=S.Blob(onnx[2]), cls=S.Blob(onnx[1]))
+    sess = retto_amd.RettoSession(cfg)
+
+    def unfolded_conv(u):
+        def conv(w, name, x, stride=(1, 1), pad=(0, 0), groups=1):
+            r = u[name]
+            y = F.conv2d(x, torch.from_numpy(r["w"]), None if r["b"] is None else torch.from_numpy(r["b"]), stride=stride, padding=pad, groups=groups)
+            if r["bn"] is not None:
+                s_, B, mean, var, eps = r["bn"]
+                y = F.batch_norm(y, torch.from_numpy(mean), torch.from_numpy(var), torch.from_numpy(s_), torch.from_numpy(B), False, 0.0, eps)
+            return y
+        return conv
+    saved = N._conv
+    try:
+        assert _model_info(sess) == "server/f16 f16 server/f16"
+        rng = np.random.default_rng(77)
+        x = rng.uniform(-1, 1, (1, 3, 160, 224)).astype(np.float32)
+        N._conv = unfolded_conv(unf[0])
+        ref = N.sdet_forward({k: torch.from_numpy(v) for k, v in tens[0].items()}, torch.from_numpy(x)).numpy()
+        got = sess.worker.det(x)
+        err = np.abs(got - ref)
+        assert err.max() <= DET_ATOL_F16 and err.mean() <= DET_MEAN_F16
+        assert np.abs(got - hip_server.worker.det(x)).max() <= 2e-2       # same graph from the RTWB blob
+        x = rng.uniform(-1, 1, (2, 3, 48, 352)).astype(np.float32)
+        x[:, :, :, 250:] = 0.0
+        N._conv = unfolded_conv(unf[2])
+        ref = N.srec_forward({k: torch.from_numpy(v) for k, v in tens[2].items()}, torch.from_numpy(x)).numpy()
+        frac_decisive, frac_equal = _check_rec(sess.worker.rec(x), ref, REC_ATOL_F16, REC_MARGIN_F16)
+        assert frac_equal > REC_EQUAL_FLOOR_F16
+        assert sum(1 for r in unf[0].values() if r["bn"] is not None) > 50     # the det file really carried un-folded BatchNorms
+    finally:
+        N._conv = saved
+        sess.close()

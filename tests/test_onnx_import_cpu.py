@@ -9,7 +9,8 @@ from retto_amd import synth
 
 from onnx_writer import GraphWriter, build_model_onnx
 
-KINDS = [(retto_amd.MODEL_DET, synth.det_tensors), (retto_amd.MODEL_CLS, synth.cls_tensors), (retto_amd.MODEL_REC, synth.rec_tensors)]
+KINDS = [(retto_amd.MODEL_DET, synth.det_tensors), (retto_amd.MODEL_CLS, synth.cls_tensors), (retto_amd.MODEL_REC, synth.rec_tensors),
+         (retto_amd.MODEL_SDET, synth.sdet_tensors), (retto_amd.MODEL_SREC, synth.srec_tensors)]   # + the PP-OCRv4 server graphs (config 5)
 
 
 @pytest.mark.parametrize("which,make", KINDS)
@@ -40,6 +41,18 @@ def test_import_round_trip(which, make, style):
         for name, ref in t.items():
             if ".neck.blk" in name or name.endswith((".g", ".beta", ".a", ".c")):
                 assert np.array_equal(back[name], ref), name
+
+
+def test_server_files_come_through_the_det_and_rec_sources():
+    """A host hands ch_PP-OCRv4_server_{det,rec}_infer.onnx to the same det / rec model sources as the mobile files
+    (worker.rs:30-56): MODEL_DET / MODEL_REC recognise PPHGNet's 3 -> 64 stem and import against the server manifest."""
+    for generic, server, make in ((retto_amd.MODEL_DET, retto_amd.MODEL_SDET, synth.sdet_tensors), (retto_amd.MODEL_REC, retto_amd.MODEL_SREC, synth.srec_tensors)):
+        t = make()
+        onnx = build_model_onnx(retto_amd.model_manifest(server), t, seed=3, style=0)
+        back = synth.unpack_blob(retto_amd.onnx_to_rtwb(generic, onnx))
+        assert set(back) == set(t) and all(k.startswith(("sdet.", "srec.")) for k in back)
+        for name, ref in t.items():
+            np.testing.assert_allclose(back[name], ref, rtol=2e-6, atol=2e-7, err_msg=name)
 
 
 def test_import_errors():
