@@ -124,6 +124,21 @@ def unclip(box_i32, ratio=1.6):
     return out[:2 * n].reshape(-1, 2).copy()
 
 
+def unclip_distance(box_i32, ratio=1.6):
+    b = np.ascontiguousarray(np.asarray(box_i32, np.int32).reshape(8))
+    lib().orc_unclip_distance.restype = C.c_float
+    return np.float32(lib().orc_unclip_distance(i32p(b), C.c_float(ratio)))
+
+
+def crop_projection(box):
+    """(forward, inverse) 3x3 f32 matrices of the projection get_crop_img warps with."""
+    b = np.ascontiguousarray(np.asarray(box, np.float32).reshape(8))
+    t, inv = np.zeros(9, np.float32), np.zeros(9, np.float32)
+    if lib().orc_crop_projection(f32p(b), f32p(t), f32p(inv)) != 0:
+        raise ValueError("singular homography")
+    return t.reshape(3, 3), inv.reshape(3, 3)
+
+
 def det_postprocess(pred, ori_h, ori_w, thresh=0.3, box_thresh=0.5, unclip_ratio=1.6, min_size=3, dilate=True,
                     max_out=65536):
     """a5: returns (boxes [n,4,2] f32, scores [n] f32)."""

@@ -654,6 +654,25 @@ static void unclip(const IPt box[4], float unclip_ratio, std::vector<Pt>& out) {
   out.push_back(out[0]);
 }
 
+// pin kit (tests/golden/pin): the offset distance det_processor.rs:236-240 hands to Clipper, as unclip() computes it
+ORC_API float orc_unclip_distance(const int* box8, float ratio) {
+  float cx[5], cy[5];
+  for (int i = 0; i < 4; i++) { cx[i] = (float)box8[2 * i]; cy[i] = (float)box8[2 * i + 1]; }
+  cx[4] = cx[0]; cy[4] = cy[0];
+  float tmp = 0.0f;
+  for (int i = 0; i < 4; i++) {
+    float ax = cx[i] - cx[0], ay = cy[i] - cy[0], bx = cx[i + 1] - cx[0], by = cy[i + 1] - cy[0];
+    tmp += ax * by - bx * ay;
+  }
+  float area = fabsf(tmp / 2.0f), perimeter = 0.0f;
+  for (int i = 0; i < 4; i++) {
+    float dx = cx[i] - cx[i + 1], dy = cy[i] - cy[i + 1];
+    perimeter += (float)sqrt((double)dx * (double)dx + (double)dy * (double)dy);
+  }
+  perimeter = perimeter + 0.0f;
+  return area * ratio / perimeter;
+}
+
 ORC_API int orc_unclip(const int* box8, float ratio, float* out_xy, int max_pts) {
   IPt b[4]; for (int i = 0; i < 4; i++) b[i] = IPt{box8[2 * i], box8[2 * i + 1]};
   std::vector<Pt> o; unclip(b, ratio, o);
@@ -825,6 +844,15 @@ ORC_API void orc_crop_dims(const float* box8, int* out_w, int* out_h, int* rotat
   *rotated = (w > 0 && (float)h / (float)w >= 1.5f) ? 1 : ((w == 0 && h > 0) ? 1 : 0);  // h/0 = inf >= 1.5
   if (w == 0 && h == 0) *rotated = 0;  // 0/0 = NaN
   if (*rotated) { *out_w = (int)h; *out_h = (int)w; } else { *out_w = (int)w; *out_h = (int)h; }
+}
+
+// pin kit: the projection get_crop_img builds for a box (forward matrix and the inverse warp_into samples with), f32 row-major
+ORC_API int orc_crop_projection(const float* box8, float* t9, float* inv9) {
+  int ow, oh, rot; float cw, ch;
+  orc_crop_dims(box8, &ow, &oh, &rot, &cw, &ch);
+  float to[8] = {0.0f, 0.0f, cw, 0.0f, cw, ch, 0.0f, ch};
+  int cls;
+  return projection_from_control_points(box8, to, t9, inv9, &cls) ? 0 : -1;
 }
 
 // out must hold out_w*out_h*3 bytes (dims from orc_crop_dims). Returns 0, or

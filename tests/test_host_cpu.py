@@ -258,3 +258,77 @@ def test_format_f32_ignores_the_locale():
         assert {v: fmt(v) for v in want} == want
     finally:
         locale.setlocale(locale.LC_NUMERIC, old)
+
+
+# ---------------------------------------------------------------- the pin kit of INTEGRATION.md section 9
+def _pin_dir():
+    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "pin")
+
+
+def test_pin_kit_names_in_the_doc_exist():
+    """Every pin-kit file and every pin.json key that INTEGRATION.md section 9 tells a maintainer to compare against exists
+    (round 2's checklist named keys the fixtures did not hold)."""
+    import json
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    doc = open(os.path.join(root, "INTEGRATION.md")).read()
+    sec = doc[doc.index("## 9. What a maintainer"):]
+    table = sec[:sec.index("Ready to paste")]
+    kit = json.load(open(os.path.join(_pin_dir(), "pin.json")))
+    files = set(re.findall(r"`([a-z0-9_]+_\d+x\d+(?:x\d+)?\.(?:u8|f32))`", table))
+    assert len(files) >= 12
+    for f in files:
+        assert os.path.exists(os.path.join(_pin_dir(), f)), f
+
+    def resolve(node, path):
+        """path like dbpost.*.contours[*].box_score_fast.bits; returns the list of leaves reached"""
+        nodes = [node]
+        for part in re.findall(r"[A-Za-z0-9_{},]+|\*|\[\*\]", path):
+            nxt = []
+            for n in nodes:
+                if part in ("*", "[*]"):
+                    nxt += list(n.values()) if isinstance(n, dict) else list(n)
+                elif part.startswith("{"):
+                    nxt += [n[k] for k in part.strip("{}").split(",")]
+                else:
+                    nxt += [n[part]] if not isinstance(n, list) else [m[part] for m in n if part in m]
+            nodes = nxt
+        return nodes
+    keys = set(re.findall(r"`((?:thumbnail|dbpost|crops|reading_order|dictionary|json_f32)[A-Za-z0-9_.*\[\]{},]*)`", table))
+    assert len(keys) >= 18
+    for key in keys:
+        if re.search(r"\.\{[a-z_,]+\}$", key):       # trailing {a,b,c}: each of them
+            base, alts = key[:key.rindex(".{")], key[key.rindex(".{") + 2:-1].split(",")
+            for a_ in alts:
+                assert resolve(kit, base + "." + a_), (key, a_)
+        else:
+            assert resolve(kit, key), key
+    # the Rust module reads exactly these top-level sections
+    for k in ("thumbnail", "dbpost", "crops", "reading_order", "dictionary", "json_f32"):
+        assert 'k["%s"]' % k in sec or 'kit()["%s"]' % k in sec, k
+
+
+def test_pin_kit_matches_the_oracle_and_the_library(tmp_path):
+    """The committed kit is what the oracle produces today (no drift), and the two rows the library implements on the host
+    (dictionary parsing, f32 -> JSON text) give the kit's expectations."""
+    import filecmp
+    import importlib.util
+    import json
+    import struct
+    spec = importlib.util.spec_from_file_location("make_pin_kit", os.path.join(os.path.dirname(_pin_dir()), "make_pin_kit.py"))
+    mk = importlib.util.module_from_spec(spec); spec.loader.exec_module(mk)
+    mk.PIN = str(tmp_path / "pin")
+    mk.build()
+    names = sorted(os.listdir(_pin_dir()))
+    assert names == sorted(os.listdir(mk.PIN))
+    for n in names:
+        assert filecmp.cmp(os.path.join(_pin_dir(), n), os.path.join(mk.PIN, n), shallow=False), n
+    kit = json.load(open(os.path.join(_pin_dir(), "pin.json")))
+    rc, classes = _parse_dict(bytes.fromhex(kit["dictionary"]["bytes_hex"]))
+    assert rc == 0 and classes == kit["dictionary"]["expected_classes"]
+    lib = _lib.load()
+    lib.rt_format_f32.argtypes = [C.c_float, C.c_char_p, C.c_size_t]
+    for e in kit["json_f32"]:
+        v = struct.unpack("<f", struct.pack("<I", int(e["bits"], 16)))[0]
+        b = C.create_string_buffer(64); lib.rt_format_f32(v, b, 64)
+        assert b.value.decode() == e["expected"]
