@@ -918,10 +918,142 @@ __global__ __launch_bounds__(256) void k_conv_sp(const float* __restrict__ x, in
                      epi.residual ? epi.residual + pb * epi.ld_res : nullptr, q);
 }
 
+// ---------------------------------------------------------------------------
+// 3x3 dense conv onto FEW output channels (N = 4 * NG <= 64, e.g. the RSEFPN / DB-head 96 -> 24 layers) without
+// padding the channel dimension to MFMA tiles.  On the 16-wide tiles of k_conv_sp 24 channels run as 32: a quarter of the
+// matrix work multiplies zeros, and these layers are MFMA bound (PMC: 82 TFLOP/s of real work = 110 padded).
+// v_mfma_f32_4x4x1_16B_f32 computes sixteen independent 4 x 4 outer products per instruction at the full f32 MFMA rate
+// (8 cycles, 512 FLOP); with the A-operand broadcast (cbsz = 4, abid = g) every block takes the SAME four weights --
+// channel group g of this k -- and its own four pixels: lane l = pixel l of the wave's 64, D[i] = channel 4 g + i.  One
+// ds_read_b128 per operand feeds four k steps x NG channel groups = 4 NG MFMAs; a lane ends with all N channels of its
+// pixel (N * 4 contiguous bytes per store).  Work: exactly N channels.  Workgroup = 4 waves on a 16 x 16 pixel tile,
+// halo tile + nine taps of a 32-channel slab in LDS, next slab prefetched into registers (as k_conv_sp), 2 workgroups / CU.
+// ---------------------------------------------------------------------------
+template <int NG>
+__global__ __launch_bounds__(256, 2) void k_conv3_few(const float* __restrict__ x, int ldx, const ImgGeom* __restrict__ geom,
+                                                      int Cin, const float* __restrict__ Wp, int N, int Npad,
+                                                      float* __restrict__ y, int ldy, Epilogue epi) {
+  constexpr int TH = 16, TW = 16, HH = TH + 2, HW = TW + 2, TAPS = 9, NCH = 4 * NG;
+  __shared__ __attribute__((aligned(16))) float lds[(HH * HW + TAPS * NCH) * LROW];
+  float* xs = lds;
+  float* ws = lds + HH * HW * LROW;
+  const ImgGeom g = geom[blockIdx.y];
+  const int tiles_x = (g.W + TW - 1) / TW, tiles_y = (g.H + TH - 1) / TH;
+  if ((int)blockIdx.x >= tiles_x * tiles_y) return;
+  const int ty = blockIdx.x / tiles_x, tx = blockIdx.x % tiles_x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int py = wave * 4 + (lane >> 4), px = lane & 15;   // this lane's pixel (tile-local)
+  f32x4 acc[NG];
+#pragma unroll
+  for (int i = 0; i < NG; i++) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int nkc = (Cin + KC - 1) / KC;
+  constexpr int XLD = (HH * HW * 8 + 255) / 256, WLD = (TAPS * NCH * 8 + 255) / 256;
+  f32x4 px_[XLD], pw_[WLD];
+  auto fetch = [&](int kc) {
+    const int k0 = kc * KC;
+#pragma unroll
+    for (int i = 0; i < XLD; i++) {
+      const int idx = tid + 256 * i;
+      px_[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (idx < HH * HW * 8) {
+        const int hp = idx >> 3, c4 = idx & 7;
+        const int hy = hp / HW, hx = hp % HW;
+        const int gy = ty * TH + hy - 1, gx = tx * TW + hx - 1;
+        if (gy >= 0 && gy < g.H && gx >= 0 && gx < g.W && k0 + c4 * 4 < Cin)
+          px_[i] = *reinterpret_cast<const f32x4*>(x + (g.off + (long long)gy * g.W + gx) * ldx + k0 + c4 * 4);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < WLD; i++) {
+      const int idx = tid + 256 * i;
+      pw_[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (idx < TAPS * NCH * 8) {
+        const int row = idx >> 3, c4 = idx & 7;
+        const int tap = row / NCH, n = row % NCH;
+        if (n < Npad) pw_[i] = *reinterpret_cast<const f32x4*>(Wp + (((long long)kc * TAPS + tap) * Npad + n) * KC + c4 * 4);
+      }
+    }
+  };
+  auto stash = [&]() {
+#pragma unroll
+    for (int i = 0; i < XLD; i++) {
+      const int idx = tid + 256 * i;
+      if (idx < HH * HW * 8) *reinterpret_cast<f32x4*>(xs + (idx >> 3) * LROW + (idx & 7) * 4) = px_[i];
+    }
+#pragma unroll
+    for (int i = 0; i < WLD; i++) {
+      const int idx = tid + 256 * i;
+      if (idx < TAPS * NCH * 8) *reinterpret_cast<f32x4*>(ws + (idx >> 3) * LROW + (idx & 7) * 4) = pw_[i];
+    }
+  };
+  const float* wrow = ws + (lane < NCH ? lane : 0) * LROW;   // A operand: lane 4 g + i holds channel 4 g + i (lanes >= N are never selected)
+  fetch(0);
+  for (int kc = 0; kc < nkc; kc++) {
+    stash();
+    __syncthreads();
+    if (kc + 1 < nkc) fetch(kc + 1);
+#pragma unroll
+    for (int dy = 0; dy < 3; dy++)
+#pragma unroll
+      for (int dx = 0; dx < 3; dx++) {
+        const float* xr = xs + ((py + dy) * HW + px + dx) * LROW;
+        const float* wr = wrow + (dy * 3 + dx) * NCH * LROW;
+#pragma unroll
+        for (int kk = 0; kk < KC / 4; kk++) {
+          const f32x4 b = *reinterpret_cast<const f32x4*>(xr + kk * 4);
+          const f32x4 a = *reinterpret_cast<const f32x4*>(wr + kk * 4);
+#pragma unroll
+          for (int s2 = 0; s2 < 4; s2++) {
+            // (abid must be an immediate: one call per channel group)
+            if (NG > 0) acc[0] = __builtin_amdgcn_mfma_f32_4x4x1f32(a[s2], b[s2], acc[0], 4, 0, 0);
+            if (NG > 1) acc[NG > 1 ? 1 : 0] = __builtin_amdgcn_mfma_f32_4x4x1f32(a[s2], b[s2], acc[NG > 1 ? 1 : 0], 4, 1, 0);
+            if (NG > 2) acc[NG > 2 ? 2 : 0] = __builtin_amdgcn_mfma_f32_4x4x1f32(a[s2], b[s2], acc[NG > 2 ? 2 : 0], 4, 2, 0);
+            if (NG > 3) acc[NG > 3 ? 3 : 0] = __builtin_amdgcn_mfma_f32_4x4x1f32(a[s2], b[s2], acc[NG > 3 ? 3 : 0], 4, 3, 0);
+            if (NG > 4) acc[NG > 4 ? 4 : 0] = __builtin_amdgcn_mfma_f32_4x4x1f32(a[s2], b[s2], acc[NG > 4 ? 4 : 0], 4, 4, 0);
+            if (NG > 5) acc[NG > 5 ? 5 : 0] = __builtin_amdgcn_mfma_f32_4x4x1f32(a[s2], b[s2], acc[NG > 5 ? 5 : 0], 4, 5, 0);
+            if (NG > 6) acc[NG > 6 ? 6 : 0] = __builtin_amdgcn_mfma_f32_4x4x1f32(a[s2], b[s2], acc[NG > 6 ? 6 : 0], 4, 6, 0);
+            if (NG > 7) acc[NG > 7 ? 7 : 0] = __builtin_amdgcn_mfma_f32_4x4x1f32(a[s2], b[s2], acc[NG > 7 ? 7 : 0], 4, 7, 0);
+          }
+        }
+      }
+    __syncthreads();
+  }
+  const int oy = ty * TH + py, ox = tx * TW + px;
+  if (oy >= g.H || ox >= g.W) return;
+  float* yr = y + (g.off + (long long)oy * g.W + ox) * ldy;
+  act_dispatch(epi.act, epi.has_lab, false, [&](auto at, auto lt, auto) {
+    constexpr int A = decltype(at)::value, L = decltype(lt)::value;
+#pragma unroll
+    for (int gi = 0; gi < NG; gi++) {
+      f32x4 bias = {0.f, 0.f, 0.f, 0.f};
+      if (epi.bias) bias = *reinterpret_cast<const f32x4*>(epi.bias + gi * 4);
+      f32x4 o;
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const float t = epi_val<A, L>(acc[gi][j] + bias[j], epi.act, epi.has_lab, epi.lab_a, epi.lab_c);
+        o[j] = (gi * 4 + j < N) ? t : 0.0f;
+      }
+      *reinterpret_cast<f32x4*>(yr + gi * 4) = o;
+    }
+  });
+}
+
+static const int g_conv3_few = getenv("RT_CONV3_FEW") ? atoi(getenv("RT_CONV3_FEW")) : 1;   // A/B: 0 keeps the 16-wide tiles for every N
+
 void conv_sp(hipStream_t st, int KH, int KW, const float* x, int ldx, const ImgGeom* geom, int n_img, int maxH,
              int maxW, int Cin, const float* Wp, int N, int Npad16, float* y, int ldy, const Epilogue& epi) {
   if (n_img <= 0) return;
   int ntiles = Npad16 / 16;
+  // few output channels that do not fill 16-wide tiles (N = 24: a quarter of k_conv_sp's MFMA work would be padding)
+  if (KH == 3 && KW == 3 && g_conv3_few && N % 16 != 0 && N <= 32 && !epi.residual && ldy >= round_up(N, 4)) {
+    dim3 gridf(((maxW + 15) / 16) * ((maxH + 15) / 16), n_img);
+    switch ((N + 3) / 4) {
+#define RT_C3F(n) case n: RT_LAUNCH((k_conv3_few<n>), gridf, dim3(256), 0, st, x, ldx, geom, Cin, Wp, N, Npad16, y, ldy, epi); return;
+      RT_C3F(1) RT_C3F(2) RT_C3F(3) RT_C3F(5) RT_C3F(6)
+#undef RT_C3F
+      default: break;
+    }
+  }
   if (KH == 3 && KW == 3) {
     int NT = ntiles >= 2 ? 2 : 1;
     dim3 grid(((maxW + 15) / 16) * ((maxH + 7) / 8), n_img, (ntiles + NT - 1) / NT);
