@@ -381,13 +381,19 @@ float* DetNet::run(RunCtx& c, const float* x, Level& L0, const nn::U8Page* pages
                   inp_[j].Npad, p[j], 24, make_epi(inp_[j], ACT_NONE)); }
     p_scale[3 - j] = run_se(c, p[j], *tap_lv[j], inp_se_[j], HSIG_MBV3, 1, false);  // order p5, p4, p3, p2
   }
-  float* fuse = c.arena->alloc<float>((size_t)L4.total * 96);
-  { ProfScope ps(c.prof, c.st, "fpn_concat");
-    nn::fpn_concat(c.st, p[3], p[2], p[1], p[0], L32.d, L16.d, L8.d, L4.d, L4.n(), L4.maxPix, 24, fuse, p_scale); }
   float* h1 = c.arena->alloc<float>((size_t)L4.total * 24);
-  { ProfScope ps(c.prof, c.st, "conv3x3", shape_str(L4.total, 9 * 96, 24, 1));
+  if (nn::conv3_fpn_fused_supported(24, 24)) {   // the head conv gathers the four levels itself: no 96-channel fuse tensor
+    ProfScope ps(c.prof, c.st, "conv3x3", shape_str(L4.total, 9 * 96, 24, 1));
+    nn::conv3_fpn_fused(c.st, p[3], p[2], p[1], p[0], L32.d, L16.d, L8.d, L4.d, L4.n(), L4.maxH, L4.maxW, 24, p_scale,
+                        head_conv1_.w, 24, head_conv1_.Npad, h1, 24, make_epi(head_conv1_, ACT_RELU));
+  } else {
+    float* fuse = c.arena->alloc<float>((size_t)L4.total * 96);
+    { ProfScope ps(c.prof, c.st, "fpn_concat");
+      nn::fpn_concat(c.st, p[3], p[2], p[1], p[0], L32.d, L16.d, L8.d, L4.d, L4.n(), L4.maxPix, 24, fuse, p_scale); }
+    ProfScope ps(c.prof, c.st, "conv3x3", shape_str(L4.total, 9 * 96, 24, 1));
     nn::conv_sp(c.st, 3, 3, fuse, 96, L4.d, L4.n(), L4.maxH, L4.maxW, 96, head_conv1_.w, 24, head_conv1_.Npad, h1, 24,
-                make_epi(head_conv1_, ACT_RELU)); }
+                make_epi(head_conv1_, ACT_RELU));
+  }
   float* map = c.arena->alloc<float>((size_t)L0.total);
   { ProfScope ps(c.prof, c.st, "db_head_tail");
     nn::db_head_tail(c.st, h1, L4.d, L0.d, L4.n(), L4.maxPix, dc1_w_, dc1_b_, dc2_w_, dc2_b_, map); }

@@ -97,6 +97,12 @@ void upsample_add(hipStream_t st, const float* a, const float* b, const ImgGeom*
 void fpn_concat(hipStream_t st, const float* p5, const float* p4, const float* p3, const float* p2, const ImgGeom* g5,
                 const ImgGeom* g4, const ImgGeom* g3, const ImgGeom* g2, int n_img, long long max_pix, int Cq,
                 float* out, const float* const* scales = nullptr);  // scales[4]: per-level [img][Cq] factors (p5..p2) or null
+// The DB head's first 3x3 conv reading concat(up8(p5), up4(p4), up2(p3), p2) (x per-level scales) directly from the four levels
+// (fpn_concat + conv_sp in one kernel; the pair's result to fp32 rounding: the K slabs are the four levels).
+bool conv3_fpn_fused_supported(int Cq, int N);
+void conv3_fpn_fused(hipStream_t st, const float* p5, const float* p4, const float* p3, const float* p2, const ImgGeom* g5,
+                     const ImgGeom* g4, const ImgGeom* g3, const ImgGeom* g2, int n_img, int maxH, int maxW, int Cq,
+                     const float* const* scales, const float* Wp, int N, int Npad16, float* y, int ldy, const Epilogue& epi);
 // DB head tail: convT2x2s2(24->24)+relu, convT2x2s2(24->1), sigmoid. in [.,.,24] at 1/4 res,
 // out f32 map at full res (geometry gout, one float per pixel).
 void db_head_tail(hipStream_t st, const float* x, const ImgGeom* gin, const ImgGeom* gout, int n_img, long long max_pix,

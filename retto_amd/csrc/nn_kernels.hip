@@ -929,11 +929,24 @@ __global__ __launch_bounds__(256) void k_conv_sp(const float* __restrict__ x, in
 // pixel (N * 4 contiguous bytes per store).  Work: exactly N channels.  Workgroup = 4 waves on a 16 x 16 pixel tile,
 // halo tile + nine taps of a 32-channel slab in LDS, next slab prefetched into registers (as k_conv_sp), 2 workgroups / CU.
 // ---------------------------------------------------------------------------
-template <int NG>
+// FUSE: the input is the RSEFPN's concat(up8(p5) * s5, up4(p4) * s4, up2(p3) * s3, p2 * s2) gathered on the fly (FpnSrc): the
+// 4 x Cq-channel fuse tensor (k_fpn_concat: a 0.7 GB write + read per 32 pages) is never built.  Same values as the
+// two-step form's operands (scale multiply first); the K slabs are the four levels (24 channels each) instead of three
+// 32-channel slabs, so the sum runs in another order: equal to the pair to fp32 rounding, not bit for bit.
+struct FpnSrc {
+  const float* p[4];        // p5, p4, p3, p2 (pitch Cq each)
+  const ImgGeom* g[4];
+  const float* scale[4];    // [image][Cq] or null
+  int Cq;
+};
+template <int NG, int FUSE = 0>
 __global__ __launch_bounds__(256, 2) void k_conv3_few(const float* __restrict__ x, int ldx, const ImgGeom* __restrict__ geom,
                                                       int Cin, const float* __restrict__ Wp, int N, int Npad,
-                                                      float* __restrict__ y, int ldy, Epilogue epi) {
+                                                      float* __restrict__ y, int ldy, Epilogue epi, FpnSrc fs) {
   constexpr int TH = 16, TW = 16, HH = TH + 2, HW = TW + 2, TAPS = 9, NCH = 4 * NG;
+  // channels per K slab, in 4-channel chunks: a 32-channel slab of the input tensor, or (FUSE) one whole FPN level of
+  // Cq = 24 channels -- all threads of a slab then gather from the same level (uniform geometry and pointers)
+  constexpr int CH4 = FUSE ? 6 : KC / 4;
   __shared__ __attribute__((aligned(16))) float lds[(HH * HW + TAPS * NCH) * LROW];
   float* xs = lds;
   float* ws = lds + HH * HW * LROW;
@@ -946,31 +959,45 @@ __global__ __launch_bounds__(256, 2) void k_conv3_few(const float* __restrict__ 
   f32x4 acc[NG];
 #pragma unroll
   for (int i = 0; i < NG; i++) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const int nkc = (Cin + KC - 1) / KC;
-  constexpr int XLD = (HH * HW * 8 + 255) / 256, WLD = (TAPS * NCH * 8 + 255) / 256;
+  const int nkc = FUSE ? 4 : (Cin + KC - 1) / KC;
+  constexpr int XLD = (HH * HW * CH4 + 255) / 256, WLD = (TAPS * NCH * CH4 + 255) / 256;
   f32x4 px_[XLD], pw_[WLD];
   auto fetch = [&](int kc) {
-    const int k0 = kc * KC;
+    const int k0 = kc * CH4 * 4;
+    // FUSE: level kc (p5, p4, p3, p2): nearest-neighbour source pixel (gy >> sh, gx >> sh), times the level's SE scale
+    const int sh = 3 - kc;
+    const ImgGeom G = FUSE ? fs.g[kc][blockIdx.y] : g;
+    const float* src = FUSE ? fs.p[kc] : x;
+    const float* scl = FUSE ? fs.scale[kc] : nullptr;
 #pragma unroll
     for (int i = 0; i < XLD; i++) {
       const int idx = tid + 256 * i;
       px_[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (idx < HH * HW * 8) {
-        const int hp = idx >> 3, c4 = idx & 7;
+      if (idx < HH * HW * CH4) {
+        const int hp = idx / CH4, c4 = idx - hp * CH4;
         const int hy = hp / HW, hx = hp % HW;
         const int gy = ty * TH + hy - 1, gx = tx * TW + hx - 1;
-        if (gy >= 0 && gy < g.H && gx >= 0 && gx < g.W && k0 + c4 * 4 < Cin)
-          px_[i] = *reinterpret_cast<const f32x4*>(x + (g.off + (long long)gy * g.W + gx) * ldx + k0 + c4 * 4);
+        if (gy >= 0 && gy < g.H && gx >= 0 && gx < g.W && (FUSE || k0 + c4 * 4 < Cin)) {
+          if (FUSE) {
+            const int sy = min(gy >> sh, G.H - 1), sx = min(gx >> sh, G.W - 1);
+            f32x4 v = *reinterpret_cast<const f32x4*>(src + (G.off + (long long)sy * G.W + sx) * fs.Cq + c4 * 4);
+            if (scl) v *= *reinterpret_cast<const f32x4*>(scl + (long long)blockIdx.y * fs.Cq + c4 * 4);
+            px_[i] = v;
+          } else {
+            px_[i] = *reinterpret_cast<const f32x4*>(x + (g.off + (long long)gy * g.W + gx) * ldx + k0 + c4 * 4);
+          }
+        }
       }
     }
 #pragma unroll
     for (int i = 0; i < WLD; i++) {
       const int idx = tid + 256 * i;
       pw_[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (idx < TAPS * NCH * 8) {
-        const int row = idx >> 3, c4 = idx & 7;
+      if (idx < TAPS * NCH * CH4) {
+        const int row = idx / CH4, c4 = idx - row * CH4;
         const int tap = row / NCH, n = row % NCH;
-        if (n < Npad) pw_[i] = *reinterpret_cast<const f32x4*>(Wp + (((long long)kc * TAPS + tap) * Npad + n) * KC + c4 * 4);
+        const int ch = k0 + c4 * 4;   // input channel of the chunk; the packed weights are in 32-channel slabs
+        if (n < Npad) pw_[i] = *reinterpret_cast<const f32x4*>(Wp + (((long long)(ch >> 5) * TAPS + tap) * Npad + n) * KC + (ch & 31));
       }
     }
   };
@@ -978,12 +1005,12 @@ __global__ __launch_bounds__(256, 2) void k_conv3_few(const float* __restrict__ 
 #pragma unroll
     for (int i = 0; i < XLD; i++) {
       const int idx = tid + 256 * i;
-      if (idx < HH * HW * 8) *reinterpret_cast<f32x4*>(xs + (idx >> 3) * LROW + (idx & 7) * 4) = px_[i];
+      if (idx < HH * HW * CH4) *reinterpret_cast<f32x4*>(xs + (idx / CH4) * LROW + (idx % CH4) * 4) = px_[i];
     }
 #pragma unroll
     for (int i = 0; i < WLD; i++) {
       const int idx = tid + 256 * i;
-      if (idx < TAPS * NCH * 8) *reinterpret_cast<f32x4*>(ws + (idx >> 3) * LROW + (idx & 7) * 4) = pw_[i];
+      if (idx < TAPS * NCH * CH4) *reinterpret_cast<f32x4*>(ws + (idx / CH4) * LROW + (idx % CH4) * 4) = pw_[i];
     }
   };
   const float* wrow = ws + (lane < NCH ? lane : 0) * LROW;   // A operand: lane 4 g + i holds channel 4 g + i (lanes >= N are never selected)
@@ -999,7 +1026,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3_few(const float* __restrict__ 
         const float* xr = xs + ((py + dy) * HW + px + dx) * LROW;
         const float* wr = wrow + (dy * 3 + dx) * NCH * LROW;
 #pragma unroll
-        for (int kk = 0; kk < KC / 4; kk++) {
+        for (int kk = 0; kk < CH4; kk++) {
           const f32x4 b = *reinterpret_cast<const f32x4*>(xr + kk * 4);
           const f32x4 a = *reinterpret_cast<const f32x4*>(wr + kk * 4);
 #pragma unroll
@@ -1040,6 +1067,21 @@ __global__ __launch_bounds__(256, 2) void k_conv3_few(const float* __restrict__ 
 
 static const int g_conv3_few = getenv("RT_CONV3_FEW") ? atoi(getenv("RT_CONV3_FEW")) : 1;   // A/B: 0 keeps the 16-wide tiles for every N
 
+// DB head's first 3x3 conv (4 * Cq -> N) straight from the four FPN levels: conv_sp over fpn_concat's result without building it.
+bool conv3_fpn_fused_supported(int Cq, int N) { return g_conv3_few && Cq == 24 && N == 24 && getenv("RT_NO_FPN_FUSE") == nullptr; }
+void conv3_fpn_fused(hipStream_t st, const float* p5, const float* p4, const float* p3, const float* p2, const ImgGeom* g5,
+                     const ImgGeom* g4, const ImgGeom* g3, const ImgGeom* g2, int n_img, int maxH, int maxW, int Cq,
+                     const float* const* scales, const float* Wp, int N, int Npad16, float* y, int ldy, const Epilogue& epi) {
+  if (n_img <= 0) return;
+  FpnSrc fs;
+  fs.p[0] = p5; fs.p[1] = p4; fs.p[2] = p3; fs.p[3] = p2;
+  fs.g[0] = g5; fs.g[1] = g4; fs.g[2] = g3; fs.g[3] = g2;
+  for (int i = 0; i < 4; i++) fs.scale[i] = scales ? scales[i] : nullptr;
+  fs.Cq = Cq;
+  dim3 gridf(((maxW + 15) / 16) * ((maxH + 15) / 16), n_img);
+  RT_LAUNCH((k_conv3_few<6, 1>), gridf, dim3(256), 0, st, nullptr, 4 * Cq, g2, 4 * Cq, Wp, N, Npad16, y, ldy, epi, fs);
+}
+
 void conv_sp(hipStream_t st, int KH, int KW, const float* x, int ldx, const ImgGeom* geom, int n_img, int maxH,
              int maxW, int Cin, const float* Wp, int N, int Npad16, float* y, int ldy, const Epilogue& epi) {
   if (n_img <= 0) return;
@@ -1048,7 +1090,7 @@ void conv_sp(hipStream_t st, int KH, int KW, const float* x, int ldx, const ImgG
   if (KH == 3 && KW == 3 && g_conv3_few && N % 16 != 0 && N <= 32 && !epi.residual && ldy >= round_up(N, 4)) {
     dim3 gridf(((maxW + 15) / 16) * ((maxH + 15) / 16), n_img);
     switch ((N + 3) / 4) {
-#define RT_C3F(n) case n: RT_LAUNCH((k_conv3_few<n>), gridf, dim3(256), 0, st, x, ldx, geom, Cin, Wp, N, Npad16, y, ldy, epi); return;
+#define RT_C3F(n) case n: RT_LAUNCH((k_conv3_few<n>), gridf, dim3(256), 0, st, x, ldx, geom, Cin, Wp, N, Npad16, y, ldy, epi, FpnSrc{}); return;
       RT_C3F(1) RT_C3F(2) RT_C3F(3) RT_C3F(5) RT_C3F(6)
 #undef RT_C3F
       default: break;
