@@ -1129,12 +1129,8 @@ void conv_sp(hipStream_t st, int KH, int KW, const float* x, int ldx, const ImgG
 // instead of re-reading HBM.  Accumulation order per output: bias, then taps in (dy, dx) order.
 // 128 VGPRs (4 waves/SIMD): +15 % over 3 waves at C = 480.  Measured and rejected: lane groups
 // spanning whole pixels with all the weights in LDS (1.2-1.5x slower), one-row-ahead register
-// prefetch (hipcc hoists every load: spills).  Round 3, measured and rejected: a column-sweep form (k_dwconv_sweep: a thread
-// owns a 4-pixel x 4-channel column of the whole 12-row map and streams the input rows once through a rotating window of
-// K accumulator rows -- every input row fetched once, bit-identical): 80 accumulator + 32 input registers need the
-// 168-register budget (3 waves / SIMD) and the kernel ran 0.674 vs 0.611 ms on the 1.23 M-pixel 256-channel maps.  The
-// 1.63x over-fetch of this kernel (PMC) is served by the Infinity Cache; what bounds it is the latency of the one input
-// row a wave keeps in flight (waves parked on loads 55 % of the cycles), so occupancy beats fewer bytes.
+// prefetch (hipcc hoists every load: spills).  On short maps (<= 24 rows, no pooling) the 5x5 stride-1 layers run on
+// k_dwconv_sweep below instead (every input row fetched once).
 __device__ int g_dw_xcd_dev = 1;  // XCD-aware block order of k_dwconv_rows (A/B: set_dw_xcd)
 template <int K, int R, int SH, int SW, int POOL, int LP = 8>  // LP lanes (16 bytes each) side by side on a pixel: 32- or 64-channel slabs
 __global__ __launch_bounds__(256, 4) void k_dwconv_rows(const float* __restrict__ x, const ImgGeom* __restrict__ gin,
@@ -1256,12 +1252,120 @@ __global__ __launch_bounds__(256, 4) void k_dwconv_rows(const float* __restrict_
   }
 }
 
+// ---------------------------------------------------------------------------
+// Column-sweep depthwise conv (stride 1) for short, wide maps (the recognition net's 12- / 6-row stages): a thread owns a
+// PX-pixel x 4-channel column of the WHOLE image and streams the input rows top to bottom once, holding the K output rows
+// an input row feeds in a rotating window of accumulators (slot = output row % K, compile time: rows walked in groups of
+// K); an output row is stored and its slot restarted from the bias as soon as its last input row has gone through.
+// k_dwconv_rows re-reads the K - 1 rows that vertically adjacent strips share -- 20 row reads for 12 rows, 1.63x the output
+// bytes at the fabric (PMC), which is what bounds it (4.1 TB/s algorithmic = 6.7 TB/s of fetches).  Same accumulation
+// order per output (bias, taps in (dy, dx) order): bit-identical.  Measured on the 1.23 M-pixel 256-channel maps (k_dwconv_rows
+// 0.621 ms): PX = 4 at 3 waves / SIMD 0.543 ms (4.64 TB/s), PX = 2 at 4 waves / SIMD 0.567; a first form that loaded the
+// columns one tap column ahead (dx-outer loop) ran 0.674 -- the eight loads of a row must be in flight together.
+// ---------------------------------------------------------------------------
+template <int K, int LP, int PX, int WAVES>
+__global__ __launch_bounds__(256, WAVES) void k_dwconv_sweep(const float* __restrict__ x, const ImgGeom* __restrict__ gin,
+                                                           const ImgGeom* __restrict__ gout, int Cp, int C,
+                                                           const float* __restrict__ Wd, const float* __restrict__ bias, int act,
+                                                           int has_lab, float lab_a, float lab_c, float* __restrict__ y) {
+  constexpr int NV = PX - 1 + K, P = K / 2, SPB = 256 / LP;
+  __shared__ __attribute__((aligned(16))) float wl[K * K * LP * 4];
+  const ImgGeom gi = gin[blockIdx.y], go = gout[blockIdx.y];
+  const int strips_x = (go.W + PX - 1) / PX;
+  if ((int)blockIdx.x * SPB >= strips_x) return;
+  const int cbase = blockIdx.z * LP * 4;
+  const int tid = threadIdx.x;
+  for (int i = tid; i < K * K * LP; i += 256) {
+    int t = i / LP, cc = i % LP;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (cbase + cc * 4 < Cp) v = *reinterpret_cast<const f32x4*>(Wd + t * Cp + cbase + cc * 4);
+    *reinterpret_cast<f32x4*>(wl + i * 4) = v;
+  }
+  __syncthreads();
+  const int c4 = tid % LP, ch = cbase + c4 * 4;
+  const int strip = (int)blockIdx.x * SPB + tid / LP;
+  if (ch >= Cp || strip >= strips_x) return;
+  const int ox0 = strip * PX, H = gi.H;   // (stride 1: output and input maps have the same size)
+  const f32x4 b = *reinterpret_cast<const f32x4*>(bias + ch);
+  f32x4 acc[K][PX];
+#pragma unroll
+  for (int r = 0; r < K; r++)
+#pragma unroll
+    for (int j = 0; j < PX; j++) acc[r][j] = b;
+  const float* xcol = x + gi.off * Cp + ch;
+  float* ycol = y + (go.off + ox0) * Cp + ch;
+  act_dispatch(act, has_lab, false, [&](auto at, auto lt, auto) {
+    constexpr int A = decltype(at)::value, L = decltype(lt)::value;
+    auto store_row = [&](int oy, f32x4 (&a)[PX]) __attribute__((always_inline)) {
+#pragma unroll
+      for (int j = 0; j < PX; j++) {
+        if (ox0 + j < go.W) {
+          f32x4 o;
+#pragma unroll
+          for (int e = 0; e < 4; e++) {
+            const float t = epi_val<A, L>(a[j][e], act, has_lab, lab_a, lab_c);
+            o[e] = (ch + e < C) ? t : 0.f;  // pitch padding (chan_pitch) holds zeros whatever the input padding held
+          }
+          *reinterpret_cast<f32x4*>(ycol + ((long long)oy * go.W + j) * Cp) = o;
+        }
+        a[j] = b;
+      }
+    };
+    for (int i0 = 0; i0 < H; i0 += K) {
+#pragma unroll
+      for (int u = 0; u < K; u++) {
+        const int i = i0 + u;   // input row; feeds output rows i - P .. i + P through tap rows dy = K - 1 .. 0
+        if (i < H) {
+          const float* row = xcol + (long long)i * gi.W * Cp;
+          // (one running column pointer, opaque to the optimiser: with row + ix * Cp hipcc precomputes the 64-bit column
+          //  offsets ahead of the row loop and spills them)
+          const float* colp = row + ((long long)ox0 - P) * Cp;
+          asm volatile("" : "+v"(colp));
+          f32x4 v[NV];
+#pragma unroll
+          for (int j = 0; j < NV; j++) {
+            const int ix = ox0 + j - P;
+            v[j] = (ix >= 0 && ix < gi.W) ? *reinterpret_cast<const f32x4*>(colp) : f32x4{0.f, 0.f, 0.f, 0.f};
+            colp += Cp;
+          }
+#pragma unroll
+          for (int dy = 0; dy < K; dy++) {
+            const int r = i + P - dy;                  // output row fed through tap row dy
+            const int slot = (u + P - dy + K) % K;     // == r mod K (i0 is a multiple of K): compile time
+            if (r >= 0 && r < H) {
+#pragma unroll
+              for (int dx = 0; dx < K; dx++) {
+                const f32x4 w = *reinterpret_cast<const f32x4*>(wl + ((dy * K + dx) * LP + c4) * 4);
+#pragma unroll
+                for (int j = 0; j < PX; j++)
+#pragma unroll
+                  for (int e = 0; e < 4; e++) acc[slot][j][e] = fmaf(v[j + dx][e], w[e], acc[slot][j][e]);
+              }
+            }
+          }
+          if (i - P >= 0) store_row(i - P, acc[(u - P + K) % K]);   // output row i - P has seen its last input row
+        }
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < P; t++) {   // the last P output rows end at the bottom padding
+      const int r = H - P + t;
+      if (r >= 0) {
+#pragma unroll
+        for (int sl = 0; sl < K; sl++)
+          if (r % K == sl) store_row(r, acc[sl]);
+      }
+    }
+  });
+}
+
 void set_dw_xcd(int v) { RT_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_dw_xcd_dev), &v, sizeof(int))); }
 int g_dw_wide_slab_min = 192;      // channel pitch from which the 5x5 kernels use wide slabs (1 << 30: never, A/B)
 static int dw_lanes_per_pixel(int K, int sh, int sw, int R, int Cp, bool pool);
 int g_dw_wide3_min = 128;          // same for the 3x3 kernels (64-channel slabs)
 int g_dw_wide_lp = 16;             // 16 = 64-channel slabs, 32 = 128-channel slabs
 int g_dw_variant = 0;
+int g_dw_sweep = getenv("RT_DW_SWEEP") ? atoi(getenv("RT_DW_SWEEP")) : 4;   // column-sweep 5x5 kernel on short maps: pixels per thread (0: off)
 // Output rows per thread of k_dwconv_rows: 4 (stride 1) or 2 (stride 2); 3 for the 3- and 6-row maps of the
 // recognition net's last stages, where 4-row (2-row) strips would leave a quarter of the lanes' rows empty.
 static int dw_strip_rows(int sh, int maxHo) {
@@ -1280,6 +1384,15 @@ void dwconv(hipStream_t st, int K, int sh, int sw, const float* x, const ImgGeom
     // 64- / 128-channel slabs (256 / 512 contiguous bytes per pixel and load) for wide tensors: the 5x5 kernel on
     // 256 channels goes from 2.9 to 4.1 TB/s with 64-channel slabs; 32-channel slabs otherwise
     const int lp = dw_lanes_per_pixel(K, sh, sw, R, Cp, pool != nullptr);
+    // short, wide maps: one thread column sweeps the whole height (RT_DW_SWEEP: 0 off; 2 / 3 / 4 = form, A/B)
+    if (g_dw_sweep && K == 5 && sh == 1 && sw == 1 && !pool && lp == 16 && maxHo >= 5 && maxHo <= 24) {
+      const int spb = 256 / 16, px = g_dw_sweep == 4 ? 4 : 2;
+      dim3 grids((unsigned)(((maxWo + px - 1) / px + spb - 1) / spb), n_img, (Cp + 63) / 64);
+      if (px == 4) RT_LAUNCH((k_dwconv_sweep<5, 16, 4, 3>), grids, dim3(256), 0, st, x, gin, gout, Cp, C, Wd, bias, act, has_lab, lab_a, lab_c, y);
+      else if (g_dw_sweep == 3) RT_LAUNCH((k_dwconv_sweep<5, 16, 2, 5>), grids, dim3(256), 0, st, x, gin, gout, Cp, C, Wd, bias, act, has_lab, lab_a, lab_c, y);
+      else RT_LAUNCH((k_dwconv_sweep<5, 16, 2, 4>), grids, dim3(256), 0, st, x, gin, gout, Cp, C, Wd, bias, act, has_lab, lab_a, lab_c, y);
+      return;
+    }
     if (lp != 8) {
       const int spb = 256 / lp;
       dim3 gridw((unsigned)((strips + spb - 1) / spb), n_img, (Cp + lp * 4 - 1) / (lp * 4));
