@@ -665,7 +665,8 @@ void lc_thin(hipStream_t st, int sh, int sw, const float* x, const ImgGeom* gin,
   // measured per shape: 64-pixel tiles (more workgroups per CU) win from 48 channels up, 128-pixel tiles below
   const int code = lc_thin_code(sh, sw, Cp, Npad16);
   const int TH = code >= 6 ? 4 : (g_lc_thin == 2 ? 8 : (g_lc_thin == 3 ? 4 : (Cp >= 48 ? 4 : 8)));  // 2 / 3 force a variant (A/B)
-  const int tiles = ((maxWo + 15) / 16) * ((maxHo + TH - 1) / TH), tpb = 8;
+  static const int tpb_env = getenv("RT_LCT_TPB") ? atoi(getenv("RT_LCT_TPB")) : 0;
+  const int tiles = ((maxWo + 15) / 16) * ((maxHo + TH - 1) / TH), tpb = tpb_env > 0 ? tpb_env : 8;
   dim3 grid((tiles + tpb - 1) / tpb, n_img);
 #define RT_LCT_T(CC, NN, TT, S1, S2) RT_LAUNCH((k_lc_thin<CC, NN, TT, S1, S2>), grid, dim3(64 * TT), 0, st, x, gin, gout, C, Wd, bd, dw_act, dw_has_lab, dw_a, dw_c, Wp, N, Npad16, y, ldy, epi, tpb)
 #define RT_LCT(CC, NN) do { if (TH == 4) RT_LCT_T(CC, NN, 4, 1, 1); else RT_LCT_T(CC, NN, 8, 1, 1); } while (0)
