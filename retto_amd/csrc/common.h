@@ -20,18 +20,20 @@ enum Act { ACT_NONE = 0, ACT_RELU = 1, ACT_HSWISH = 2, ACT_SWISH = 3, ACT_SIGMOI
 
 // Fused conv/GEMM epilogue: y = lab(act(acc + bias)) [+ residual]
 struct Epilogue {
-  const float* bias;      // [Npad16] zero padded, or nullptr
-  int act;                // Act
-  int has_lab;            // LCNetV3 LearnableAffineBlock after the activation
-  float lab_a, lab_c;
-  const float* residual;  // optional, same row indexing as the output
-  int ld_res;
+  const float* bias = nullptr;   // [Npad16] zero padded, or nullptr
+  int act = ACT_NONE;     // Act
+  int has_lab = 0;        // LCNetV3 LearnableAffineBlock after the activation
+  float lab_a = 1.f, lab_c = 0.f;
+  const float* residual = nullptr;  // optional, same row indexing as the output
+  int ld_res = 0;
   // Squeeze-excite scale folded into the A operand (wide GEMM tiles only): row m of image i is
   // multiplied by a_scale[i * ld_scale + k] while its K-slab is staged.  a_tab holds, per row tile,
   // {image of the tile's first row, first row of the next image}; a tile spans at most 2 images.
   const float* a_scale = nullptr;
   int ld_scale = 0;
   const int* a_tab = nullptr;
+  int a_tab_stride = 2;   // 3: {image, first row of the next image, of the one after} per 256-row block (k_gemm32p; images >= 128 rows)
+  int n_img = 0;          // images behind a_scale (k_gemm32p clamps the neighbours it prefetches)
   // CTC head: instead of storing the logits tile, the wide GEMM leaves per (row, column tile) the
   // maximum, its column and sum(exp(logit - max)); nn::argmax_merge folds the tiles of a row.
   float* am_max = nullptr;

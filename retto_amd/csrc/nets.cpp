@@ -239,12 +239,12 @@ static float* run_lc(RunCtx& c, const LcBlock& b, const float* x, const Level& L
   // Squeeze-excite without extra passes over y1: the depthwise kernel leaves per-block channel sums,
   // the FC turns them into scales, and the pointwise GEMM multiplies them in while staging its A
   // rows (a row tile spans at most two images when every image has >= tile rows).
-  const int tile_rows = b.se ? nn::gemm_tile_rows(Lout.total, b.pw.Npad) : 0;
   long long min_pix = Lout.maxPix;
   for (const ImgGeom& g : Lout.h) min_pix = std::min<long long>(min_pix, (long long)g.H * g.W);
+  // 256: k_gemm32p (3-int table entries), 128: register-staged wide tiles (2-int entries), 0: no fused form
+  const int tile_rows = b.se ? nn::gemm_se_tile_rows(b.dw.Cp, Lout.total, b.pw.K, b.pw.N, b.pw.Npad, ACT_HSWISH, min_pix) : 0;
   static const bool no_se_fusion = getenv("RT_NO_SE_FUSION") != nullptr;  // A/B switch
-  const bool fuse_se = b.se && tile_rows > 0 && min_pix >= tile_rows && b.pw.K <= 512 && (b.dw.k == 3 || b.dw.k == 5) &&
-                       !no_se_fusion;
+  const bool fuse_se = b.se && tile_rows > 0 && b.pw.K <= 512 && (b.dw.k == 3 || b.dw.k == 5) && !no_se_fusion;
   float* pool = nullptr; int chunks = 0, strip_R = 0, strips_pb = 32;
   if (fuse_se) {
     nn::dwconv_pool_layout(b.dw.k, b.sh, b.sw, b.dw.Cp, Lout.maxH, Lout.maxW, &chunks, &strip_R, &strips_pb);
@@ -260,27 +260,29 @@ static float* run_lc(RunCtx& c, const LcBlock& b, const float* x, const Level& L
       nn::se_fc_from_dw(c.st, pool, Lout.d, Lout.n(), chunks, strip_R, strips_pb, b.sew.C, b.dw.Cp, b.sew.w1, b.sew.b1, b.sew.w2,
                         b.sew.b2, b.sew.Cr, HSIG_LCNET, 0, scale); }
     const int*& dtab = Lout.a_tabs[tile_rows];
+    const int stride = tile_rows == 256 ? 3 : 2;   // per row block: image of its first row, first row of the next image (, of the one after)
     if (!dtab) {
       const long long tiles = (Lout.total + tile_rows - 1) / tile_rows;
-      int* htab = c.pinned->alloc<int>((size_t)tiles * 2);
-      int* dt = c.arena->alloc<int>((size_t)tiles * 2);
+      int* htab = c.pinned->alloc<int>((size_t)tiles * stride);
+      int* dt = c.arena->alloc<int>((size_t)tiles * stride);
       size_t img = 0;
       for (long long t = 0; t < tiles; t++) {
         const long long m0 = t * tile_rows;
         while (img + 1 < Lout.h.size() && Lout.h[img + 1].off <= m0) img++;
-        htab[2 * t] = (int)img;
-        htab[2 * t + 1] = img + 1 < Lout.h.size() ? (int)Lout.h[img + 1].off : 0x7fffffff;  // no next image: never crossed
+        htab[stride * t] = (int)img;
+        htab[stride * t + 1] = img + 1 < Lout.h.size() ? (int)Lout.h[img + 1].off : 0x7fffffff;  // no next image: never crossed
+        if (stride == 3) htab[stride * t + 2] = img + 2 < Lout.h.size() ? (int)Lout.h[img + 2].off : 0x7fffffff;
       }
-      RT_HIP_CHECK(hipMemcpyAsync(dt, htab, (size_t)tiles * 2 * sizeof(int), hipMemcpyHostToDevice, c.st));
+      RT_HIP_CHECK(hipMemcpyAsync(dt, htab, (size_t)tiles * stride * sizeof(int), hipMemcpyHostToDevice, c.st));
       dtab = dt;
     }
-    epi.a_scale = scale; epi.ld_scale = b.dw.Cp; epi.a_tab = dtab;
+    epi.a_scale = scale; epi.ld_scale = b.dw.Cp; epi.a_tab = dtab; epi.a_tab_stride = stride; epi.n_img = Lout.n();
   } else if (b.se) {
     run_se(c, y1, Lout, b.sew, HSIG_LCNET, 0);
   }
   int Cpo = chan_pitch(b.cout);
   float* y2 = c.arena->alloc<float>((size_t)Lout.total * Cpo);
-  { ProfScope ps(c.prof, c.st, nn::gemm_pw_label(Lout.total, b.pw.Npad, fuse_se), shape_str(Lout.total, b.pw.K, b.pw.N, 0));
+  { ProfScope ps(c.prof, c.st, nn::gemm_pw_label(Lout.total, b.pw.Npad, fuse_se, tile_rows), shape_str(Lout.total, b.pw.K, b.pw.N, 0));
     nn::gemm(c.st, y1, b.dw.Cp, Lout.total, b.pw.K, b.pw.w, b.pw.N, b.pw.Npad, y2, Cpo, 0, epi); }
   return y2;
 }

@@ -12,7 +12,7 @@ constexpr int KC = 32;  // K-chunk of the MFMA GEMM / conv kernels (weights are 
 // C[M, ldc] (+coff) = epi(A[M, lda] x W), W packed as [ceil(K/KC)][Npad16][KC].
 void gemm(hipStream_t st, const float* A, int lda, long long M, int K, const float* Wp, int N, int Npad16, float* C,
           int ldc, int coff, const Epilogue& epi);
-const char* gemm_pw_label(long long M, int Npad16, bool a_scale = false);
+const char* gemm_pw_label(long long M, int Npad16, bool a_scale = false, int se_tile_rows = 0);   // se_tile_rows: gemm_se_tile_rows() of the layer
 // Persistent LDS-DMA form of the 256 x 240 tile (nn_gemm_dma.hip): N a multiple of 240, K whole 16-deep groups, plain
 // bias / activation / LAB epilogue.  gemm() takes it for the large 240- / 480-channel layers.
 bool gemm_dma_supported(int lda, long long M, int K, int N, int Npad16, const Epilogue& epi);
@@ -43,6 +43,10 @@ void se_fc_from_dw(hipStream_t st, const float* partial, const ImgGeom* geom, in
 // kernel: Epilogue::a_scale (squeeze-excite scale folded into the A staging) needs a wide tile and
 // every image at least that many rows.
 int gemm_tile_rows(long long M, int Npad16);
+// ... and which fused squeeze-excite form gemm() will take for this layer: 256 (k_gemm32p: a_tab entries of 3 ints per
+// 256-row block, Epilogue::a_tab_stride = 3, n_img set), 128 (wide register-staged tiles: 2 ints per 128-row block) or 0 (none:
+// scale the tensor in a pass of its own).  min_pix: rows of the smallest image.
+int gemm_se_tile_rows(int lda, long long M, int K, int N, int Npad16, int act, long long min_pix);
 // Fused CTC head: gemm() with Epilogue::am_* set (am_tiles = gemm_argmax_tiles(Npad16), buffers of
 // M * am_tiles elements) leaves softmax statistics per column tile; argmax_merge gives, per row, the
 // argmax over the N logits and softmax(logits)[argmax] -- the [M, 6625] logits never reach HBM.

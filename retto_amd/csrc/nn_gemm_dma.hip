@@ -61,6 +61,10 @@ struct GemmPArgs {
   long long M;
   int lda, K, N, Npad, ldc, coff;
   int n_rb, n_cb;      // row blocks of 256, column blocks of 240
+  // ASC (squeeze-excite scale folded into the pixel operand): row m of image i is multiplied by a_scale[i * ld_scale + k].
+  // a_tab holds 3 ints per row block: {image of the block's first row, first row of the next image, of the one after}
+  // (INT_MAX when there is none); every image has >= 128 rows, so a 256-row block touches at most 3.
+  const float* a_scale; const int* a_tab; int ld_scale, n_img;
   unsigned* sched;     // [0] tiles handed out beyond the first gridDim.x, [1] workgroups done (both zero between launches)
   Epilogue epi;
 };
@@ -70,11 +74,13 @@ constexpr unsigned P_ABYTES = P_BM * 128, P_WBYTES = P_BN * 128, P_STAGE = P_ABY
 constexpr int P_AJ = P_BM / 8, P_WJ = P_BN / 8;              // 1-KB DMA pieces (8 rows of 128 bytes) per operand and slab
 constexpr int P_NSTORE = P_MT * P_NT;                        // store instructions of one wave's epilogue
 constexpr int P_BIAS_MAX = 960;                              // bias vector kept in LDS (N <= 960)
+constexpr int P_SCK = 512;                                   // ASC: K <= 512; scale table = 2 tile parities x 3 images x P_SCK floats
 constexpr size_t P_LDS = 2 * (size_t)P_STAGE + P_BIAS_MAX * 4 + 16;   // slabs | bias | tile queue
+constexpr size_t P_LDS_ASC = P_LDS + 2 * 3 * P_SCK * 4;               // ... | scale tables
 
 // ACT / LAB: compile-time epilogue (-1 = decided per element); HALF: K = 32 j + 16, the last slab holds one group
 // DBG (timing experiments, wrong results): 1 no stores, 2 no requests after the first two, 4 no epilogue math, 8 stamps
-template <int ACT, int LAB, bool HALF, int DBG = 0>
+template <int ACT, int LAB, bool HALF, int DBG = 0, bool ASC = false>
 __global__ __launch_bounds__(P_NTHR, 1) void k_gemm32p(const GemmPArgs g) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem32p[];
   constexpr int MT = P_MT, NT = P_NT, WN = P_WN;
@@ -142,6 +148,15 @@ __global__ __launch_bounds__(P_NTHR, 1) void k_gemm32p(const GemmPArgs g) {
       glds16_so(off_w(3), wbase, dst + 3 * (P_NW * 1024));
       glds16_so(off_w(4), wbase, dst + 4 * (P_NW * 1024));
       if (wid + 5 * P_NW < P_AJ + P_WJ) glds16_so(off_w(5), wbase, dst + 5 * (P_NW * 1024));
+      if (ASC && it_kc == 0 && wid >= 2 && wid < 8) {
+        // the tile's scale vectors (3 images x K floats) ride with its first slab: waves 2..7 request one 1-KB piece each
+        // (image slot (wid - 2) / 2, half (wid - 2) % 2) into the table of this tile's parity
+        const int slot = (wid - 2) >> 1, half = (wid - 2) & 1;
+        const int img = min(g.a_tab[3 * it_rb] + slot, g.n_img - 1);
+        const float* sbase = g.a_scale + (long long)img * g.ld_scale;
+        const unsigned soff = (unsigned)min(half * 1024 + ln * 16, g.K * 4 - 16);   // (K = 240: the second half re-reads the tail)
+        glds16_so(soff, sbase, lds_b + (unsigned)(2 * P_STAGE + P_BIAS_MAX * 4 + 16) + (unsigned)(((it_j & 1) * 3 + slot) * P_SCK * 4 + half * 1024));
+      }
       it_buf ^= 1;
       if (++it_kc == nkc) {
         it_kc = 0;
@@ -252,12 +267,32 @@ __global__ __launch_bounds__(P_NTHR, 1) void k_gemm32p(const GemmPArgs g) {
     }
   };
 
+  // ASC: the pixel fragments of group grp of slab kc times the squeeze-excite scales of their rows' images
+  const float* sc_tab = reinterpret_cast<const float*>(smem32p + 2 * P_STAGE + P_BIAS_MAX * 4 + 16);
+  int sc_j = 0, sc_b1 = 0x7fffffff, sc_b2 = 0x7fffffff;   // current tile: table parity, tile-relative first rows of images 1 and 2
+  auto scale_a = [&](f32x4 (&a)[MT], int kc, int grp) __attribute__((always_inline)) {
+    if (ASC) {
+      int ln = lane_id();
+      asm volatile("" : "+v"(ln));
+      // (one table read per fragment at a per-lane address -- the image slot of the fragment's row -- instead of three vectors
+      //  and selects: 4 temporaries instead of 16; lanes of a quarter mostly share the address: LDS broadcast)
+      const float* t = sc_tab + (sc_j & 1) * 3 * P_SCK + kc * KC + grp * 16 + (ln >> 4) * 4;
+      const int rowb = wm * MT * 16 + (ln & 15);
+#pragma unroll
+      for (int mt = 0; mt < MT; mt++) {
+        const int row = rowb + mt * 16;
+        const int slot = (row >= sc_b1 ? 1 : 0) + (row >= sc_b2 ? 1 : 0);
+        a[mt] *= *reinterpret_cast<const f32x4*>(t + slot * P_SCK);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  };
   // One 32-deep slab = 10 steps of 16 MFMAs (5 weight fragments x 2 groups).  Weight fragments roll through B[0..4] two
   // steps ahead of their use, the pixel fragments of group 1 are read during group 0 and those of the next slab's group 0
   // during the last two steps; every wait leaves exactly the younger reads in flight (LDS returns in order).
   // COPY: the previous slab was a half slab, whose successor's pixel fragments went to A1 (A0 was still in use).
   // EPI: first slab of a tile -- the previous tile's epilogue chunks (if there is one: pend_cbase) precede the group-0 steps.
-  auto slab_full = [&](auto copy, auto epi) __attribute__((always_inline)) {
+  auto slab_full = [&](auto copy, auto epi, int kc) __attribute__((always_inline)) {
     constexpr bool COPY = decltype(copy)::value, EPI = decltype(epi)::value;
     const unsigned nxt_b = lds_b + ((cur_b - lds_b) ^ P_STAGE);
     const unsigned wa0 = cur_b + wo0, wa1 = wa0 ^ 64u, xa1 = (cur_b + xo0) ^ 64u;
@@ -277,13 +312,14 @@ __global__ __launch_bounds__(P_NTHR, 1) void k_gemm32p(const GemmPArgs g) {
 #pragma unroll
       for (int i = 0; i < MT; i++) A0[i] = A1[i];
     }
+    scale_a(A0, kc, 0);
     if (EPI) RT_MF0(A0, 0); else RT_MF(A0, 0);
     if (!EPI) {
       RT_RDB(wa0, 3); RT_RDA(xa1, A1); lgkm_wait<6>(); RT_MF(A0, 1);
       RT_RDB(wa0, 4); lgkm_wait<6>(); RT_MF(A0, 2);
       RT_RDB(wa1, 0); lgkm_wait<6>(); RT_MF(A0, 3);
       RT_RDB(wa1, 1); lgkm_wait<2>(); RT_MF(A0, 4);
-      RT_RDB(wa1, 2); lgkm_wait<2>(); RT_MF(A1, 0);
+      RT_RDB(wa1, 2); lgkm_wait<2>(); scale_a(A1, kc, 1); RT_MF(A1, 0);
     } else {
       // (with the epilogue chunks in front of the steps the group-1 pixel fragments are read late, at step 4: A1 is then
       //  dead while the chunks' temporaries are live -- read at step 1 the slab spills accumulators)
@@ -291,7 +327,7 @@ __global__ __launch_bounds__(P_NTHR, 1) void k_gemm32p(const GemmPArgs g) {
       RT_RDB(wa0, 4); if (pend_cbase) epi_chunk(IntTag<2>{}); lgkm_wait<2>(); RT_MF0(A0, 2);
       RT_RDB(wa1, 0); if (pend_cbase) epi_chunk(IntTag<3>{}); lgkm_wait<2>(); RT_MF0(A0, 3);
       RT_RDB(wa1, 1); if (pend_cbase) epi_chunk(IntTag<4>{}); RT_RDA(xa1, A1); lgkm_wait<6>(); RT_MF0(A0, 4);
-      RT_RDB(wa1, 2); lgkm_wait<1>(); RT_MF(A1, 0);
+      RT_RDB(wa1, 2); lgkm_wait<1>(); scale_a(A1, kc, 1); RT_MF(A1, 0);
     }
     RT_RDB(wa1, 3); lgkm_wait<2>(); RT_MF(A1, 1);
     RT_RDB(wa1, 4); lgkm_wait<2>(); RT_MF(A1, 2);
@@ -308,11 +344,11 @@ __global__ __launch_bounds__(P_NTHR, 1) void k_gemm32p(const GemmPArgs g) {
     st_slab_end();
     cur_b = nxt_b;
   };
-  auto slab_half = [&]() __attribute__((always_inline)) {   // group 0 only; the next slab's pixel fragments go to A1
+  auto slab_half = [&](int kc) __attribute__((always_inline)) {   // group 0 only; the next slab's pixel fragments go to A1
     const unsigned nxt_b = lds_b + ((cur_b - lds_b) ^ P_STAGE);
     const unsigned wa0 = cur_b + wo0;
     RT_ST(0);
-    RT_RDB(wa0, 2); lgkm_wait<2>(); RT_MF(A0, 0);
+    RT_RDB(wa0, 2); lgkm_wait<2>(); scale_a(A0, kc, 0); RT_MF(A0, 0);
     RT_RDB(wa0, 3); lgkm_wait<2>(); RT_MF(A0, 1);
     RT_RDB(wa0, 4); lgkm_wait<2>(); RT_MF(A0, 2);
     lgkm_wait<0>();
@@ -335,15 +371,29 @@ __global__ __launch_bounds__(P_NTHR, 1) void k_gemm32p(const GemmPArgs g) {
     // vector-memory operations of the wave, behind the slab request it waits for: exactly they may stay in flight.
     // (The stores of a partial row block may be skipped by whole waves: then nothing is assumed to be in flight.)
     after_epi = pend_cbase != nullptr && pend_rows == P_BM;
-    slab_full(std::integral_constant<bool, HALF>{}, std::true_type{});
+    if (ASC) {
+      const long long m0s = (long long)rb * P_BM;
+      sc_j = j;
+      sc_b1 = (int)min((long long)0x7fffffff, max(0ll, (long long)g.a_tab[3 * rb + 1] - m0s));
+      sc_b2 = (int)min((long long)0x7fffffff, max(0ll, (long long)g.a_tab[3 * rb + 2] - m0s));
+    }
+    slab_full(std::integral_constant<bool, HALF>{}, std::true_type{}, 0);
     if (ST) { if (st_on) { st_sum[5] += st_t[1] - st_t[6]; st_sum[6] += 1; } __builtin_amdgcn_sched_barrier(0); }
     // The id of tile j + 1 of this workgroup: one returning atomic of wave 0, issued at the start of the tile's second slab
     // and published at that slab's hand-over, whose vmcnt(0) covers its return.  (Inline asm: through the builtin hipcc waits
     // vmcnt(0) right behind the atomic, i.e. for the slab requests just issued; and not in the first slab, where the
     // result register would be live across the epilogue chunks.)
     fetch_now = true; pub_slot = (j + 1) & 3;
-    for (int kc = 1; kc + 1 < nkc; kc++) slab_full(std::false_type{}, std::false_type{});
-    if (HALF) slab_half(); else slab_full(std::false_type{}, std::false_type{});
+    // (nkc >= 4: at least two middle slabs.  Register allocation here is at its limit and sensitive to the loop form: the
+    //  ASC instantiations spill ~100 VGPRs with the top-tested loop -- the zero-trip path's copies -- and none with the
+    //  bottom-tested one; the plain K = 32 j instantiations are the other way round, by 4)
+    if constexpr (ASC) {
+      int kc = 1;
+      do { slab_full(std::false_type{}, std::false_type{}, kc); kc++; } while (kc + 1 < nkc);
+    } else {
+      for (int kc = 1; kc + 1 < nkc; kc++) slab_full(std::false_type{}, std::false_type{}, kc);
+    }
+    if (HALF) slab_half(nkc - 1); else slab_full(std::false_type{}, std::false_type{}, nkc - 1);
     const long long m0 = (long long)rb * P_BM;
     pend_cbase = reinterpret_cast<char*>(g.C + m0 * g.ldc + g.coff + cb * P_BN);
     pend_n0 = cb * P_BN + wn * NT * 16;
@@ -386,7 +436,9 @@ __global__ __launch_bounds__(P_NTHR, 1) void k_gemm32p(const GemmPArgs g) {
 }
 
 bool gemm_dma_supported(int lda, long long M, int K, int N, int Npad16, const Epilogue& epi) {
-  if (epi.a_scale || epi.am_max || epi.residual) return false;
+  if (epi.am_max || epi.residual) return false;
+  // squeeze-excite scale: 3-int row-block table (gemm_se_tile_rows() == 256), hardswish epilogue, K within the LDS scale table
+  if (epi.a_scale && (epi.a_tab_stride != 3 || !epi.a_tab || K > P_SCK || epi.act != ACT_HSWISH || epi.n_img <= 0)) return false;
   if ((N + 3) / 4 * 4 != N) return false;
   if (Npad16 != N || N % P_BN != 0 || N > P_BIAS_MAX) return false;
   // (>= 4 slabs: the request side reads the next tile's id when it has issued a tile's last slab, at the hand-over of the
@@ -426,6 +478,7 @@ void gemm_dma(hipStream_t st, const float* A, int lda, long long M, int K, const
   g.sched = sched;
   g.A = A; g.Wp = Wp; g.C = C; g.M = M; g.lda = lda; g.K = K; g.N = N; g.Npad = Npad16; g.ldc = ldc; g.coff = coff;
   g.n_rb = (int)((M + P_BM - 1) / P_BM); g.n_cb = N / P_BN; g.epi = epi;
+  g.a_scale = epi.a_scale; g.a_tab = epi.a_tab; g.ld_scale = epi.ld_scale; g.n_img = epi.n_img;
   const int grid = std::min(g.n_rb * g.n_cb, cus[dev]);
   const bool half = K % KC != 0;   // (supported K are whole 16-deep groups)
 #define RT_G32P(ACTV, LABV) do { if (half) { allow_big_lds((const void*)k_gemm32p<ACTV, LABV, true>, 160 * 1024); RT_LAUNCH((k_gemm32p<ACTV, LABV, true>), dim3((unsigned)grid), dim3(P_NTHR), P_LDS, st, g); } \
@@ -461,6 +514,13 @@ void gemm_dma(hipStream_t st, const float* A, int lda, long long M, int K, const
     if ((dbg & 16) && h[1]) fprintf(stderr, "g32p clock: %llu shader cycles in %.1f us = %.3f GHz\n", h[0], h[1] / 100.0, h[0] / (h[1] * 10.0));
     if ((dbg & 8) && h[7]) fprintf(stderr, "g32p stamps (wave %d of block 7): %llu slabs, per slab: steps0-7 %llu | lgkm+vmcnt wait %llu | barrier %llu | step 8 + dma issue %llu | step 9 %llu ; %llu first slabs with epilogue chunks: steps 0-7 %llu cycles\n",
                                    g.epi.am_tiles, h[7], h[0] / h[7], h[1] / h[7], h[2] / h[7], h[3] / h[7], h[4] / h[7], h[6], h[6] ? h[5] / h[6] : 0);
+    return;
+  }
+  if (epi.a_scale) {
+#define RT_G32P_SE(LABV) do { if (half) { allow_big_lds((const void*)k_gemm32p<ACT_HSWISH, LABV, true, 0, true>, 160 * 1024); RT_LAUNCH((k_gemm32p<ACT_HSWISH, LABV, true, 0, true>), dim3((unsigned)grid), dim3(P_NTHR), P_LDS_ASC, st, g); } \
+                              else { allow_big_lds((const void*)k_gemm32p<ACT_HSWISH, LABV, false, 0, true>, 160 * 1024); RT_LAUNCH((k_gemm32p<ACT_HSWISH, LABV, false, 0, true>), dim3((unsigned)grid), dim3(P_NTHR), P_LDS_ASC, st, g); } } while (0)
+    if (epi.has_lab) RT_G32P_SE(1); else RT_G32P_SE(0);
+#undef RT_G32P_SE
     return;
   }
   if (epi.act == ACT_HSWISH && epi.has_lab) RT_G32P(ACT_HSWISH, 1);

@@ -696,7 +696,8 @@ static int gemm_dispatch(long long M, int Npad16) {
 }
 // Profiler label of a pointwise-conv GEMM: family + the kernel symbol the dispatcher picks, so the
 // per-kernel numbers of bench.py can be compared with rocprofv3's kernel stats one to one.
-const char* gemm_pw_label(long long M, int Npad16, bool a_scale) {
+const char* gemm_pw_label(long long M, int Npad16, bool a_scale, int se_tile_rows) {
+  if (a_scale && se_tile_rows == 256) return "gemm_pw/k_gemm32p+se";
   if (a_scale && !g_gemm_variant) return gemm_dispatch(M, Npad16) == 0 ? "gemm_pw/k_gemm_wide<2,4,4,2>+se" : "gemm_pw/k_gemm_wide<2,5,4,3>+se";
   switch (g_gemm_variant ? -1 : gemm_dispatch(M, Npad16)) {
     case 15: return g_gemm_dma ? "gemm_pw/k_gemm32p" : "gemm_pw/k_gemm_wide<4,5,4,3>";
@@ -732,6 +733,17 @@ void argmax_merge(hipStream_t st, const float* pm, const int* pi, const float* p
   RT_LAUNCH(k_argmax_merge, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, pm, pi, ps, tiles, rows, idx, prob);
 }
 
+// Row-block height of the squeeze-excite (a_scale) form the dispatcher will take: 256 = k_gemm32p (3-int a_tab entries, images
+// of >= 128 rows), 128 = the register-staged wide tiles (2-int entries, images >= 128 rows), 0 = no fused form.
+int gemm_se_tile_rows(int lda, long long M, int K, int N, int Npad16, int act, long long min_pix) {
+  if (g_gemm_variant) return 0;
+  Epilogue probe; probe.act = act;
+  if (g_gemm_dma && gemm_dispatch(M, Npad16) == 15 && min_pix >= 128 && K <= 512 && act == ACT_HSWISH &&
+      gemm_dma_supported(lda, M, K, N, Npad16, probe))
+    return 256;
+  const int r = gemm_tile_rows(M, Npad16);
+  return (r > 0 && min_pix >= r) ? r : 0;
+}
 int gemm_tile_rows(long long M, int Npad16) {
   if (g_gemm_variant) return 0;
   if (gemm_dispatch(M, Npad16) != 0) return 128;  // (a_scale runs the 256 x 240 shapes on the 128 x 240 tile)
@@ -763,6 +775,7 @@ void gemm(hipStream_t st, const float* A, int lda, long long M, int K, const flo
     return;
   }
   if (v == 30) v = 15;
+  if (epi.a_scale && epi.a_tab_stride != 2) throw RtError(8, "gemm: a 3-int a_tab is only understood by k_gemm32p (gemm_se_tile_rows() == 256)");
   if (epi.a_scale) {  // squeeze-excite scale folded into the A staging: wide tiles only (gemm_tile_rows)
     if (K > 512 || !epi.a_tab) throw RtError(8, "gemm: a_scale needs K <= 512 and a row-tile table");
     if (v == 15) v = 10;  // the 256-row tile has no registers to spare for the scaling (spills): 128 x 240 measured faster

@@ -26,6 +26,8 @@ def gemm_pw_label(M: int, N: int, se: bool = False) -> str:
     squeeze-excite whose scale is folded into the GEMM's A staging (wide tiles, every image
     >= 128 rows at that level -- true for the bench workloads)."""
     npad = (N + 15) // 16 * 16
+    if se and npad % 240 == 0 and M >= 131072 and os.environ.get("RT_GEMM_DMA", "1") != "0":
+        return "gemm_pw/k_gemm32p+se"   # (images of >= 128 rows at that level: true for the bench workloads)
     if se and M >= 8192 and npad >= 128:
         return "gemm_pw/k_gemm_wide<2,5,4,3>+se" if npad % 240 == 0 and M >= 16384 else "gemm_pw/k_gemm_wide<2,4,4,2>+se"
     if npad % 240 == 0 and M >= 131072:   # (the persistent LDS-DMA form unless RT_GEMM_DMA=0 keeps the register-staged tile)
