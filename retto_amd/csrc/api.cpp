@@ -496,4 +496,72 @@ RT_API int rt_bench_gemm(rt_session* s, long long M, int K, int N, int variant, 
   });
 }
 
+// Kernel micro-benchmark: the fused thin LCNetV3 block (3x3 depthwise -> pointwise) on n images of h x w pixels, random data.
+// form 0 = k_lc_thin (LDS staged), 1 = k_lc_wave; maxdiff compares with form 0.
+RT_API int rt_bench_lc(rt_session* s, int n, int h, int w, int cin, int cout, int stride, int form, int iters, float* ms_out, float* maxdiff_out) {
+  RT_REQUIRE(s && ms_out && n > 0 && h > 0 && w > 0 && (stride == 1 || stride == 2), s, "rt_bench_lc: bad argument");
+  return guarded(s, [&] {
+    RT_HIP_CHECK(hipSetDevice(s->device));
+    const int Cp = round_up(cin, 4), Np = round_up(cout, 16), ldy = chan_pitch(cout), nkc = (Cp + nn::KC - 1) / nn::KC;
+    const int ho = (h + stride - 1) / stride, wo = (w + stride - 1) / stride;
+    if (!nn::lc_thin_supported(3, stride, stride, Cp, cin, Np)) throw RtError(8, "rt_bench_lc: shape not instantiated");
+    std::vector<ImgGeom> gi(n), go(n);
+    for (int i = 0; i < n; i++) { gi[i] = ImgGeom{(long long)i * h * w, h, w, 0}; go[i] = ImgGeom{(long long)i * ho * wo, ho, wo, 0}; }
+    const size_t nin = (size_t)n * h * w * Cp, nout = (size_t)n * ho * wo * ldy;
+    std::vector<float> hx(nin), hwd(9 * Cp), hbd(Cp, 0.05f), hw((size_t)nkc * Np * nn::KC, 0.f), hb(Np, 0.1f);
+    uint32_t st = 777;
+    auto rnd = [&]() { st = st * 1664525u + 1013904223u; return ((st >> 8) & 0xffff) / 32768.0f - 1.0f; };
+    for (auto& v : hx) v = rnd();
+    for (auto& v : hwd) v = rnd() * 0.3f;
+    for (int k = 0; k < cin; k++) for (int c = 0; c < cout; c++) hw[((size_t)(k / nn::KC) * Np + c) * nn::KC + k % nn::KC] = rnd() * 0.1f;
+    float *dx, *dwd, *dbd, *dw, *db, *dy, *dy0; ImgGeom *dgi, *dgo;
+    RT_HIP_CHECK(hipMalloc((void**)&dx, nin * 4)); RT_HIP_CHECK(hipMalloc((void**)&dwd, hwd.size() * 4)); RT_HIP_CHECK(hipMalloc((void**)&dbd, hbd.size() * 4));
+    RT_HIP_CHECK(hipMalloc((void**)&dw, hw.size() * 4)); RT_HIP_CHECK(hipMalloc((void**)&db, hb.size() * 4));
+    RT_HIP_CHECK(hipMalloc((void**)&dy, nout * 4)); RT_HIP_CHECK(hipMalloc((void**)&dy0, nout * 4));
+    RT_HIP_CHECK(hipMalloc((void**)&dgi, n * sizeof(ImgGeom))); RT_HIP_CHECK(hipMalloc((void**)&dgo, n * sizeof(ImgGeom)));
+    RT_HIP_CHECK(hipMemset(dy, 0, nout * 4)); RT_HIP_CHECK(hipMemset(dy0, 0, nout * 4));
+    RT_HIP_CHECK(hipMemcpy(dx, hx.data(), nin * 4, hipMemcpyHostToDevice)); RT_HIP_CHECK(hipMemcpy(dwd, hwd.data(), hwd.size() * 4, hipMemcpyHostToDevice));
+    RT_HIP_CHECK(hipMemcpy(dbd, hbd.data(), hbd.size() * 4, hipMemcpyHostToDevice)); RT_HIP_CHECK(hipMemcpy(dw, hw.data(), hw.size() * 4, hipMemcpyHostToDevice));
+    RT_HIP_CHECK(hipMemcpy(db, hb.data(), hb.size() * 4, hipMemcpyHostToDevice));
+    RT_HIP_CHECK(hipMemcpy(dgi, gi.data(), n * sizeof(ImgGeom), hipMemcpyHostToDevice)); RT_HIP_CHECK(hipMemcpy(dgo, go.data(), n * sizeof(ImgGeom), hipMemcpyHostToDevice));
+    Epilogue e; e.bias = db; e.act = ACT_HSWISH; e.has_lab = 1; e.lab_a = 1.01f; e.lab_c = 0.02f;
+    auto run = [&](float* out) {
+      nn::lc_thin(s->st, stride, stride, dx, dgi, dgo, n, ho, wo, Cp, cin, dwd, dbd, stride == 1 ? ACT_HSWISH : ACT_NONE, stride == 1, 0.99f, 0.01f, dw, cout, Np, out, ldy, e);   // (depthwise tail as in the LCNetV3 blocks)
+    };
+    const int keep = nn::g_lc_wave;
+    nn::g_lc_wave = getenv("RT_BENCH_LC_REF") ? atoi(getenv("RT_BENCH_LC_REF")) : 0; run(dy0);
+    nn::g_lc_wave = form; run(dy);
+    hipEvent_t a, b; RT_HIP_CHECK(hipEventCreate(&a)); RT_HIP_CHECK(hipEventCreate(&b));
+    RT_HIP_CHECK(hipEventRecord(a, s->st));
+    for (int i = 0; i < iters; i++) run(dy);
+    RT_HIP_CHECK(hipEventRecord(b, s->st));
+    RT_HIP_CHECK(hipStreamSynchronize(s->st));
+    nn::g_lc_wave = keep;
+    float ms = 0; RT_HIP_CHECK(hipEventElapsedTime(&ms, a, b)); *ms_out = ms / iters;
+    if (maxdiff_out) {
+      const size_t cnt = std::min<size_t>(nout, (size_t)1 << 22);
+      std::vector<float> c0(cnt), c1(cnt);
+      float md = 0;
+      for (size_t off : {(size_t)0, nout - cnt}) {
+        RT_HIP_CHECK(hipMemcpy(c0.data(), dy0 + off, cnt * 4, hipMemcpyDeviceToHost)); RT_HIP_CHECK(hipMemcpy(c1.data(), dy + off, cnt * 4, hipMemcpyDeviceToHost));
+        size_t bad = 0;
+        std::map<std::string, int> hist;
+        for (size_t i = 0; i < cnt; i++) {
+          const float d = std::fabs(c0[i] - c1[i]); md = (d > md || d != d) ? (d != d ? INFINITY : d) : md;
+          if (d != 0 && getenv("RT_BENCH_LC_DUMP")) {
+            const size_t e = off + i, px = e / ldy; const int ch = (int)(e % ldy), img = (int)(px / ((size_t)ho * wo)), yy = (int)(px % ((size_t)ho * wo)) / wo, xx = (int)(px % wo);
+            if (bad++ < 4) fprintf(stderr, "  diff img %d y %d x %d ch %d: %g vs %g\n", img, yy, xx, ch, c0[i], c1[i]);
+            hist["x%16=" + std::to_string(xx % 16)]++; hist["ch%4=" + std::to_string(ch % 4)]++; hist["ch/16=" + std::to_string(ch / 16)]++; hist["y%2=" + std::to_string(yy % 2)]++;
+            hist["tx=" + std::to_string(xx / 16)]++; hist["q=" + std::to_string((ch % 16) / 4)]++;
+          }
+        }
+        if (bad) { fprintf(stderr, "  %zu of %zu differ:", bad, cnt); for (auto& kv : hist) fprintf(stderr, " %s:%d", kv.first.c_str(), kv.second); fprintf(stderr, "\n"); }
+      }
+      *maxdiff_out = md;
+    }
+    (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+    for (void* p : {(void*)dx, (void*)dwd, (void*)dbd, (void*)dw, (void*)db, (void*)dy, (void*)dy0, (void*)dgi, (void*)dgo}) (void)hipFree(p);
+  });
+}
+
 }  // extern "C"

@@ -61,6 +61,12 @@ bool lc_thin_supported(int K, int sh, int sw, int Cp, int C, int Npad16);
 void lc_thin(hipStream_t st, int sh, int sw, const float* x, const ImgGeom* gin, const ImgGeom* gout, int n_img, int maxHo,
              int maxWo, int Cp, int C, const float* Wd, const float* bd, int dw_act, int dw_has_lab, float dw_a, float dw_c,
              const float* Wp, int N, int Npad16, float* y, int ldy, const Epilogue& epi);
+// one-wave-per-tile form of the same block (nn_lcwave.hip): activations never touch LDS; bit-identical to lc_thin
+extern int g_lc_wave;
+bool lc_wave_supported(int K, int sh, int sw, int Cp, int C, int N, int Npad16, int dw_act, int dw_has_lab, const Epilogue& epi);
+void lc_wave(hipStream_t st, int sh, int sw, const float* x, const ImgGeom* gin, const ImgGeom* gout, int n_img, int maxHo,
+             int maxWo, int Cp, int C, const float* Wd, const float* bd, int dw_act, int dw_has_lab, float dw_a, float dw_c,
+             const float* Wp, int N, int Npad16, float* y, int ldy, const Epilogue& epi);
 
 // 3x3 stride-2 stem on a 3(+1 pad)-channel f32 NHWC input. Ws packed [27][COUT]. COUT in {8,16}.
 // One RGB8 page of a det launch group (device pointer; npix = H*W; out_pix = its pixel offset in the group).
