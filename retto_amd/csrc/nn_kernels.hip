@@ -640,7 +640,7 @@ __global__ __launch_bounds__(64 * TH) void k_lc_thin(const float* __restrict__ x
   }
 }
 
-int g_lc_wave = getenv("RT_LC_WAVE") ? atoi(getenv("RT_LC_WAVE")) : 0;   // A/B: 1 = one-wave-per-tile form (nn_lcwave.hip)
+int g_lc_wave = getenv("RT_LC_WAVE") ? atoi(getenv("RT_LC_WAVE")) : 3;   // 3 = wave-private LDS form for the stride-1 blocks (nn_lcwave.hip, default); 1 = direct-load form, every shape (A/B); 0 = k_lc_thin
 int g_lc_thin = 4;  // 4 = fused thin blocks (default); 2 / 3 = force the 128- / 64-pixel tile; 0 = separate depthwise + GEMM kernels (A/B)
 static int lc_thin_code(int sh, int sw, int Cp, int Npad16) {  // instantiated (stride, C_in/4, column tiles) combinations
   const int c4 = Cp / 4, nt = (Npad16 + 31) / 32;
@@ -663,7 +663,7 @@ void lc_thin(hipStream_t st, int sh, int sw, const float* x, const ImgGeom* gin,
              const float* Wp, int N, int Npad16, float* y, int ldy, const Epilogue& epi) {
   if (n_img <= 0) return;
   if (epi.residual || epi.a_scale) throw RtError(8, "lc_thin: residual / a_scale epilogues are not supported");
-  if (g_lc_wave && g_lc_thin == 4 && lc_wave_supported(3, sh, sw, Cp, C, N, Npad16, dw_act, dw_has_lab, epi)) {
+  if (g_lc_wave && g_lc_thin == 4 && (sh == 1 || g_lc_wave < 3) && lc_wave_supported(3, sh, sw, Cp, C, N, Npad16, dw_act, dw_has_lab, epi)) {
     lc_wave(st, sh, sw, x, gin, gout, n_img, maxHo, maxWo, Cp, C, Wd, bd, dw_act, dw_has_lab, dw_a, dw_c, Wp, N, Npad16, y, ldy, epi);
     return;
   }

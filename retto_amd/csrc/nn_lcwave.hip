@@ -60,7 +60,7 @@ struct LcwArgs {   // (compact: the kernel keeps its scalars in SGPRs; a spilled
   const float* x; const ImgGeom* gin; const ImgGeom* gout;
   const float* Wd; const float* bd; const float* Wp; const float* bias; float* y;
   float dw_a, dw_c, pw_a, pw_c;
-  int Npad, ldy, tiles_per_wave, flags;   // flags & 1: pointwise bias from global memory (A/B)
+  int Npad, ldy, tiles_per_wave, flags;
 };
 
 // DWA: the depthwise half ends in hardswish + LAB (stride 1) or in nothing (stride 2).  The pointwise half always ends in
@@ -439,7 +439,7 @@ void lc_wave(hipStream_t st, int sh, int sw, const float* x, const ImgGeom* gin,
     const int mtl = mt_env == 2 ? 2 : 4;
     const int tiles = ((maxWo + 15) / 16) * ((maxHo + mtl - 1) / mtl);
     dim3 grid((tiles + 4 * tpw - 1) / (4 * tpw), n_img);
-    LcwArgs a{x, gin, gout, Wd, bd, Wp, epi.bias, y, dw_a, dw_c, epi.has_lab ? epi.lab_a : 1.f, epi.has_lab ? epi.lab_c : 0.f, Npad16, ldy, tpw, g_lc_wave == 4 ? 1 : 0};
+    LcwArgs a{x, gin, gout, Wd, bd, Wp, epi.bias, y, dw_a, dw_c, epi.has_lab ? epi.lab_a : 1.f, epi.has_lab ? epi.lab_c : 0.f, Npad16, ldy, tpw, 0};
 #define RT_LCL(GG, NN) do { if (mtl == 2) RT_LAUNCH((k_lc_lds<GG, NN, 2, true>), grid, dim3(256), 0, st, a); else RT_LAUNCH((k_lc_lds<GG, NN, 4, true>), grid, dim3(256), 0, st, a); } while (0)
     switch (code) {
       case 1: RT_LCL(1, 2); break;
@@ -453,7 +453,7 @@ void lc_wave(hipStream_t st, int sh, int sw, const float* x, const ImgGeom* gin,
   const int mt = mt_env == 1 ? 1 : 2;
   const int tiles = ((maxWo + 15) / 16) * ((maxHo + mt - 1) / mt);
   dim3 grid((tiles + 4 * tpw - 1) / (4 * tpw), n_img);
-  LcwArgs a{x, gin, gout, Wd, bd, Wp, epi.bias, y, dw_a, dw_c, epi.has_lab ? epi.lab_a : 1.f, epi.has_lab ? epi.lab_c : 0.f, Npad16, ldy, tpw, g_lc_wave == 2 ? 1 : 0};
+  LcwArgs a{x, gin, gout, Wd, bd, Wp, epi.bias, y, dw_a, dw_c, epi.has_lab ? epi.lab_a : 1.f, epi.has_lab ? epi.lab_c : 0.f, Npad16, ldy, tpw, 0};
 #define RT_LCW_T(GG, NN, MM, SS) RT_LAUNCH((k_lc_wave<GG, NN, MM, SS, SS == 1>), grid, dim3(256), 0, st, a)
 #define RT_LCW(GG, NN, SS) do { if (mt == 1) RT_LCW_T(GG, NN, 1, SS); else RT_LCW_T(GG, NN, 2, SS); } while (0)
   switch (code) {
