@@ -499,12 +499,12 @@ RT_API int rt_bench_gemm(rt_session* s, long long M, int K, int N, int variant, 
 // Kernel micro-benchmark: the fused thin LCNetV3 block (3x3 depthwise -> pointwise) on n images of h x w pixels, random data.
 // form 0 = k_lc_thin (LDS staged), 1 = k_lc_wave; maxdiff compares with form 0.
 RT_API int rt_bench_lc(rt_session* s, int n, int h, int w, int cin, int cout, int stride, int form, int iters, float* ms_out, float* maxdiff_out) {
-  RT_REQUIRE(s && ms_out && n > 0 && h > 0 && w > 0 && (stride == 1 || stride == 2), s, "rt_bench_lc: bad argument");
+  RT_REQUIRE(s && ms_out && n > 0 && h > 0 && w > 0 && (stride == 1 || stride == 2 || stride == 21), s, "rt_bench_lc: bad argument");
   return guarded(s, [&] {
     RT_HIP_CHECK(hipSetDevice(s->device));
     const int Cp = round_up(cin, 4), Np = round_up(cout, 16), ldy = chan_pitch(cout), nkc = (Cp + nn::KC - 1) / nn::KC;
-    const int ho = (h + stride - 1) / stride, wo = (w + stride - 1) / stride;
-    if (!nn::lc_thin_supported(3, stride, stride, Cp, cin, Np)) throw RtError(8, "rt_bench_lc: shape not instantiated");
+    const int sh = stride == 21 ? 2 : stride, sw = stride == 21 ? 1 : stride;   // 21: stride (2, 1)
+    const int ho = (h + sh - 1) / sh, wo = (w + sw - 1) / sw;
     std::vector<ImgGeom> gi(n), go(n);
     for (int i = 0; i < n; i++) { gi[i] = ImgGeom{(long long)i * h * w, h, w, 0}; go[i] = ImgGeom{(long long)i * ho * wo, ho, wo, 0}; }
     const size_t nin = (size_t)n * h * w * Cp, nout = (size_t)n * ho * wo * ldy;
@@ -525,8 +525,16 @@ RT_API int rt_bench_lc(rt_session* s, int n, int h, int w, int cin, int cout, in
     RT_HIP_CHECK(hipMemcpy(db, hb.data(), hb.size() * 4, hipMemcpyHostToDevice));
     RT_HIP_CHECK(hipMemcpy(dgi, gi.data(), n * sizeof(ImgGeom), hipMemcpyHostToDevice)); RT_HIP_CHECK(hipMemcpy(dgo, go.data(), n * sizeof(ImgGeom), hipMemcpyHostToDevice));
     Epilogue e; e.bias = db; e.act = ACT_HSWISH; e.has_lab = 1; e.lab_a = 1.01f; e.lab_c = 0.02f;
+    const int dw_act = (sh == 2 && sw == 2) ? ACT_NONE : ACT_HSWISH, dw_lab = !(sh == 2 && sw == 2);   // (depthwise tail as in the LCNetV3 blocks)
+    float* dy1 = nullptr;   // unfused reference: depthwise output
     auto run = [&](float* out) {
-      nn::lc_thin(s->st, stride, stride, dx, dgi, dgo, n, ho, wo, Cp, cin, dwd, dbd, stride == 1 ? ACT_HSWISH : ACT_NONE, stride == 1, 0.99f, 0.01f, dw, cout, Np, out, ldy, e);   // (depthwise tail as in the LCNetV3 blocks)
+      if (nn::g_lc_wave == 0 && !nn::lc_thin_supported(3, sh, sw, Cp, cin, Np)) {   // no k_lc_thin instance: depthwise + GEMM
+        if (!dy1) RT_HIP_CHECK(hipMalloc((void**)&dy1, (size_t)n * ho * wo * Cp * 4));
+        nn::dwconv(s->st, 3, sh, sw, dx, dgi, dgo, n, ho, wo, Cp, cin, dwd, dbd, dw_act, dw_lab, 0.99f, 0.01f, dy1, nullptr);
+        nn::gemm(s->st, dy1, Cp, (long long)n * ho * wo, Cp, dw, cout, Np, out, ldy, 0, e);
+        return;
+      }
+      nn::lc_thin(s->st, sh, sw, dx, dgi, dgo, n, ho, wo, Cp, cin, dwd, dbd, dw_act, dw_lab, 0.99f, 0.01f, dw, cout, Np, out, ldy, e);
     };
     const int keep = nn::g_lc_wave;
     nn::g_lc_wave = getenv("RT_BENCH_LC_REF") ? atoi(getenv("RT_BENCH_LC_REF")) : 0; run(dy0);
@@ -560,7 +568,7 @@ RT_API int rt_bench_lc(rt_session* s, int n, int h, int w, int cin, int cout, in
       *maxdiff_out = md;
     }
     (void)hipEventDestroy(a); (void)hipEventDestroy(b);
-    for (void* p : {(void*)dx, (void*)dwd, (void*)dbd, (void*)dw, (void*)db, (void*)dy, (void*)dy0, (void*)dgi, (void*)dgo}) (void)hipFree(p);
+    for (void* p : {(void*)dx, (void*)dwd, (void*)dbd, (void*)dw, (void*)db, (void*)dy, (void*)dy0, (void*)dgi, (void*)dgo, (void*)dy1}) (void)hipFree(p);
   });
 }
 

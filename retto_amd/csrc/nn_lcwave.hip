@@ -249,10 +249,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 // No barrier: LDS operations of a wave execute in order, the buffer belongs to the wave.  MT = 4 rows per tile: the taps and the
 // weight fragments (LDS reads, too) are amortised over four MFMA row tiles.  Same arithmetic order as k_lc_wave / k_lc_thin.
 // ---------------------------------------------------------------------------------------------------------------------
-template <int G, int NT, int MT, bool DWA>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MT == 2 ? 3 : 2, MT == 2 ? 3 : 2))) void k_lc_lds(LcwArgs p) {
+template <int G, int NT, int MT, int SH, int SW, bool DWA, int WPE>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_lc_lds(LcwArgs p) {
   constexpr int CP = G * 16, NKC = (CP + KC - 1) / KC, NCOL = NT * 16;
-  constexpr int IR = MT + 2, PXR = 18, RP = PXR * 64;     // input rows of a tile, pixels per row, row pitch in bytes
+  constexpr int IR = (MT - 1) * SH + 3, PXR = 15 * SW + 3, RP = PXR * 64;     // input rows of a tile, pixels per row, row pitch in bytes
   constexpr int SLOTS = IR * PXR * 4, NJ = (SLOTS + 63) / 64, XB = IR * RP + 512;   // (+ 512 bytes: the slots past the patch land there)
   __shared__ __attribute__((aligned(16))) float wt[NKC * NCOL * LROW];
   __shared__ __attribute__((aligned(16))) float tp[10 * CP + NCOL];  // 9 taps + depthwise bias, [t][CP]; pointwise bias [NCOL]
@@ -287,38 +287,42 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MT == 2 ? 3
   for (int j = 0; j < NJ; j++) {
     const int t = lane + 64 * j, row = t / (PXR * 4), rem = t - row * (PXR * 4), px = rem >> 2, c = rem & 3;
     const unsigned la = (unsigned)(size_t)(__attribute__((address_space(3))) char*)xw + (t < SLOTS ? row * RP + swz(px, c) : IR * RP + (lane & 31) * 16);
-    wr[j] = la | (unsigned)(t < SLOTS ? row : 31) << 24 | (unsigned)(px * 4 + c) << 17;   // (LDS addresses stay below 2^17)
+    wr[j] = la | (unsigned)(t < SLOTS ? row : 31) << 25 | (unsigned)(px * 4 + c) << 17;   // (LDS addresses stay below 2^17; pixel * 4 + chunk < 256)
   }
   const char* rd[3];
 #pragma unroll
-  for (int dx = 0; dx < 3; dx++) rd[dx] = xw + swz(r + dx, q);
+  for (int dx = 0; dx < 3; dx++) rd[dx] = xw + swz(r * SW + dx, q);
 
   int tile = first + wave;
   if (tile >= n_tiles) return;
   int ty = tile / tiles_x, tx = tile - ty * tiles_x;
   ty = __builtin_amdgcn_readfirstlane(ty); tx = __builtin_amdgcn_readfirstlane(tx);
 
+  // Prefetch distance: one slice (the loads of slice n + 1 fly under the depthwise + MFMA work of slice n, ~1.3 us) or, where
+  // the registers allow it (MT = 4 runs 2 waves per SIMD) and G is even, two slices with two sets of staging registers.
+  constexpr int DEPTH = (MT == 4 && G % 2 == 0 && SH == 1 && SW == 1) ? 2 : 1;
   unsigned goff[NJ], y_off;
-  f32x4 st[NJ];
+  f32x4 st[DEPTH][NJ];
   auto lane_offsets = [&](int tyy, int txx) __attribute__((always_inline)) {
 #pragma unroll
     for (int j = 0; j < NJ; j++) {
-      const int row = wr[j] >> 24, pc = (wr[j] >> 17) & 127;
-      const int iy = tyy * MT - 1 + row, ix = txx * 16 - 1 + (pc >> 2);
+      const int row = wr[j] >> 25, pc = (wr[j] >> 17) & 255;
+      const int iy = tyy * (MT * SH) - 1 + row, ix = txx * (16 * SW) - 1 + (pc >> 2);
       const bool ok = row < IR && (unsigned)iy < (unsigned)gi.H && (unsigned)ix < (unsigned)gi.W;
       goff[j] = ok ? (unsigned)iy * row_bytes + (unsigned)ix * (CP * 4) + (pc & 3) * 16 : OOB;
     }
     const int ox = txx * 16 + r;
     y_off = ox < g.W ? (unsigned)ox * ((unsigned)p.ldy * 4) + q * 16 : OOB;
   };
-  auto fetch = [&](auto gg_tag) __attribute__((always_inline)) {
-    constexpr int GG = decltype(gg_tag)::value;
+  auto fetch = [&](auto gg_tag, auto buf_tag) __attribute__((always_inline)) {   // slice GG of the tile `goff` describes
+    constexpr int GG = decltype(gg_tag)::value, B = decltype(buf_tag)::value;
 #pragma unroll
-    for (int j = 0; j < NJ; j++) st[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, goff[j], GG * 64, 0));
+    for (int j = 0; j < NJ; j++) st[B][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, goff[j], GG * 64, 0));
   };
 
   lane_offsets(ty, tx);
-  fetch(IntTag<0>{});
+  fetch(IntTag<0>{}, IntTag<0>{});
+  if (DEPTH == 2) fetch(IntTag<1 % G>{}, IntTag<DEPTH - 1>{});
   for (int it = 0; it < p.tiles_per_wave; it++) {
     int ntx = tx + 4, nty = ty;
     while (ntx >= tiles_x) { ntx -= tiles_x; nty++; }
@@ -328,15 +332,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MT == 2 ? 3
 #pragma unroll
     for (int gg = 0; gg < G; gg++) {
       // ---- slice gg: staging registers -> the wave's LDS buffer (the reads of slice gg - 1 are ahead of these writes in the
-      //      wave's LDS queue), then the next slice's loads into the same registers ----
+      //      wave's LDS queue), then a later slice's loads into the same registers ----
+      constexpr int dummy = 0; (void)dummy;
+      const int b = DEPTH == 2 ? (gg & 1) : 0;
 #pragma unroll
-      for (int j = 0; j < NJ; j++) *reinterpret_cast<__attribute__((address_space(3))) f32x4*>(wr[j] & 0x1ffff) = st[j];
+      for (int j = 0; j < NJ; j++) *reinterpret_cast<__attribute__((address_space(3))) f32x4*>(wr[j] & 0x1ffff) = st[b][j];
       __builtin_amdgcn_sched_barrier(0);
-      if (gg + 1 < G) {
-        if (gg == 0) fetch(IntTag<1 % G>{}); else if (gg == 1) fetch(IntTag<2 % G>{}); else fetch(IntTag<3 % G>{});
-      } else if (more) {
-        lane_offsets(nty, ntx);
-        fetch(IntTag<0>{});
+      {
+        const int nx = gg + DEPTH;   // the slice to request: of this tile, or of the next one
+        if (nx < G) {
+          if (nx == 1) fetch(IntTag<1 % G>{}, IntTag<(1 % G) % DEPTH>{}); else if (nx == 2) fetch(IntTag<2 % G>{}, IntTag<(2 % G) % DEPTH>{}); else fetch(IntTag<3 % G>{}, IntTag<(3 % G) % DEPTH>{});
+        } else if (more) {
+          if (nx == G) lane_offsets(nty, ntx);
+          if (nx == G) fetch(IntTag<0>{}, IntTag<0>{}); else fetch(IntTag<1 % G>{}, IntTag<DEPTH - 1>{});
+        }
       }
       __builtin_amdgcn_sched_barrier(0);
       // ---- depthwise 3x3 of the slice: the MFMA pixel operand ----
@@ -354,7 +363,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MT == 2 ? 3
           for (int dx = 0; dx < 3; dx++) col[dx] = *reinterpret_cast<const f32x4*>(rd[dx] + i * RP);
 #pragma unroll
           for (int mt = 0; mt < MT; mt++) {
-            const int dy = i - mt;
+            const int dy = i - mt * SH;
             if (dy < 0 || dy > 2) continue;
 #pragma unroll
             for (int dx = 0; dx < 3; dx++) {
@@ -416,6 +425,8 @@ static int lc_wave_code(int sh, int sw, int Cp, int Npad16) {
   } else if (sh == 2 && sw == 2) {
     if (gq == 2 && nt == 3) return 6;   // 32 -> 48
     if (gq == 3 && nt == 6) return 7;   // 48 -> 96
+  } else if (sh == 2 && sw == 1) {
+    if (gq == 4 && nt == 8) return 8;   // 64 -> 128 (rec s4.0; k_lc_lds only)
   }
   return 0;
 }
@@ -423,7 +434,8 @@ bool lc_wave_supported(int K, int sh, int sw, int Cp, int C, int N, int Npad16, 
   if (K != 3 || Cp != C || N != Npad16 || lc_wave_code(sh, sw, Cp, Npad16) == 0) return false;
   if (epi.residual || epi.a_scale || epi.am_max || !epi.bias || epi.act != ACT_HSWISH) return false;
   // depthwise tail: hardswish + LAB (LearnableRepLayer at stride 1) or nothing (stride 2)
-  return sh == 1 ? (dw_act == ACT_HSWISH && dw_has_lab) : (dw_act == ACT_NONE && !dw_has_lab);
+  // depthwise tail (LearnableRepLayer: the activation is skipped when stride == 2; the rec net's (2, 1) is not 2)
+  return (sh == 2 && sw == 2) ? (dw_act == ACT_NONE && !dw_has_lab) : (dw_act == ACT_HSWISH && dw_has_lab);
 }
 
 void lc_wave(hipStream_t st, int sh, int sw, const float* x, const ImgGeom* gin, const ImgGeom* gout, int n_img, int maxHo,
@@ -435,17 +447,20 @@ void lc_wave(hipStream_t st, int sh, int sw, const float* x, const ImgGeom* gin,
   static const int mt_env = getenv("RT_LCW_MT") ? atoi(getenv("RT_LCW_MT")) : 0;
   const int code = lc_wave_code(sh, sw, Cp, Npad16);
   const int tpw = tpw_env > 0 ? tpw_env : 4;
-  if (g_lc_wave >= 3 && sh == 1) {   // LDS-staged form, 4-row tiles
-    const int mtl = mt_env == 2 ? 2 : 4;
+  if (g_lc_wave >= 3 || code == 8) {   // LDS-staged form: 4-row tiles at stride 1 (2 waves per SIMD), 2-row tiles at stride 2
+    const int mtl = (sh == 1 && mt_env != 2) ? 4 : 2;
     const int tiles = ((maxWo + 15) / 16) * ((maxHo + mtl - 1) / mtl);
     dim3 grid((tiles + 4 * tpw - 1) / (4 * tpw), n_img);
     LcwArgs a{x, gin, gout, Wd, bd, Wp, epi.bias, y, dw_a, dw_c, epi.has_lab ? epi.lab_a : 1.f, epi.has_lab ? epi.lab_c : 0.f, Npad16, ldy, tpw, 0};
-#define RT_LCL(GG, NN) do { if (mtl == 2) RT_LAUNCH((k_lc_lds<GG, NN, 2, true>), grid, dim3(256), 0, st, a); else RT_LAUNCH((k_lc_lds<GG, NN, 4, true>), grid, dim3(256), 0, st, a); } while (0)
+#define RT_LCL(GG, NN) do { if (mtl == 2) RT_LAUNCH((k_lc_lds<GG, NN, 2, 1, 1, true, 3>), grid, dim3(256), 0, st, a); else RT_LAUNCH((k_lc_lds<GG, NN, 4, 1, 1, true, 2>), grid, dim3(256), 0, st, a); } while (0)
     switch (code) {
       case 1: RT_LCL(1, 2); break;
       case 2: RT_LCL(2, 4); break;
       case 3: RT_LCL(3, 3); break;
-      default: RT_LCL(4, 4); break;
+      case 4: RT_LCL(4, 4); break;
+      case 6: RT_LAUNCH((k_lc_lds<2, 3, 2, 2, 2, false, 2>), grid, dim3(256), 0, st, a); break;
+      case 7: RT_LAUNCH((k_lc_lds<3, 6, 2, 2, 2, false, 2>), grid, dim3(256), 0, st, a); break;
+      default: RT_LAUNCH((k_lc_lds<4, 8, 2, 2, 1, true, 2>), grid, dim3(256), 0, st, a); break;
     }
 #undef RT_LCL
     return;
@@ -454,7 +469,7 @@ void lc_wave(hipStream_t st, int sh, int sw, const float* x, const ImgGeom* gin,
   const int tiles = ((maxWo + 15) / 16) * ((maxHo + mt - 1) / mt);
   dim3 grid((tiles + 4 * tpw - 1) / (4 * tpw), n_img);
   LcwArgs a{x, gin, gout, Wd, bd, Wp, epi.bias, y, dw_a, dw_c, epi.has_lab ? epi.lab_a : 1.f, epi.has_lab ? epi.lab_c : 0.f, Npad16, ldy, tpw, 0};
-#define RT_LCW_T(GG, NN, MM, SS) RT_LAUNCH((k_lc_wave<GG, NN, MM, SS, SS == 1>), grid, dim3(256), 0, st, a)
+#define RT_LCW_T(GG, NN, MM, SS) RT_LAUNCH((k_lc_wave<GG, NN, MM, SS, SS == 1>), grid, dim3(256), 0, st, a)   // (stride (s, s) only)
 #define RT_LCW(GG, NN, SS) do { if (mt == 1) RT_LCW_T(GG, NN, 1, SS); else RT_LCW_T(GG, NN, 2, SS); } while (0)
   switch (code) {
     case 1: RT_LCW(1, 2, 1); break;
