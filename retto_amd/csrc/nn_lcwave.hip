@@ -262,15 +262,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
   const int first = blockIdx.x * 4 * p.tiles_per_wave;
   if (first >= n_tiles) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), r = lane & 15, q = lane >> 4;
+  const int n0 = blockIdx.z * NCOL;   // this workgroup's block of output channels (N = gridDim.z * NCOL)
   for (int idx = tid; idx < NKC * NCOL * 8; idx += 256) {
     const int c4i = idx & 7, row = (idx >> 3) % NCOL, kc = (idx >> 3) / NCOL;
     *reinterpret_cast<f32x4*>(wt + (kc * NCOL + row) * LROW + c4i * 4) =
-        *reinterpret_cast<const f32x4*>(p.Wp + ((long long)kc * p.Npad + row) * KC + c4i * 4);
+        *reinterpret_cast<const f32x4*>(p.Wp + ((long long)kc * p.Npad + n0 + row) * KC + c4i * 4);
   }
   for (int idx = tid; idx < 10 * CP / 4; idx += 256)
     *reinterpret_cast<f32x4*>(tp + idx * 4) =
         idx < 9 * CP / 4 ? *reinterpret_cast<const f32x4*>(p.Wd + idx * 4) : *reinterpret_cast<const f32x4*>(p.bd + (idx - 9 * CP / 4) * 4);
-  for (int idx = tid; idx < NCOL / 4; idx += 256) *reinterpret_cast<f32x4*>(tp + 10 * CP + idx * 4) = *reinterpret_cast<const f32x4*>(p.bias + idx * 4);
+  for (int idx = tid; idx < NCOL / 4; idx += 256) *reinterpret_cast<f32x4*>(tp + 10 * CP + idx * 4) = *reinterpret_cast<const f32x4*>(p.bias + n0 + idx * 4);
   __syncthreads();   // the only barrier
 
   const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
@@ -312,7 +313,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
       goff[j] = ok ? (unsigned)iy * row_bytes + (unsigned)ix * (CP * 4) + (pc & 3) * 16 : OOB;
     }
     const int ox = txx * 16 + r;
-    y_off = ox < g.W ? (unsigned)ox * ((unsigned)p.ldy * 4) + q * 16 : OOB;
+    y_off = ox < g.W ? (unsigned)ox * ((unsigned)p.ldy * 4) + n0 * 4 + q * 16 : OOB;
   };
   auto fetch = [&](auto gg_tag, auto buf_tag) __attribute__((always_inline)) {   // slice GG of the tile `goff` describes
     constexpr int GG = decltype(gg_tag)::value, B = decltype(buf_tag)::value;
@@ -341,7 +342,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
       {
         const int nx = gg + DEPTH;   // the slice to request: of this tile, or of the next one
         if (nx < G) {
-          if (nx == 1) fetch(IntTag<1 % G>{}, IntTag<(1 % G) % DEPTH>{}); else if (nx == 2) fetch(IntTag<2 % G>{}, IntTag<(2 % G) % DEPTH>{}); else fetch(IntTag<3 % G>{}, IntTag<(3 % G) % DEPTH>{});
+          switch (nx) {   // (gg is a constant after unrolling: one case survives)
+            case 1: fetch(IntTag<1 % G>{}, IntTag<(1 % G) % DEPTH>{}); break;
+            case 2: fetch(IntTag<2 % G>{}, IntTag<(2 % G) % DEPTH>{}); break;
+            case 3: fetch(IntTag<3 % G>{}, IntTag<(3 % G) % DEPTH>{}); break;
+            case 4: fetch(IntTag<4 % G>{}, IntTag<(4 % G) % DEPTH>{}); break;
+            case 5: fetch(IntTag<5 % G>{}, IntTag<(5 % G) % DEPTH>{}); break;
+            case 6: fetch(IntTag<6 % G>{}, IntTag<(6 % G) % DEPTH>{}); break;
+            default: fetch(IntTag<7 % G>{}, IntTag<(7 % G) % DEPTH>{}); break;
+          }
         } else if (more) {
           if (nx == G) lane_offsets(nty, ntx);
           if (nx == G) fetch(IntTag<0>{}, IntTag<0>{}); else fetch(IntTag<1 % G>{}, IntTag<DEPTH - 1>{});
@@ -422,6 +431,9 @@ static int lc_wave_code(int sh, int sw, int Cp, int Npad16) {
     if (gq == 2 && nt == 4) return 2;   // 32 -> 64
     if (gq == 3 && nt == 3) return 3;   // 48 -> 48
     if (gq == 4 && nt == 4) return 4;   // 64 -> 64
+    // 128 -> 128 in two blocks of 64 output channels: 1.35 vs 1.56 ms on uniform images, but 1.69 vs 1.52 ms on the ragged C3
+    // batch (every block recomputes the depthwise half): opt-in (RT_LC_WAVE=5)
+    if (gq == 8 && nt == 8 && g_lc_wave == 5) return 9;
   } else if (sh == 2 && sw == 2) {
     if (gq == 2 && nt == 3) return 6;   // 32 -> 48
     if (gq == 3 && nt == 6) return 7;   // 48 -> 96
@@ -447,7 +459,7 @@ void lc_wave(hipStream_t st, int sh, int sw, const float* x, const ImgGeom* gin,
   static const int mt_env = getenv("RT_LCW_MT") ? atoi(getenv("RT_LCW_MT")) : 0;
   const int code = lc_wave_code(sh, sw, Cp, Npad16);
   const int tpw = tpw_env > 0 ? tpw_env : 4;
-  if (g_lc_wave >= 3 || code == 8) {   // LDS-staged form: 4-row tiles at stride 1 (2 waves per SIMD), 2-row tiles at stride 2
+  if (g_lc_wave >= 3 || code >= 8) {   // LDS-staged form: 4-row tiles at stride 1 (2 waves per SIMD), 2-row tiles at stride 2
     const int mtl = (sh == 1 && mt_env != 2) ? 4 : 2;
     const int tiles = ((maxWo + 15) / 16) * ((maxHo + mtl - 1) / mtl);
     dim3 grid((tiles + 4 * tpw - 1) / (4 * tpw), n_img);
@@ -460,6 +472,7 @@ void lc_wave(hipStream_t st, int sh, int sw, const float* x, const ImgGeom* gin,
       case 4: RT_LCL(4, 4); break;
       case 6: RT_LAUNCH((k_lc_lds<2, 3, 2, 2, 2, false, 2>), grid, dim3(256), 0, st, a); break;
       case 7: RT_LAUNCH((k_lc_lds<3, 6, 2, 2, 2, false, 2>), grid, dim3(256), 0, st, a); break;
+      case 9: grid.z = 2; RT_LAUNCH((k_lc_lds<8, 4, 4, 1, 1, true, 2>), grid, dim3(256), 0, st, a); break;
       default: RT_LAUNCH((k_lc_lds<4, 8, 2, 2, 1, true, 2>), grid, dim3(256), 0, st, a); break;
     }
 #undef RT_LCL
