@@ -1,23 +1,36 @@
-// Fused thin LCNetV3 block, one wave per tile, no LDS staging of activations (gfx950).
+// Fused thin LCNetV3 blocks, one wave per tile, no barrier after the weights are staged (gfx950).
 //
-//   y = epi_pw( W_pw . lab(act(dw3x3(x) + b_dw)) )        C_in = 16 G <= 64, N = 16 NT <= 128, stride (1,1) or (2,2)
+//   y = epi_pw( W_pw . lab(act(dw3x3(x) + b_dw)) )        C_in = 16 G, N = 16 NT
 //
 // k_lc_thin (nn_kernels.hip) stages an input patch and the depthwise result through LDS with two barriers per tile; at
-// 2 workgroups per CU the phases (loads, depthwise VALU, MFMA, stores) of a tile run one after the other and the layer sits
-// at 0.3 of HBM.  Here a wave owns a 16-pixel-wide, MT-row-high output tile and never meets a barrier after the weights are
-// staged:
+// 2 workgroups per CU the phases (loads, depthwise VALU, MFMA, stores) of a tile run one after the other and the layers sit
+// at 0.3 of HBM.  Two forms that drop the barriers, both bit-identical to k_lc_thin and to k_dwconv_rows + k_gemm (arithmetic
+// order per output: bias, then taps (dy, dx) ascending with fmaf; k ascending in the MFMA chain):
+//
+// k_lc_lds (production, strides (1,1), (2,2), (2,1)): a wave stages the 16-channel slice of its input patch through its own LDS
+// buffer -- see the comment at the kernel.
+//
+// k_lc_wave (stride 1, kept as the A/B form RT_LC_WAVE=1): no LDS for activations at all.
 //   * the MFMA pixel operand of v_mfma_f32_16x16x4_f32 wants lane (r = lane & 15, q = lane >> 4) to hold channels
 //     16 g + 4 q .. + 3 of pixel r for the 16-deep k group g (nn_kernels.hip, mma_chunk).  That is one f32x4 of an NHWC
-//     pixel: the lane loads it straight from global memory, for the MT + 2 (stride 2: 2 MT + 1) input rows of the tile;
+//     pixel: the lane loads it straight from global memory, for the MT + 2 input rows of the tile;
 //   * the horizontal taps are the neighbouring lanes' registers: DPP row_shr:1 / row_shl:1 move them inside the 16-lane row
 //     (= the same q), and the two lanes at the row ends keep the `old` operand, which a sparse load (lanes r = 0 and 15
-//     only) has filled with the halo pixel.  Stride 2: lanes load the even and the odd column, the left tap is the odd
-//     column of lane r - 1;
+//     only, by exec mask) has filled with the halo pixel;
 //   * the depthwise result of group g is the MFMA operand as it stands; the weights' fragments come from LDS (staged once
 //     per workgroup), the 9 taps of the lane's channel group too (4 distinct addresses per wave: broadcast reads);
 //   * the loads of group g + 1 are issued before the MFMAs of group g.
-// Arithmetic order per output: bias, then taps (dy, dx) ascending with fmaf; k ascending in the MFMA chain -- the order of
-// k_dwconv_rows + k_gemm and of k_lc_thin: bit-identical to both.
+//   It lost to k_lc_lds on every shape: 16 different pixels in the 16 lanes of a row make the texture addresser walk 64
+//   separate 16-byte pieces per load / store (TA_BUSY 0.72).
+//
+// What the measurements behind these kernels showed (tools/scratch/*.hip):
+//   * the VALU does not run under an executing fp32 MFMA, not even from another wave of the SIMD (64 MFMAs + 128 v_fma take
+//     the sum of both): every VALU op of the epilogues and of the depthwise half is paid in MFMA time -- hence packed
+//     v_pk_fma / v_pk_mul / v_pk_add, v_med3 for the clamp, buffer addressing with scalar offsets, no predicates;
+//   * __builtin_bit_cast on an ELEMENT of an ext_vector miscompiles with this hipcc (all four lanes became element 0);
+//   * buffer_store_dwordx4 with an SGPR soffset: hipcc's hazard recognizer assumes no store-data hazard and lets the next VALU
+//     op overwrite the data registers; on gfx950 dword 1 of lanes 12-15 of each 16-lane row was stored corrupted.  The stores
+//     here keep soffset = 0.
 #include <mutex>
 
 #include "common.h"
@@ -65,11 +78,11 @@ struct LcwArgs {   // (compact: the kernel keeps its scalars in SGPRs; a spilled
 
 // DWA: the depthwise half ends in hardswish + LAB (stride 1) or in nothing (stride 2).  The pointwise half always ends in
 // hardswish + LAB (a block without LAB passes a = 1, c = 0).  C_in = 16 G and N = 16 NT exactly: no channel masks.
-template <int G, int NT, int MT, int S, bool DWA>
+template <int G, int NT, int MT, bool DWA>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_lc_wave(LcwArgs p) {
   constexpr int CP = G * 16, NKC = (CP + KC - 1) / KC, NCOL = NT * 16;
-  constexpr int IR = (MT - 1) * S + 3;   // input rows of a tile
-  constexpr int NV = S == 1 ? 2 : 3;     // registers per row: {centre, halo} or {even, odd, left halo}
+  constexpr int IR = MT + 2;   // input rows of a tile (stride 1)
+  constexpr int NV = 2;        // registers per row: {centre, halo}
   __shared__ __attribute__((aligned(16))) float wt[NKC * NCOL * LROW];
   __shared__ __attribute__((aligned(16))) float tp[10 * CP + NCOL];  // 9 taps + depthwise bias, [t][CP]; pointwise bias [NCOL]
   const ImgGeom g = p.gout[blockIdx.y], gi = p.gin[blockIdx.y];
@@ -106,25 +119,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
   f32x4 in[IR][NV];
   unsigned c_off, h_off, y_off;
   auto lane_offsets = [&](int txx) __attribute__((always_inline)) {
-    const int ox = txx * 16 + r, ix = S == 1 ? ox : 2 * ox;
-    const int hx = S == 1 ? (r == 0 ? ox - 1 : ox + 1) : ix - 1;
-    const bool h_ok = (S == 1 ? (r == 0 || r == 15) : r == 0) && (unsigned)hx < (unsigned)gi.W;
+    const int ox = txx * 16 + r, ix = ox;
+    const int hx = r == 0 ? ox - 1 : ox + 1;
+    const bool h_ok = (r == 0 || r == 15) && (unsigned)hx < (unsigned)gi.W;
     c_off = ix < gi.W ? (unsigned)ix * (CP * 4) + q * 16 : OOB;
     h_off = h_ok ? (unsigned)hx * (CP * 4) + q * 16 : OOB;
     y_off = ox < g.W ? (unsigned)ox * ((unsigned)p.ldy * 4) + q * 16 : OOB;
   };
   // requests channel group GG of the tile in tile row tyy (lane offsets of its tile column are current)
-  const bool edge_lane = S == 1 ? (r == 0 || r == 15) : r == 0;
+  const bool edge_lane = r == 0 || r == 15;
   auto fetch = [&](int tyy, auto gg_tag) __attribute__((always_inline)) {
     constexpr int GG = decltype(gg_tag)::value;
 #pragma unroll
     for (int i = 0; i < IR; i++) {
-      const int iy = tyy * (MT * S) - 1 + i;
+      const int iy = tyy * MT - 1 + i;
       if ((unsigned)iy < (unsigned)gi.H) {   // (uniform)
         const unsigned so = (unsigned)iy * row_bytes + GG * 64;
         in[i][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, c_off, so, 0));
-        // (S == 2: the odd column is the next pixel; past the row end it must read zero: its own offset)
-        if (S == 2) in[i][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, c_off == OOB ? OOB : c_off + CP * 4, so, 0));
       } else {
 #pragma unroll
         for (int v = 0; v < NV - 1; v++) in[i][v] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -135,7 +146,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     if (edge_lane) {
 #pragma unroll
       for (int i = 0; i < IR; i++) {
-        const int iy = tyy * (MT * S) - 1 + i;
+        const int iy = tyy * MT - 1 + i;
         if ((unsigned)iy < (unsigned)gi.H) in[i][NV - 1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, h_off, (unsigned)iy * row_bytes + GG * 64, 0));
         else in[i][NV - 1] = f32x4{0.f, 0.f, 0.f, 0.f};
       }
@@ -164,20 +175,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 #pragma unroll
         for (int i = 0; i < IR; i++) {
           f32x4 col[3];
-          if (S == 1) {
-            col[0] = dpp_row<DPP_ROW_SHR1>(in[i][1], in[i][0]);
-            col[1] = in[i][0];
-            col[2] = dpp_row<DPP_ROW_SHL1>(in[i][1], in[i][0]);
-          } else {
-            col[0] = dpp_row<DPP_ROW_SHR1>(in[i][NV - 1], in[i][1]);
-            col[1] = in[i][0];
-            col[2] = in[i][1];
-          }
-          // input row i is tap row dy = i - mt * S of output row mt; rows arrive in ascending i, i.e. ascending dy for
+          col[0] = dpp_row<DPP_ROW_SHR1>(in[i][1], in[i][0]);
+          col[1] = in[i][0];
+          col[2] = dpp_row<DPP_ROW_SHL1>(in[i][1], in[i][0]);
+          // input row i is tap row dy = i - mt of output row mt; rows arrive in ascending i, i.e. ascending dy for
           // every mt: per output the order stays (dy, dx) ascending
 #pragma unroll
           for (int mt = 0; mt < MT; mt++) {
-            const int dy = i - mt * S;
+            const int dy = i - mt;
             if (dy < 0 || dy > 2) continue;
 #pragma unroll
             for (int dx = 0; dx < 3; dx++) {
@@ -459,7 +464,8 @@ void lc_wave(hipStream_t st, int sh, int sw, const float* x, const ImgGeom* gin,
   static const int mt_env = getenv("RT_LCW_MT") ? atoi(getenv("RT_LCW_MT")) : 0;
   const int code = lc_wave_code(sh, sw, Cp, Npad16);
   const int tpw = tpw_env > 0 ? tpw_env : 4;
-  if (g_lc_wave >= 3 || code >= 8) {   // LDS-staged form: 4-row tiles at stride 1 (2 waves per SIMD), 2-row tiles at stride 2
+  if (g_lc_wave >= 3 || code >= 6) {   // (the direct-load form below is kept for the stride-1 blocks only: A/B, RT_LC_WAVE=1)
+    // LDS-staged form: 4-row tiles at stride 1 (2 waves per SIMD), 2-row tiles at stride 2
     const int mtl = (sh == 1 && mt_env != 2) ? 4 : 2;
     const int tiles = ((maxWo + 15) / 16) * ((maxHo + mtl - 1) / mtl);
     dim3 grid((tiles + 4 * tpw - 1) / (4 * tpw), n_img);
@@ -482,15 +488,13 @@ void lc_wave(hipStream_t st, int sh, int sw, const float* x, const ImgGeom* gin,
   const int tiles = ((maxWo + 15) / 16) * ((maxHo + mt - 1) / mt);
   dim3 grid((tiles + 4 * tpw - 1) / (4 * tpw), n_img);
   LcwArgs a{x, gin, gout, Wd, bd, Wp, epi.bias, y, dw_a, dw_c, epi.has_lab ? epi.lab_a : 1.f, epi.has_lab ? epi.lab_c : 0.f, Npad16, ldy, tpw, 0};
-#define RT_LCW_T(GG, NN, MM, SS) RT_LAUNCH((k_lc_wave<GG, NN, MM, SS, SS == 1>), grid, dim3(256), 0, st, a)   // (stride (s, s) only)
+#define RT_LCW_T(GG, NN, MM, SS) RT_LAUNCH((k_lc_wave<GG, NN, MM, true>), grid, dim3(256), 0, st, a)
 #define RT_LCW(GG, NN, SS) do { if (mt == 1) RT_LCW_T(GG, NN, 1, SS); else RT_LCW_T(GG, NN, 2, SS); } while (0)
   switch (code) {
     case 1: RT_LCW(1, 2, 1); break;
     case 2: RT_LCW(2, 4, 1); break;
     case 3: RT_LCW(3, 3, 1); break;
     case 4: RT_LCW(4, 4, 1); break;
-    case 6: RT_LCW(2, 3, 2); break;
-    case 7: RT_LCW(3, 6, 2); break;
     default: throw RtError(8, "lc_wave: unsupported shape (check lc_wave_supported)");
   }
 #undef RT_LCW

@@ -667,3 +667,28 @@ def test_det_postprocess_border_hugging_contours(hip_session, seed):
     rb, rs = R.det_postprocess(m, H, W)
     assert len(gb) == len(rb) >= 2
     assert np.array_equal(gb, rb) and np.array_equal(gs.view(np.uint32), rs.view(np.uint32))
+
+
+# ---------------------------------------------------------------- fused thin LCNetV3 blocks: the three kernel forms
+# rt_bench_lc runs one block (3x3 depthwise -> 1x1 conv, random weights, the LCNetV3 tails) through k_lc_thin (or, where that
+# kernel has no instance, the unfused depthwise + GEMM pair) and through the barrier-free forms of nn_lcwave.hip (1 = direct
+# loads + DPP taps, 3 = wave-private LDS staging, the production form) and returns max |difference|: the forms share the
+# arithmetic order, so the bar is bit-identity -- on ragged sizes too (widths that are no multiple of the 16-pixel tile, heights
+# that are no multiple of the 2- / 4-row tile, single-pixel and single-row images, images narrower than one tile).
+_LC_BLOCKS = [(16, 32, 1), (32, 64, 1), (48, 48, 1), (64, 64, 1), (32, 48, 2), (48, 96, 2), (64, 128, 21)]
+_LC_SIZES = [(3, 13, 37), (2, 5, 16), (4, 1, 1), (2, 24, 17), (1, 50, 100), (5, 1, 33), (2, 7, 2)]
+
+
+@pytest.mark.parametrize("cin,cout,stride", _LC_BLOCKS)
+@pytest.mark.parametrize("form", [1, 3])
+def test_thin_block_kernel_forms_are_bit_identical(hip_session, cin, cout, stride, form):
+    import ctypes as C
+    if form == 1 and stride != 1:
+        pytest.skip("the direct-load form is kept for the stride-1 blocks only")
+    lib, h = hip_session._hd.lib, hip_session._hd.h
+    lib.rt_bench_lc.argtypes = [C.c_void_p] + [C.c_int] * 8 + [C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    for n, hh, ww in _LC_SIZES:
+        ms, md = C.c_float(), C.c_float(-1.0)
+        rc = lib.rt_bench_lc(h, n, hh, ww, cin, cout, stride, form, 1, C.byref(ms), C.byref(md))
+        assert rc == 0, lib.rt_last_error(h)
+        assert md.value == 0.0, f"{cin}->{cout} /{stride} form {form} on {n} x {hh} x {ww}: max |diff| {md.value}"
