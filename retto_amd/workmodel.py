@@ -38,15 +38,17 @@ def gemm_pw_label(M: int, N: int, se: bool = False) -> str:
 
 
 def lc_thin_fused(k: int, sh: int, sw: int, cin: int, cout: int, se: bool) -> bool:
-    """Mirror of nn::lc_thin_supported: thin stride-1 3x3 blocks run as ONE kernel (k_lc_thin), whose algorithmic
-    traffic is the block's input + output (the depthwise result never reaches HBM)."""
-    if se or k != 3 or cin % 4:
+    """Mirror of nn::lc_block_supported: thin 3x3 blocks run as ONE kernel (k_lc_lds, nn_lcwave.hip; k_lc_thin with
+    RT_LC_WAVE=0), whose algorithmic traffic is the block's input + output (the depthwise result never reaches HBM)."""
+    if se or k != 3 or cin % 16 or cout % 16:
         return False
-    c4, nt = cin // 4, ((cout + 15) // 16 * 16 + 31) // 32
+    g, nt = cin // 16, cout // 16
     if (sh, sw) == (1, 1):
-        return (c4, nt) in ((4, 1), (8, 2), (12, 2), (16, 2))
+        return (g, nt) in ((1, 2), (2, 4), (3, 3), (4, 4))
     if (sh, sw) == (2, 2):
-        return (c4, nt) in ((8, 2), (12, 3))
+        return (g, nt) in ((2, 3), (3, 6))
+    if (sh, sw) == (2, 1):   # the rec net's 64 -> 128 block: k_lc_lds only
+        return (g, nt) == (4, 8) and os.environ.get("RT_LC_WAVE", "3") != "0"
     return False
 
 
