@@ -31,8 +31,6 @@
 //   * buffer_store_dwordx4 with an SGPR soffset: hipcc's hazard recognizer assumes no store-data hazard and lets the next VALU
 //     op overwrite the data registers; on gfx950 dword 1 of lanes 12-15 of each 16-lane row was stored corrupted.  The stores
 //     here keep soffset = 0.
-#include <mutex>
-
 #include "common.h"
 #include "nn_dev.h"
 
@@ -73,7 +71,7 @@ struct LcwArgs {   // (compact: the kernel keeps its scalars in SGPRs; a spilled
   const float* x; const ImgGeom* gin; const ImgGeom* gout;
   const float* Wd; const float* bd; const float* Wp; const float* bias; float* y;
   float dw_a, dw_c, pw_a, pw_c;
-  int Npad, ldy, tiles_per_wave, flags;
+  int Npad, ldy, tiles_per_wave;
 };
 
 // DWA: the depthwise half ends in hardswish + LAB (stride 1) or in nothing (stride 2).  The pointwise half always ends in
@@ -339,7 +337,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
     for (int gg = 0; gg < G; gg++) {
       // ---- slice gg: staging registers -> the wave's LDS buffer (the reads of slice gg - 1 are ahead of these writes in the
       //      wave's LDS queue), then a later slice's loads into the same registers ----
-      constexpr int dummy = 0; (void)dummy;
       const int b = DEPTH == 2 ? (gg & 1) : 0;
 #pragma unroll
       for (int j = 0; j < NJ; j++) *reinterpret_cast<__attribute__((address_space(3))) f32x4*>(wr[j] & 0x1ffff) = st[b][j];
@@ -469,7 +466,7 @@ void lc_wave(hipStream_t st, int sh, int sw, const float* x, const ImgGeom* gin,
     const int mtl = (sh == 1 && mt_env != 2) ? 4 : 2;
     const int tiles = ((maxWo + 15) / 16) * ((maxHo + mtl - 1) / mtl);
     dim3 grid((tiles + 4 * tpw - 1) / (4 * tpw), n_img);
-    LcwArgs a{x, gin, gout, Wd, bd, Wp, epi.bias, y, dw_a, dw_c, epi.has_lab ? epi.lab_a : 1.f, epi.has_lab ? epi.lab_c : 0.f, Npad16, ldy, tpw, 0};
+    LcwArgs a{x, gin, gout, Wd, bd, Wp, epi.bias, y, dw_a, dw_c, epi.has_lab ? epi.lab_a : 1.f, epi.has_lab ? epi.lab_c : 0.f, Npad16, ldy, tpw};
 #define RT_LCL(GG, NN) do { if (mtl == 2) RT_LAUNCH((k_lc_lds<GG, NN, 2, 1, 1, true, 3>), grid, dim3(256), 0, st, a); else RT_LAUNCH((k_lc_lds<GG, NN, 4, 1, 1, true, 2>), grid, dim3(256), 0, st, a); } while (0)
     switch (code) {
       case 1: RT_LCL(1, 2); break;
@@ -487,7 +484,7 @@ void lc_wave(hipStream_t st, int sh, int sw, const float* x, const ImgGeom* gin,
   const int mt = mt_env == 1 ? 1 : 2;
   const int tiles = ((maxWo + 15) / 16) * ((maxHo + mt - 1) / mt);
   dim3 grid((tiles + 4 * tpw - 1) / (4 * tpw), n_img);
-  LcwArgs a{x, gin, gout, Wd, bd, Wp, epi.bias, y, dw_a, dw_c, epi.has_lab ? epi.lab_a : 1.f, epi.has_lab ? epi.lab_c : 0.f, Npad16, ldy, tpw, 0};
+  LcwArgs a{x, gin, gout, Wd, bd, Wp, epi.bias, y, dw_a, dw_c, epi.has_lab ? epi.lab_a : 1.f, epi.has_lab ? epi.lab_c : 0.f, Npad16, ldy, tpw};
 #define RT_LCW_T(GG, NN, MM, SS) RT_LAUNCH((k_lc_wave<GG, NN, MM, true>), grid, dim3(256), 0, st, a)
 #define RT_LCW(GG, NN, SS) do { if (mt == 1) RT_LCW_T(GG, NN, 1, SS); else RT_LCW_T(GG, NN, 2, SS); } while (0)
   switch (code) {
