@@ -228,7 +228,8 @@ static const float HSIG_MBV3 = 0.2f;         // F.hardsigmoid(slope=0.2, offset=
 
 static float* run_lc(RunCtx& c, const LcBlock& b, const float* x, const Level& Lin, const Level& Lout) {
   if (!b.se && b.pw.K == b.dw.Cp &&
-      nn::lc_block_supported(b.dw.k, b.sh, b.sw, b.dw.Cp, b.dw.C, b.pw.N, b.pw.Npad, b.dw_act, b.dw_lab.has, make_epi(b.pw, ACT_HSWISH, &b.pw_lab))) {
+      nn::lc_block_supported(b.dw.k, b.sh, b.sw, b.dw.Cp, b.dw.C, b.pw.N, b.pw.Npad, b.dw_act, b.dw_lab.has, make_epi(b.pw, ACT_HSWISH, &b.pw_lab),
+                             Lout.maxH, Lout.maxW)) {
     int Cpo = chan_pitch(b.cout);
     float* y2 = c.arena->alloc<float>((size_t)Lout.total * Cpo);
     ProfScope ps(c.prof, c.st, "lc_thin", shape_str(Lout.total, b.dw.Cp, b.pw.N, b.sh * 10 + b.sw));

@@ -64,7 +64,8 @@ void lc_thin(hipStream_t st, int sh, int sw, const float* x, const ImgGeom* gin,
 // one-wave-per-tile form of the same block (nn_lcwave.hip): activations never touch LDS; bit-identical to lc_thin
 extern int g_lc_wave;
 // either form has an instance for the block (what run_lc asks before it takes the fused path)
-bool lc_block_supported(int K, int sh, int sw, int Cp, int C, int N, int Npad16, int dw_act, int dw_has_lab, const Epilogue& epi);
+bool lc_block_supported(int K, int sh, int sw, int Cp, int C, int N, int Npad16, int dw_act, int dw_has_lab, const Epilogue& epi,
+                        int maxHo, int maxWo);
 bool lc_wave_supported(int K, int sh, int sw, int Cp, int C, int N, int Npad16, int dw_act, int dw_has_lab, const Epilogue& epi);
 void lc_wave(hipStream_t st, int sh, int sw, const float* x, const ImgGeom* gin, const ImgGeom* gout, int n_img, int maxHo,
              int maxWo, int Cp, int C, const float* Wd, const float* bd, int dw_act, int dw_has_lab, float dw_a, float dw_c,

@@ -658,16 +658,23 @@ static int lc_thin_code(int sh, int sw, int Cp, int Npad16) {  // instantiated (
 bool lc_thin_supported(int K, int sh, int sw, int Cp, int C, int Npad16) {
   return g_lc_thin && K == 3 && Cp == round_up(C, 4) && lc_thin_code(sh, sw, Cp, Npad16) != 0;
 }
-bool lc_block_supported(int K, int sh, int sw, int Cp, int C, int N, int Npad16, int dw_act, int dw_has_lab, const Epilogue& epi) {
+// (k_lc_lds / k_lc_wave address an image through a 32-bit buffer offset, out-of-range marker 0x80000000: images up to 1 GB)
+static bool lc_wave_fits(int maxHo, int maxWo, int sh, int sw, int Cp, int ldy) {
+  const long long in_bytes = (long long)(maxHo * sh + 2) * (maxWo * sw + 2) * Cp * 4, out_bytes = (long long)maxHo * maxWo * ldy * 4;
+  return in_bytes < (1ll << 30) && out_bytes < (1ll << 30);
+}
+bool lc_block_supported(int K, int sh, int sw, int Cp, int C, int N, int Npad16, int dw_act, int dw_has_lab, const Epilogue& epi,
+                        int maxHo, int maxWo) {
   if (lc_thin_supported(K, sh, sw, Cp, C, Npad16)) return true;
-  return g_lc_wave && g_lc_thin == 4 && lc_wave_supported(K, sh, sw, Cp, C, N, Npad16, dw_act, dw_has_lab, epi);
+  return g_lc_wave && g_lc_thin == 4 && lc_wave_supported(K, sh, sw, Cp, C, N, Npad16, dw_act, dw_has_lab, epi) &&
+         lc_wave_fits(maxHo, maxWo, sh, sw, Cp, chan_pitch(N));
 }
 void lc_thin(hipStream_t st, int sh, int sw, const float* x, const ImgGeom* gin, const ImgGeom* gout, int n_img, int maxHo,
              int maxWo, int Cp, int C, const float* Wd, const float* bd, int dw_act, int dw_has_lab, float dw_a, float dw_c,
              const float* Wp, int N, int Npad16, float* y, int ldy, const Epilogue& epi) {
   if (n_img <= 0) return;
   if (epi.residual || epi.a_scale) throw RtError(8, "lc_thin: residual / a_scale epilogues are not supported");
-  if (g_lc_wave && g_lc_thin == 4 && lc_wave_supported(3, sh, sw, Cp, C, N, Npad16, dw_act, dw_has_lab, epi)) {
+  if (g_lc_wave && g_lc_thin == 4 && lc_wave_supported(3, sh, sw, Cp, C, N, Npad16, dw_act, dw_has_lab, epi) && lc_wave_fits(maxHo, maxWo, sh, sw, Cp, ldy)) {
     lc_wave(st, sh, sw, x, gin, gout, n_img, maxHo, maxWo, Cp, C, Wd, bd, dw_act, dw_has_lab, dw_a, dw_c, Wp, N, Npad16, y, ldy, epi);
     return;
   }
