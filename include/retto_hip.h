@@ -258,8 +258,12 @@ RT_API int rt_broadcast_blobs(const void* id, int rank, int world, int device_id
  * 128x128 / 128x240 / 256x240 wide tiles / the streaming kernel; dw_variant 0 = production,
  * 4 = 2-row depthwise strips; flags bits: 1 fused thin blocks OFF, 2 thin blocks on the
  * 128-pixel tile, 3 plain (not XCD-aware) depthwise block order, 4 32-channel depthwise slabs
- * only, 5 128- instead of 64-channel wide slabs, 6 CTC head on the 128x128 wide tile.
- * Process-wide; every setting computes bit-identical results. */
+ * only, 5 128- instead of 64-channel wide slabs, 6 CTC head on the 128x128 wide tile, 7 thin
+ * LCNetV3 blocks back on k_lc_thin / the unfused pair (instead of k_lc_lds), 8 the wide fp32 GEMM
+ * back on the register-staged tile (instead of k_gemm32p), 9 5x5 depthwise back on
+ * k_dwconv_rows (instead of the column sweep).
+ * Process-wide; every setting computes bit-identical results (tests/test_gpu_parity.py checks
+ * bits 7-9 on whole networks). */
 RT_API void rt_debug_set_variants(int gemm_variant, int dw_variant, int flags);
 /* one launch of the fp16 implicit-GEMM conv kernel on host tensors: x [n, cin, h, w], wt [cout, cin, kh, kw], bias [cout] or
  * NULL, "same" padding k/2, stride (sh, sw), act = 0 none / 1 relu / 2 hardswish / 3 swish / 4 sigmoid -> out [n, cout, ho, wo] */

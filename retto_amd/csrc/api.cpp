@@ -378,6 +378,11 @@ RT_API void rt_debug_set_variants(int gemm_variant, int dw_variant, int flags) {
   nn::g_dw_wide3_min = (flags & 16) ? (1 << 30) : 128;
   nn::g_dw_wide_lp = (flags & 32) ? 32 : 16;
   nn::g_argmax_wide = (flags & 64) ? 2 : 0;
+  // round-3 kernels: bits 7-9 send their layers back to the kernels they replaced (defaults = what the environment selected at load)
+  static const int lc_wave0 = nn::g_lc_wave, gemm_dma0 = nn::g_gemm_dma, dw_sweep0 = nn::g_dw_sweep;
+  nn::g_lc_wave = (flags & 128) ? 0 : lc_wave0;
+  nn::g_gemm_dma = (flags & 256) ? 0 : gemm_dma0;
+  nn::g_dw_sweep = (flags & 512) ? 0 : dw_sweep0;
 }
 // Runs one nh::conv16 launch on host tensors (diagnostics: the numerics tests compare it with torch conv2d).
 // x [n, cin, h, w] f32, w [cout, cin, kh, kw] f32, bias [cout] or null, "same" padding k/2, stride (sh, sw); out [n, cout, ho, wo] f32.

@@ -23,6 +23,7 @@ extern int g_dw_wide_slab_min, g_dw_wide3_min, g_dw_wide_lp;
 extern int g_dw_variant;    // same for dwconv
 extern int g_gemm_variant;  // kernel micro-benchmark hook (0 = production dispatch)
 extern int g_gemm_dma;      // A/B: persistent LDS-DMA wide GEMM on (default) / off
+extern int g_dw_sweep;      // A/B: column-sweep 5x5 depthwise kernel: pixels per thread (0: off)
 
 // Dense stride-1 "same" convolution, kernel (KH,KW) in {(3,3),(1,3)}; W packed as
 // [ceil(Cin/KC)][KH*KW][Npad16][KC].

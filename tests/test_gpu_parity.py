@@ -692,3 +692,25 @@ def test_thin_block_kernel_forms_are_bit_identical(hip_session, cin, cout, strid
         rc = lib.rt_bench_lc(h, n, hh, ww, cin, cout, stride, form, 1, C.byref(ms), C.byref(md))
         assert rc == 0, lib.rt_last_error(h)
         assert md.value == 0.0, f"{cin}->{cout} /{stride} form {form} on {n} x {hh} x {ww}: max |diff| {md.value}"
+
+
+@pytest.mark.parametrize("flags", [128, 256, 512, 128 | 256 | 512])
+def test_round3_kernels_are_bit_identical_to_the_ones_they_replaced(hip_session, flags):
+    """k_lc_lds (fused thin blocks, incl. the newly fused (2,1) block), k_gemm32p (+se) and the column-sweep depthwise kernel
+    against k_lc_thin / the unfused pair, the register-staged wide GEMM tiles and k_dwconv_rows: whole networks, same process,
+    switched by rt_debug_set_variants bits 7-9.  Sizes large enough for the wide-GEMM and squeeze-excite dispatch thresholds."""
+    lib = hip_session._hd.lib
+    rng = np.random.default_rng(flags)
+    xd = rng.uniform(-1, 1, (2, 3, 416, 352)).astype(np.float32)
+    xr = rng.uniform(-1, 1, (420, 3, 48, 400)).astype(np.float32)   # 420 x 12 x 100 = 504000 rows at the 240-channel stages
+    for i in range(xr.shape[0]):
+        xr[i, :, :, 180 + (37 * i) % 220:] = 0
+    xc = rng.uniform(-1, 1, (9, 3, 48, 192)).astype(np.float32)
+    try:
+        lib.rt_debug_set_variants(0, 0, flags)
+        old = [hip_session.worker.det(xd), hip_session.worker.rec(xr), hip_session.worker.cls(xc)]
+    finally:
+        lib.rt_debug_set_variants(0, 0, 0)
+    new = [hip_session.worker.det(xd), hip_session.worker.rec(xr), hip_session.worker.cls(xc)]
+    for name, a, b in zip(("det", "rec", "cls"), old, new):
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), f"{name}: max |diff| {np.abs(a.astype(np.float64) - b).max()}"
