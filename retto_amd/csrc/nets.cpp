@@ -582,6 +582,18 @@ float* ClsNet::run(RunCtx& c, const float* x, Level& L0) {
   for (size_t i = 0; i < blocks_.size(); i++) {
     const B& b = blocks_[i];
     const Level &Lin = lv[i], &Lout = lv[i + 1];
+    if (nn::g_cls_fused && nn::cls_block_supported(b.dw.k, b.sh, b.sw, cin, b.dw.C, b.linear.N, b.act, Lin.maxH, Lin.maxW, (int)Lout.maxPix)) {
+      // the whole block in one launch, a workgroup per crop (nn_clsblock.hip)
+      const int co = b.linear.N;
+      float* y = c.arena->alloc<float>((size_t)Lout.total * co);
+      float* dscr = b.se ? c.arena->alloc<float>((size_t)Lout.total * round_up(b.dw.C, 16)) : nullptr;
+      ProfScope ps(c.prof, c.st, "cls_block", shape_str(Lin.total, b.dw.C, co, b.dw.k * 100 + b.sh * 10 + (b.se ? 1 : 0)));
+      nn::cls_block(c.st, b.dw.k, b.sh, b.se, b.act, t, Lin.d, Lout.d, Lout.n(), Lin.maxH, Lin.maxW, (int)Lout.maxPix, cin, b.dw.C, b.dw.Cp, co, b.expand.w,
+                    b.expand.b, b.dw.w, b.dw.b, b.se ? b.sew.w1 : nullptr, b.se ? b.sew.b1 : nullptr, b.se ? b.sew.w2 : nullptr,
+                    b.se ? b.sew.b2 : nullptr, b.se ? b.sew.Cr : 0, HSIG_MBV3, b.linear.w, b.linear.b, b.shortcut, y, dscr);
+      t = y; cin = co;
+      continue;
+    }
     int mid = b.dw.Cp;
     float* e = c.arena->alloc<float>((size_t)Lin.total * mid);
     { ProfScope ps(c.prof, c.st, "gemm_cls");

@@ -56,6 +56,14 @@ int gemm_argmax_tiles(int Npad16);
 void argmax_merge(hipStream_t st, const float* pm, const int* pi, const float* ps, int tiles, long long rows, int* idx,
                   float* prob);
 
+// One MobileNetV3 block of the angle classifier (expand 1x1 -> depthwise k x k -> squeeze-excite -> linear 1x1 [+ x]) as one
+// kernel, a workgroup per crop (nn_clsblock.hip).  Weights in the PackedDense / PackedDw layouts of nets.cpp.
+extern int g_cls_fused;
+bool cls_block_supported(int k, int sh, int sw, int cin, int mid, int cout, int act, int maxH_in, int maxW, int max_pix_out);
+void cls_block(hipStream_t st, int k, int sh, bool se, int act, const float* x, const ImgGeom* gin, const ImgGeom* gout, int n_img,
+               int maxH_in, int maxW, int max_pix_out, int cin, int mid, int mid_cp, int cout, const float* Wexp, const float* bexp,
+               const float* Wdw, const float* bdw, const float* w1, const float* b1, const float* w2, const float* b2, int cr, float slope,
+               const float* Wlin, const float* blin, bool shortcut, float* y, float* dscr);   // dscr: n_pixels_out x round_up(mid, 16) floats when se
 // Fused thin LCNetV3 block (3x3 depthwise -> 1x1 conv, C_in <= 64, no SE): see k_lc_thin.
 extern int g_lc_thin;
 bool lc_thin_supported(int K, int sh, int sw, int Cp, int C, int Npad16);
