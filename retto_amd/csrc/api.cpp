@@ -379,10 +379,11 @@ RT_API void rt_debug_set_variants(int gemm_variant, int dw_variant, int flags) {
   nn::g_dw_wide_lp = (flags & 32) ? 32 : 16;
   nn::g_argmax_wide = (flags & 64) ? 2 : 0;
   // round-3 kernels: bits 7-9 send their layers back to the kernels they replaced (defaults = what the environment selected at load)
-  static const int lc_wave0 = nn::g_lc_wave, gemm_dma0 = nn::g_gemm_dma, dw_sweep0 = nn::g_dw_sweep;
+  static const int lc_wave0 = nn::g_lc_wave, gemm_dma0 = nn::g_gemm_dma, dw_sweep0 = nn::g_dw_sweep, cls_fused0 = nn::g_cls_fused;
   nn::g_lc_wave = (flags & 128) ? 0 : lc_wave0;
   nn::g_gemm_dma = (flags & 256) ? 0 : gemm_dma0;
   nn::g_dw_sweep = (flags & 512) ? 0 : dw_sweep0;
+  nn::g_cls_fused = (flags & 1024) ? 0 : cls_fused0;   // (bit 10: the classifier's blocks as the unfused launch series; fp32-tolerance equal, not bit-identical)
 }
 // Runs one nh::conv16 launch on host tensors (diagnostics: the numerics tests compare it with torch conv2d).
 // x [n, cin, h, w] f32, w [cout, cin, kh, kw] f32, bias [cout] or null, "same" padding k/2, stride (sh, sw); out [n, cout, ho, wo] f32.

@@ -714,3 +714,21 @@ def test_round3_kernels_are_bit_identical_to_the_ones_they_replaced(hip_session,
     new = [hip_session.worker.det(xd), hip_session.worker.rec(xr), hip_session.worker.cls(xc)]
     for name, a, b in zip(("det", "rec", "cls"), old, new):
         assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), f"{name}: max |diff| {np.abs(a.astype(np.float64) - b).max()}"
+
+
+@pytest.mark.parametrize("n", [1, 9, 700])
+def test_fused_classifier_blocks_against_the_launch_series(hip_session, n):
+    """k_cls_block (one kernel per MobileNetV3 block, a workgroup per crop) against the unfused expand / depthwise / SE / linear
+    launches: same formulas, the squeeze-excite pooling sums in another order -> probabilities within 1e-6, labels equal."""
+    lib = hip_session._hd.lib
+    x = np.random.default_rng(n).uniform(-1, 1, (n, 3, 48, 192)).astype(np.float32)
+    x[0] *= 0.05
+    fused = hip_session.worker.cls(x)
+    try:
+        lib.rt_debug_set_variants(0, 0, 1024)
+        series = hip_session.worker.cls(x)
+    finally:
+        lib.rt_debug_set_variants(0, 0, 0)
+    assert np.isfinite(fused).all() and fused.shape == series.shape == (n, 2)
+    assert np.abs(fused - series).max() <= 1e-6
+    assert np.array_equal(fused.argmax(1), series.argmax(1))
