@@ -47,8 +47,8 @@ __device__ __forceinline__ int swz64(int px, int c) { return (px * 4 + (c ^ ((px
 int g_cls_fused = getenv("RT_CLS_FUSED") ? atoi(getenv("RT_CLS_FUSED")) : 1;   // A/B: 0 = the unfused launch series
 
 // NW waves per workgroup, each owning up to MAXU output row tiles (their linear accumulators live in registers): 8 x 9 for the
-// first block's 72 tiles, 8 x 5 / 4 x 5 for the later ones -- fewer registers and threads per crop = more crops per CU in flight,
-// which is what hides the latency chains of a block (at 8 x 9 everywhere the 200-channel blocks ran one crop per CU: 0.35 ms)
+// first block's 72 tiles, 8 x 5 for the later ones (fewer registers: more crops per CU; at 8 x 9 everywhere the 200-channel blocks
+// ran one crop per CU, 0.35 ms)
 // PADROW: the LDS slice is [row][W + 2 PAD pixels][80 bytes] with zero columns left and right (no column checks, no swizzle:
 // 80-byte pixels are conflict-free for the 16-byte reads of 8 neighbouring lanes) -- every block but the first, whose 24 x 96
 // input does not fit that way and keeps 64-byte pixels with the XOR swizzle and checked columns.
@@ -320,8 +320,10 @@ void cls_block(hipStream_t st, int k, int sh, bool se, int act, const float* x, 
   ClsBlkArgs a{x, y, gin, gout, Wexp, bexp, Wdw, bdw, w1, b1, w2, b2, Wlin, blin, dscr,
                cin, mid, mid_cp, cout, round_up(mid, 16), round_up(cout, 16), cr, shortcut ? 1 : 0, maxH_in * maxW * 64, slope};
   const int nt_out = (max_pix_out + 15) / 16;
-  const int shape = nt_out > 40 ? 0 : (nt_out > 20 ? 1 : 2);   // 8 waves x 9 tiles | 8 x 5 | 4 x 5
-  const int nw = shape == 2 ? 4 : 8;
+  // 8 waves per crop everywhere (4 on the small maps measured 1.31 vs 1.11 ms for the eleven blocks: a launch has only ~1-4
+  // crops per CU, so a crop's latency chain, not the CU's wave slots, is what counts); 9 row tiles per wave where needed
+  const int shape = nt_out > 40 ? 0 : 1;   // 8 waves x 9 tiles | 8 x 5
+  const int nw = 8;
   if (dbg & 2) a.npad_e = 16;   // one slice only
   const int small = (nw * 16 + 2 * a.npad_e + 128 + (k * k + 1) * 16) * 4;
   const long long padded = (long long)maxH_in * (maxW + 2 * (k / 2)) * 80;
@@ -334,7 +336,7 @@ void cls_block(hipStream_t st, int k, int sh, bool se, int act, const float* x, 
     allow_big_lds((const void*)k_cls_block<KK, SS, EE, AA, NWW, MU, PP>, 160 * 1024);                    \
     RT_LAUNCH((k_cls_block<KK, SS, EE, AA, NWW, MU, PP>), dim3(n_img), dim3(64 * NWW), lds, st, a);     \
   } while (0)
-#define RT_CB_S(KK, SS, EE, AA) do { if (!padrow) RT_CB(KK, SS, EE, AA, 8, 9, false); else if (shape == 0) RT_CB(KK, SS, EE, AA, 8, 9, true); else if (shape == 1) RT_CB(KK, SS, EE, AA, 8, 5, true); else RT_CB(KK, SS, EE, AA, 4, 5, true); } while (0)
+#define RT_CB_S(KK, SS, EE, AA) do { if (!padrow) RT_CB(KK, SS, EE, AA, 8, 9, false); else if (shape == 0) RT_CB(KK, SS, EE, AA, 8, 9, true); else RT_CB(KK, SS, EE, AA, 8, 5, true); } while (0)
 #define RT_CB_A(KK, SS, EE) do { if (act == ACT_RELU) RT_CB_S(KK, SS, EE, ACT_RELU); else RT_CB_S(KK, SS, EE, ACT_HSWISH); } while (0)
 #define RT_CB_E(KK, SS) do { if (se) RT_CB_A(KK, SS, true); else RT_CB_A(KK, SS, false); } while (0)
   if (k == 3 && sh == 1) RT_CB_E(3, 1);
