@@ -278,12 +278,19 @@ __global__ __launch_bounds__(P_NTHR, 1) void k_gemm32p(const GemmPArgs g) {
       //  and selects: 4 temporaries instead of 16; lanes of a quarter mostly share the address: LDS broadcast)
       const float* t = sc_tab + (sc_j & 1) * 3 * P_SCK + kc * KC + grp * 16 + (ln >> 4) * 4;
       const int rowb = wm * MT * 16 + (ln & 15);
+      if (sc_b1 >= P_BM) {   // (uniform) the whole row block lies in one image -- the majority: no per-row slot arithmetic
+        const f32x4 s0 = *reinterpret_cast<const f32x4*>(t);
 #pragma unroll
-      for (int mt = 0; mt < MT; mt++) {
-        const int row = rowb + mt * 16;
-        const int slot = (row >= sc_b1 ? 1 : 0) + (row >= sc_b2 ? 1 : 0);
-        a[mt] *= *reinterpret_cast<const f32x4*>(t + slot * P_SCK);
+        for (int mt = 0; mt < MT; mt++) a[mt] *= s0;
         __builtin_amdgcn_sched_barrier(0);
+      } else {
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++) {
+          const int row = rowb + mt * 16;
+          const int slot = (row >= sc_b1 ? 1 : 0) + (row >= sc_b2 ? 1 : 0);
+          a[mt] *= *reinterpret_cast<const f32x4*>(t + slot * P_SCK);
+          __builtin_amdgcn_sched_barrier(0);
+        }
       }
     }
   };
