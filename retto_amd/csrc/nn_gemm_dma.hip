@@ -259,8 +259,20 @@ __global__ __launch_bounds__(P_NTHR, 1) void k_gemm32p(const GemmPArgs g) {
 #pragma unroll
     for (int mt = 0; mt < MT; mt++) {
       f32x4 o;
+      if constexpr (ACT == ACT_HSWISH && (LAB == 0 || LAB == 1) && !(DBG & 4)) {
+        // the same expressions and rounding as epi_val, written on the 4-vector: packed add / mul / fma (2 values per VALU op --
+        // an fp32 MFMA loop pays every VALU cycle of its epilogue) and one v_med3 per value for the clamp
+        const f32x4 v = acc[mt][nt] + bias;
+        f32x4 t = v + 3.0f;
 #pragma unroll
-      for (int j = 0; j < 4; j++) o[j] = (DBG & 4) ? acc[mt][nt][j] : epi_val<ACT, LAB>(acc[mt][nt][j] + bias[j], g.epi.act, g.epi.has_lab, g.epi.lab_a, g.epi.lab_c);
+        for (int j = 0; j < 4; j++) { const float tj = t[j]; t[j] = __builtin_amdgcn_fmed3f(tj, 0.0f, 6.0f); }
+        o = v * t;
+        o = o * 0.16666667f;
+        if (LAB == 1) { const f32x4 a4 = {g.epi.lab_a, g.epi.lab_a, g.epi.lab_a, g.epi.lab_a}, c4 = {g.epi.lab_c, g.epi.lab_c, g.epi.lab_c, g.epi.lab_c}; o = __builtin_elementwise_fma(o, a4, c4); }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; j++) o[j] = (DBG & 4) ? acc[mt][nt][j] : epi_val<ACT, LAB>(acc[mt][nt][j] + bias[j], g.epi.act, g.epi.has_lab, g.epi.lab_a, g.epi.lab_c);
+      }
       if (DBG & 4) { if (o[0] == 123.456f) *reinterpret_cast<f32x4*>(pend_cbase + (lo + mt * mt_step + nt * 64)) = o; }
       else if (!(DBG & 1) || o[0] == 123.456f) { if (rowb < pend_rows - mt * 16) *reinterpret_cast<f32x4*>(pend_cbase + (lo + mt * mt_step + nt * 64)) = o; }
       __builtin_amdgcn_sched_barrier(0);   // (one pixel fragment at a time: interleaved, the four fragments' temporaries spill accumulators)
