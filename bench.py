@@ -91,6 +91,9 @@ def parse():
     return a
 
 
+RC_RENDEZVOUS = 75   # a rank's exit code when the rendezvous port was taken (EX_TEMPFAIL): launch_ranks() retries once
+
+
 def page_digest(lib, r, i):
     """Stable digest of one page's discrete results (boxes, labels, token ids): what must not depend on the rank / batch."""
     n = lib.rt_results_count(r, i)
@@ -108,26 +111,57 @@ def page_digest(lib, r, i):
 def launch_ranks(n):
     """`python bench.py --gpus N` without a launcher: N child interpreters with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set
     (what torch.distributed.run would export), rank 0's stdout relayed as this process's stdout (the ONE JSON line), the other
-    ranks' stdout sent to stderr.  Returns the first non-zero exit code (0 if all ranks succeed)."""
+    ranks' stdout sent to stderr.  All ranks are polled together: the first rank that exits non-zero ends the job at once (its
+    peers would otherwise sit in init_process_group / the broadcast until a timeout) and ITS exit code is returned; 0 if all
+    ranks succeed.  RT_BENCH_RANK_TIMEOUT (default 900 s: several times a default run) is only the backstop for a job in which
+    every rank hangs.  The rendezvous port is kept bound (SO_REUSEADDR) until the children are started, and a rendezvous that
+    fails on a port somebody else took in between is retried once on a fresh port."""
     import socket
-    sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
-    procs = []
-    for r in range(n):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=None if r == 0 else sys.stderr))
-    rc = 0
-    deadline = time.time() + float(os.environ.get("RT_BENCH_RANK_TIMEOUT", "3600"))
-    for pr in procs:
+    deadline = time.time() + float(os.environ.get("RT_BENCH_RANK_TIMEOUT", "900"))
+
+    def attempt():
+        sk = socket.socket()
+        sk.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+        sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]
+        procs = []
+        t_start = time.time()
         try:
-            code = pr.wait(timeout=max(1.0, deadline - time.time()))
-        except subprocess.TimeoutExpired:   # a rank that never returns (a peer died before a collective): end the job
+            for r in range(n):
+                env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                           MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+                procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                              stdout=None if r == 0 else sys.stderr))
+        finally:
+            sk.close()   # the interpreters need seconds to reach the rendezvous: the port stayed reserved while they were started
+        rc = 0
+        while True:
+            codes = [pr.poll() for pr in procs]
+            bad = [c for c in codes if c not in (None, 0)]
+            if bad:
+                rc = bad[0]
+                break
+            if all(c == 0 for c in codes):
+                break
+            if time.time() > deadline:
+                rc = 124
+                break
+            time.sleep(0.05)
+        if rc:
             for q in procs:
                 if q.poll() is None:
-                    q.kill()
-            code = 124
-        rc = rc or code
+                    q.terminate()
+            t_kill = time.time() + 5.0
+            for q in procs:
+                try:
+                    q.wait(timeout=max(0.1, t_kill - time.time()))
+                except subprocess.TimeoutExpired:
+                    q.kill(); q.wait()
+        return rc, time.time() - t_start
+
+    rc, took = attempt()
+    if rc == RC_RENDEZVOUS and took < 60 and time.time() < deadline:   # the port was taken between close() and the store's bind
+        print("bench.py: rendezvous port was taken, retrying once on a fresh port", file=sys.stderr)
+        rc, _ = attempt()
     return rc
 
 
@@ -165,17 +199,26 @@ def main():
     if world != a.gpus:
         print("bench.py: --gpus %d but WORLD_SIZE=%d" % (a.gpus, world), file=sys.stderr)
         sys.exit(2)
+    if os.environ.get("RT_BENCH_FAIL_RANK") == str(rank) and "WORLD_SIZE" in os.environ:   # test hook: a rank that dies before the rendezvous
+        print("bench.py: rank %d fails on request (RT_BENCH_FAIL_RANK)" % rank, file=sys.stderr)
+        sys.exit(3)
     import torch
     import torch.distributed as dist
     dist_on = world > 1 or os.environ.get("RT_BENCH_FORCE_DIST") == "1"  # (test hook: run the RCCL path with a single rank)
     tdev = "cuda" if a.backend == "nccl" else "cpu"
     if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if a.backend == "nccl":
-            torch.cuda.set_device(local_rank)
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(a.backend, rank=rank, world_size=world)
+        try:
+            if a.backend == "nccl":
+                torch.cuda.set_device(local_rank)
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+            else:
+                dist.init_process_group(a.backend, rank=rank, world_size=world)
+        except Exception as e:   # noqa: BLE001 -- only to tell launch_ranks() that a retry on another port can help
+            if rank == 0 and ("address already in use" in str(e).lower() or "eaddrinuse" in str(e).lower()):
+                print("bench.py: rendezvous port %s is taken: %s" % (os.environ.get("MASTER_PORT"), e), file=sys.stderr)
+                sys.exit(RC_RENDEZVOUS)
+            raise
     device = 0 if (a.share_gpu or not dist_on) else local_rank
 
     import retto_amd

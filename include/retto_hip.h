@@ -126,6 +126,12 @@ RT_API int rt_cls(rt_session* s, const float* nchw, int n, int c, int h, int w, 
 /* rec: f32 [n,3,48,w] -> f32 [n,T,6625] (softmax); *t_out = T; call with out == NULL to
  * query T only. */
 RT_API int rt_rec(rt_session* s, const float* nchw, int n, int c, int h, int w, float* out, int* t_out);
+/* rec over lines of DIFFERENT widths in one launch series: line i is f32 [3,48,widths[i]] (lines concatenated); out = the lines'
+ * [T_i,6625] softmax rows concatenated, t_out[i] = T_i (out == NULL: query the T_i only).  No reference counterpart as a worker
+ * call (ort_worker.rs:211-220 takes one width per call); it is the tensor-level view of what rt_run_batch does with
+ * rec_processor.rs:214-270's batches -- each keeps the width the running max_wh_ratio gives it, all in one ragged launch group --
+ * so that the parity tests can compare exactly that form with the oracle, line by line. */
+RT_API int rt_rec_ragged(rt_session* s, const float* nchw, int n, const int* widths, float* out, int* t_out);
 RT_API int rt_rec_classes(const rt_session* s);
 /* "<det arch>/<det dtype> <cls dtype> <rec arch>/<rec dtype>", e.g. "mobile/f32 f32 mobile/f32" or "server/f16 f16 server/f16":
  * which graphs the model sources held and the arithmetic they run in (library-owned string) */

@@ -278,6 +278,23 @@ class RettoHipWorker:
         return out
 
 
+    def rec_ragged(self, lines) -> list:
+        """rt_rec_ragged: lines = [3,48,w_i] arrays of different widths, ONE launch series (the form rt_run_batch's rec groups
+        take); returns the per-line [T_i, classes] probabilities."""
+        lines = [_as_f32(l, 3) for l in lines]
+        n = len(lines)
+        widths = (C.c_int * n)(*[l.shape[2] for l in lines])
+        ts = (C.c_int * n)()
+        flat = np.ascontiguousarray(np.concatenate([l.reshape(-1) for l in lines]))
+        _check(self._hd.lib.rt_rec_ragged(self._hd.h, flat.ctypes.data, n, widths, None, ts), self._hd.h)
+        ncls = self._hd.lib.rt_rec_classes(self._hd.h)
+        out = np.empty((sum(ts), ncls), np.float32)
+        _check(self._hd.lib.rt_rec_ragged(self._hd.h, flat.ctypes.data, n, widths, out.ctypes.data, ts), self._hd.h)
+        res, o = [], 0
+        for t in ts:
+            res.append(out[o:o + t]); o += t
+        return res
+
 def decode_image(data: bytes) -> np.ndarray:
     """ImageHelper::new_from_raw_img_flow (image_helper.rs:34-44): encoded bytes -> RGB8 [H,W,3] through the
     library's host decoder (rt_decode_image: PNG, JPEG, PNM, BMP); raises ImageError otherwise."""

@@ -41,7 +41,7 @@ class Config(C.Structure):
 # every symbol include/retto_hip.h declares (tests check that each is exported)
 EXPORTS = [
     "rt_config_default", "rt_create", "rt_destroy", "rt_last_error", "rt_version",
-    "rt_det", "rt_cls", "rt_rec", "rt_rec_classes", "rt_model_info",
+    "rt_det", "rt_cls", "rt_rec", "rt_rec_ragged", "rt_rec_classes", "rt_model_info",
     "rt_resize_both_dims", "rt_resize_both", "rt_det_input_dims", "rt_det_preprocess", "rt_det_postprocess",
     "rt_crop_dims", "rt_crop_images", "rt_scale_and_clip", "rt_resize_norm_width", "rt_resize_norm_image",
     "rt_ctc_decode",
@@ -120,6 +120,7 @@ def load():
     lib.rt_det.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
     lib.rt_cls.argtypes = lib.rt_det.argtypes
     lib.rt_rec.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, P(C.c_int)]
+    lib.rt_rec_ragged.argtypes = [C.c_void_p, C.c_void_p, C.c_int, P(C.c_int), C.c_void_p, P(C.c_int)]
     lib.rt_rec_classes.argtypes = [C.c_void_p]
     lib.rt_resize_both_dims.argtypes = [C.c_void_p, C.c_int, C.c_int, P(C.c_int), P(C.c_int)]
     lib.rt_det_input_dims.argtypes = lib.rt_resize_both_dims.argtypes

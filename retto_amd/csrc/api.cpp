@@ -124,6 +124,11 @@ int rt_rec(rt_session* s, const float* nchw, int n, int c, int h, int w, float* 
   RT_REQUIRE(out == nullptr || nchw != nullptr, s, "rt_rec: null input");
   return guarded(s, [&] { s->rec_forward(nchw, n, h, w, out, t_out); });
 }
+int rt_rec_ragged(rt_session* s, const float* nchw, int n, const int* widths, float* out, int* t_out) {
+  RT_REQUIRE(s && widths && n > 0, s, "rt_rec_ragged: bad argument");
+  RT_REQUIRE(out == nullptr || nchw != nullptr, s, "rt_rec_ragged: null input");
+  return guarded(s, [&] { s->rec_forward_ragged(nchw, n, widths, out, t_out); });
+}
 int rt_rec_classes(const rt_session* s) { return s ? s->rec->classes() : 0; }
 const char* rt_model_info(const rt_session* s) { return s ? s->model_info.c_str() : ""; }
 

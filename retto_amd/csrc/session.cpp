@@ -217,6 +217,42 @@ void rt_session::rec_forward(const float* nchw, int n, int h, int w, float* out,
   sync();
 }
 
+// Ragged form of rec_forward: line i is [3,48,widths[i]] (NCHW, lines concatenated), every line keeps its own width inside ONE
+// launch series -- what rt_run_batch's rec groups do (rec_processor.rs:214-270 gives each batch of 6 its width; the session
+// concatenates the batches).  out = the lines' [T_i, classes] probabilities concatenated, t_out[i] = T_i.
+void rt_session::rec_forward_ragged(const float* nchw, int n, const int* widths, float* out, int* t_out) {
+  const int h = 48;
+  size_t ne = 0, nt = 0;
+  for (int i = 0; i < n; i++) {
+    if (widths[i] < 8) throw RtError(RT_ERR_SHAPE, "rt_rec_ragged: every line must be at least 8 wide");
+    ne += (size_t)3 * h * widths[i];
+    int T = RecNet::tokens_for_width(widths[i]);
+    if (t_out) t_out[i] = T;
+    nt += (size_t)T;
+  }
+  if (!out) return;
+  begin_call();
+  float* d_in = arena.alloc<float>(ne);
+  RT_HIP_CHECK(hipMemcpyAsync(d_in, nchw, ne * 4, hipMemcpyHostToDevice, st));
+  float* x = arena.alloc<float>(ne / 3 * 4);
+  std::vector<std::pair<int, int>> hw;
+  size_t off = 0;
+  for (int i = 0; i < n; i++) {
+    nn::nchw3_to_nhwc4(st, d_in + off * 3, 1, h, widths[i], x + off * 4);
+    off += (size_t)h * widths[i];
+    hw.emplace_back(h, widths[i]);
+  }
+  Level L0 = make_level(hw), Lt;
+  RunCtx c = ctx(&scratch);
+  float* logits = rec->run(c, x, L0, Lt);
+  if ((size_t)Lt.total != nt) throw RtError(RT_ERR_BACKEND, "rt_rec_ragged: token count mismatch");
+  const int C = rec->classes();
+  float* probs = scratch.alloc<float>((size_t)Lt.total * C);
+  nn::softmax_rows(st, logits, rec->logits_ld(), Lt.total, C, probs);
+  RT_HIP_CHECK(hipMemcpyAsync(out, probs, (size_t)Lt.total * C * 4, hipMemcpyDeviceToHost, st));
+  sync();
+}
+
 // ---------------------------------------------------------------------------
 // stage functions
 // ---------------------------------------------------------------------------

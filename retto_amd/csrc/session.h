@@ -67,6 +67,7 @@ struct rt_session {
   void det_forward(const float* nchw, int n, int h, int w, float* out);
   void cls_forward(const float* nchw, int n, int h, int w, float* out);
   void rec_forward(const float* nchw, int n, int h, int w, float* out, int* t_out);
+  void rec_forward_ragged(const float* nchw, int n, const int* widths, float* out, int* t_out);
   // stages
   void resize_both(const uint8_t* rgb, int h, int w, uint8_t* out, int oh, int ow);
   void det_preprocess(const uint8_t* rgb, int h, int w, float* out);

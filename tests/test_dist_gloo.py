@@ -122,3 +122,39 @@ def test_bench_launches_its_own_ranks():
     assert pr1.returncode == 0, pr1.stderr[-2000:]
     j1 = json.loads([ln for ln in pr1.stdout.splitlines() if ln.startswith("{")][0])
     assert j1["gathered"] == j["gathered"] and j1["rccl_ranks"] == 1
+
+
+def test_bench_world_8_dry_run():
+    """The driver's 8-GPU launch shape on CPU: `bench.py --gpus 8 --backend gloo --dry-run` starts eight ranks, broadcasts the
+    weights rank 0 -> 7, shards ONE page list over the eight ranks (LPT) and gathers it in input order."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    pr = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--backend", "gloo", "--dry-run"],
+                        env=env, capture_output=True, text=True, timeout=900)
+    assert pr.returncode == 0, pr.stderr[-2000:]
+    lines = [ln for ln in pr.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, pr.stdout
+    j = json.loads(lines[0])
+    assert j["dry_run"] and j["n_gpus"] == 8 and j["rccl_ranks"] == 8
+    dig = j["blob_digest"][:8]
+    assert j["gathered"] == ["%d:%s" % (i, dig) for i in range(19)]
+
+
+def test_bench_launcher_ends_the_job_when_a_rank_dies():
+    """launch_ranks() polls all ranks: a rank that exits non-zero before the rendezvous ends the job at once with ITS exit code
+    (its peers would otherwise wait in init_process_group), instead of the launcher sitting on rank 0 until a timeout."""
+    import subprocess
+    import sys
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env["RT_BENCH_FAIL_RANK"] = "1"
+    t0 = time.time()
+    pr = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--dry-run"],
+                        env=env, capture_output=True, text=True, timeout=300)
+    assert pr.returncode == 3, (pr.returncode, pr.stderr[-1000:])
+    assert time.time() - t0 < 120
+    assert not [ln for ln in pr.stdout.splitlines() if ln.startswith("{")]

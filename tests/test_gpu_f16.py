@@ -181,7 +181,8 @@ def _check_rec(got, ref, atol, margin):
     return float(decisive.mean()), float((ga == ra).mean())
 
 
-@pytest.mark.parametrize("n,w", [(1, 320), (3, 321), (2, 487), (6, 640), (1, 1600)])
+# (120 x 400: the fp16 twin of test_rec_net's production-size case -- 144 000 rows at the 240-channel stages, k_gemm16p on its full-size dispatch)
+@pytest.mark.parametrize("n,w", [(1, 320), (3, 321), (2, 487), (6, 640), (1, 1600), (120, 400)])
 def test_rec_net_f16(hip16, oracle_session, n, w):
     x = np.random.default_rng(w).uniform(-1, 1, (n, 3, 48, w)).astype(np.float32)
     x[:, :, :, w // 2:] = 0.0

@@ -45,7 +45,11 @@ def test_cls_net(hip_session, oracle_session, n):
 
 # (12 / 24 x 640: 11.5 k / 23 k pixels at the squeeze-excite levels -- the fused pooling + scaled 128 x 128 / 128 x 240
 #  GEMM tiles, which smaller batches never reach)
-@pytest.mark.parametrize("n,w", [(1, 320), (3, 321), (2, 487), (1, 960), (12, 640), (24, 640), (1, 3648)])
+#  (120 x 400: 144 000 rows at the 240-channel stages -- past the M >= 131072 threshold of the persistent LDS-DMA GEMM k_gemm32p, its
+#  squeeze-excite form k_gemm32p+se and k_gemm_wide<4,...>, so the production-size kernels are compared with the oracle directly;
+#  1000 x 96: 144 rows per line at the 480-channel squeeze-excite level -- 256-row blocks that span three lines, the +se kernel's
+#  third scale slot)
+@pytest.mark.parametrize("n,w", [(1, 320), (3, 321), (2, 487), (1, 960), (12, 640), (24, 640), (1, 3648), (120, 400), (1000, 96)])
 def test_rec_net(hip_session, oracle_session, n, w):
     x = np.random.default_rng(w).uniform(-1, 1, (n, 3, 48, w)).astype(np.float32)
     x[:, :, :, w // 2:] = 0.0  # zero padding like resize_norm_image
@@ -59,6 +63,40 @@ def test_rec_net(hip_session, oracle_session, n, w):
     decisive = (top2[..., 1] - top2[..., 0]) > 1e-4
     assert (ga[decisive] == ra[decisive]).all()
     assert decisive.mean() > 0.9
+
+
+def test_rec_net_ragged_production_size(hip_session, oracle_session):
+    """The form rt_run_batch launches: lines of DIFFERENT widths in one ragged launch series (rt_rec_ragged), large enough to
+    cross every dispatch threshold of the recognition net (173 k rows at the 240-channel stages: k_gemm32p, k_gemm32p+se,
+    k_gemm_wide; lines of 48..96 pixels put 128..255-row images under the +se kernel's 256-row blocks), against the torch
+    oracle evaluated width by width (rec_processor.rs:214-270 pads a batch to one width; lines are independent)."""
+    rng = np.random.default_rng(2024)
+    widths = [48, 56, 64, 72, 88, 96, 120, 160, 200, 248, 320, 336, 400, 487, 560, 640]
+    lines = []
+    for i in range(640):
+        w = widths[(i * 7 + i // 16) % len(widths)]
+        x = rng.uniform(-1, 1, (3, 48, w)).astype(np.float32)
+        x[:, :, w - (i % 5) * (w // 8):] = 0.0   # right-hand zero padding like resize_norm_image
+        lines.append(x)
+    rows240 = sum(12 * (((l.shape[2] - 1) // 2 + 1 - 1) // 2 + 1) for l in lines)
+    assert rows240 >= 131072, rows240
+    got = hip_session.worker.rec_ragged(lines)
+    by_w = {}
+    for i, l in enumerate(lines):
+        by_w.setdefault(l.shape[2], []).append(i)
+    worst, dec_n, dec_eq, tot = 0.0, 0, 0, 0
+    for w, idx in by_w.items():
+        ref = N.rec_forward(oracle_session.wr, torch.from_numpy(np.stack([lines[i] for i in idx]))).numpy()
+        for k, i in enumerate(idx):
+            g, r = got[i], ref[k]
+            assert g.shape == r.shape, (w, g.shape, r.shape)
+            worst = max(worst, float(np.abs(g - r).max()))
+            top2 = np.sort(r, -1)[..., -2:]
+            decisive = (top2[..., 1] - top2[..., 0]) > 1e-4
+            dec_n += int(decisive.sum()); tot += decisive.size
+            dec_eq += int((g.argmax(-1)[decisive] == r.argmax(-1)[decisive]).sum())
+    assert worst <= 2e-4, worst
+    assert dec_eq == dec_n and dec_n > 0.9 * tot, (dec_eq, dec_n, tot)
 
 
 # ---------------------------------------------------------------- a2 / a3 preprocessing
@@ -706,13 +744,16 @@ def test_round3_kernels_are_bit_identical_to_the_ones_they_replaced(hip_session,
     for i in range(xr.shape[0]):
         xr[i, :, :, 180 + (37 * i) % 220:] = 0
     xc = rng.uniform(-1, 1, (9, 3, 48, 192)).astype(np.float32)
+    # narrow lines: 144 rows per line at the first squeeze-excite level (6 x 24), so k_gemm32p+se's 256-row blocks span THREE
+    # lines (scale slot 2, the third a_tab entry, the clamped prefetch of the last lines) at M = 144 000 >= 131072
+    xn = rng.uniform(-1, 1, (1000, 3, 48, 96)).astype(np.float32)
     try:
         lib.rt_debug_set_variants(0, 0, flags)
-        old = [hip_session.worker.det(xd), hip_session.worker.rec(xr), hip_session.worker.cls(xc)]
+        old = [hip_session.worker.det(xd), hip_session.worker.rec(xr), hip_session.worker.cls(xc), hip_session.worker.rec(xn)]
     finally:
         lib.rt_debug_set_variants(0, 0, 0)
-    new = [hip_session.worker.det(xd), hip_session.worker.rec(xr), hip_session.worker.cls(xc)]
-    for name, a, b in zip(("det", "rec", "cls"), old, new):
+    new = [hip_session.worker.det(xd), hip_session.worker.rec(xr), hip_session.worker.cls(xc), hip_session.worker.rec(xn)]
+    for name, a, b in zip(("det", "rec", "cls", "rec-narrow"), old, new):
         assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), f"{name}: max |diff| {np.abs(a.astype(np.float64) - b).max()}"
 
 
