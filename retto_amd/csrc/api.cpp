@@ -388,6 +388,7 @@ RT_API void rt_debug_set_variants(int gemm_variant, int dw_variant, int flags) {
   nn::g_lc_wave = (flags & 128) ? 0 : lc_wave0;
   nn::g_gemm_dma = (flags & 256) ? 0 : gemm_dma0;
   nn::g_dw_sweep = (flags & 512) ? 0 : dw_sweep0;
+  nn::g_fpn_phase_off = (flags & 2048) ? 1 : 0;   // (bit 11: RSEFPN / DB-head convs as the round-3 launch series; equal to fp32 rounding, not bit-identical)
   nn::g_cls_fused = (flags & 1024) ? 0 : cls_fused0;   // (bit 10: the classifier's blocks as the unfused launch series; fp32-tolerance equal, not bit-identical)
 }
 // Runs one nh::conv16 launch on host tensors (diagnostics: the numerics tests compare it with torch conv2d).

@@ -290,6 +290,72 @@ static float* run_lc(RunCtx& c, const LcBlock& b, const float* x, const Level& L
 }
 
 // ---------------------------------------------------------------------------
+// Weights of the upsampling-aware FPN convs (nn_fpn.hip).  w = raw conv weight [24][cin_total][3][3].
+// A 3x3 conv over up_s(z): output row y = s Y + py reads row Y - 1 of z through tap dy = 0 only when py == 0, row Y + 1
+// through tap dy = 2 only when py == s - 1, and row Y otherwise.
+// ---------------------------------------------------------------------------
+// [9 taps][24 n][cf] (cf >= cc: zero padded): the channels [c0, c0 + cc) that are convolved at their own resolution
+static std::vector<float> fpn_fine_weights(const float* w, int cin_total, int c0, int cc, int cf) {
+  std::vector<float> o((size_t)9 * 24 * cf, 0.f);
+  for (int t = 0; t < 9; t++)
+    for (int n = 0; n < 24; n++)
+      for (int c = 0; c < cc; c++) o[((size_t)t * 24 + n) * cf + c] = w[((size_t)n * cin_total + c0 + c) * 9 + t];
+  return o;
+}
+// taps of the 3-tap axis that land on the 2-tap phase axis: phase 0 = {row - 1: tap 0; row 0: taps 1, 2}, phase 1 = {row 0: taps 0, 1; row + 1: tap 2}
+static void phase_taps(int ph, int t, int* lo, int* hi) {
+  if (ph == 0) { *lo = t == 0 ? 0 : 1; *hi = t == 0 ? 0 : 2; }
+  else { *lo = t == 0 ? 0 : 2; *hi = t == 0 ? 1 : 2; }
+}
+// [cc / 24 slabs][4 phases (py, px)][4 taps (ty, tx)][24 n][24 k]: conv3x3(up2(z)) as four 2 x 2 convs of z
+static std::vector<float> fpn_phase_weights(const float* w, int cin_total, int c0, int cc) {
+  const int ns = cc / 24;
+  std::vector<float> o((size_t)ns * 16 * 576, 0.f);
+  for (int s = 0; s < ns; s++)
+    for (int py = 0; py < 2; py++)
+      for (int px = 0; px < 2; px++)
+        for (int ty = 0; ty < 2; ty++)
+          for (int tx = 0; tx < 2; tx++) {
+            int y0, y1, x0, x1;
+            phase_taps(py, ty, &y0, &y1); phase_taps(px, tx, &x0, &x1);
+            for (int n = 0; n < 24; n++)
+              for (int k = 0; k < 24; k++) {
+                double acc = 0.0;
+                for (int dy = y0; dy <= y1; dy++)
+                  for (int dx = x0; dx <= x1; dx++) acc += w[((size_t)n * cin_total + c0 + s * 24 + k) * 9 + dy * 3 + dx];
+                o[((((size_t)s * 4 + py * 2 + px) * 4 + ty * 2 + tx) * 24 + n) * 24 + k] = (float)acc;
+              }
+          }
+  return o;
+}
+// [9 classes (row class x 3 + column class)][9 taps (ry + 1, rx + 1)][24 n][24 k] for the 24 channels at c0: class 0 = first row /
+// column of an upsampling block, 1 = interior, 2 = last
+static std::vector<float> fpn_class_weights(const float* w, int cin_total, int c0) {
+  auto span = [](int cls, int r, int* lo, int* hi) {   // taps of the 3-tap axis that land on relative row r (-1, 0, +1); empty: lo > hi
+    *lo = 1; *hi = 0;
+    if (cls == 0) { if (r == -1) { *lo = 0; *hi = 0; } else if (r == 0) { *lo = 1; *hi = 2; } }
+    else if (cls == 1) { if (r == 0) { *lo = 0; *hi = 2; } }
+    else { if (r == 0) { *lo = 0; *hi = 1; } else if (r == 1) { *lo = 2; *hi = 2; } }
+  };
+  std::vector<float> o((size_t)81 * 576, 0.f);
+  for (int rc = 0; rc < 3; rc++)
+    for (int cc = 0; cc < 3; cc++)
+      for (int ry = -1; ry <= 1; ry++)
+        for (int rx = -1; rx <= 1; rx++) {
+          int y0, y1, x0, x1;
+          span(rc, ry, &y0, &y1); span(cc, rx, &x0, &x1);
+          for (int k = 0; k < 24; k++)
+            for (int n = 0; n < 24; n++) {
+              double acc = 0.0;
+              for (int dy = y0; dy <= y1; dy++)
+                for (int dx = x0; dx <= x1; dx++) acc += w[((size_t)n * cin_total + c0 + k) * 9 + dy * 3 + dx];
+              o[((((size_t)rc * 3 + cc) * 9 + (ry + 1) * 3 + (rx + 1)) * 24 + n) * 24 + k] = (float)acc;
+            }
+        }
+  return o;
+}
+
+// ---------------------------------------------------------------------------
 // DetNet
 // ---------------------------------------------------------------------------
 DetNet::DetNet(const Blob& b) {
@@ -314,6 +380,22 @@ DetNet::DetNet(const Blob& b) {
     inp_se_[j] = get_se(ws_, b, "det.fpn.inp" + js + ".se", 24);
   }
   head_conv1_ = pack_conv(ws_, b, "det.head.conv1", 24, 96, 3, 3);
+  {  // operands of the upsampling-aware forms (nn_fpn.hip): pre-summed phase / class weights of the head conv and of inp0 / inp1
+    const BlobTensor& hw = b.get("det.head.conv1.w");   // [24][96 = p5 | p4 | p3 | p2][3][3]
+    head_wf_ = ws_.upload(fpn_fine_weights(hw.data, 96, 72, 24, 24));
+    head_wc_ = ws_.upload(fpn_phase_weights(hw.data, 96, 48, 24));
+    head_cls4_ = ws_.upload(fpn_class_weights(hw.data, 96, 24));
+    head_cls5_ = ws_.upload(fpn_class_weights(hw.data, 96, 0));
+    for (int j = 0; j < 2; j++) {
+      const BlobTensor& iw = b.get("det.fpn.inp" + std::to_string(j) + ".w");   // [24][96][3][3]
+      inp_wc_[j] = ws_.upload(fpn_phase_weights(iw.data, 96, 0, 96));
+      std::vector<float> wm((size_t)9 * 24 * 96);
+      for (int t = 0; t < 9; t++)
+        for (int n = 0; n < 24; n++)
+          for (int m = 0; m < 96; m++) wm[((size_t)t * 24 + n) * 96 + m] = iw.data[((size_t)n * 96 + m) * 9 + t];
+      inp_wm_[j] = ws_.upload(wm);
+    }
+  }
   dc1_w_ = upload_raw(ws_, b, "det.head.deconv1.w", 24 * 24 * 4); dc1_b_ = upload_raw(ws_, b, "det.head.deconv1.b", 24);
   dc2_w_ = upload_raw(ws_, b, "det.head.deconv2.w", 24 * 4); dc2_b_ = upload_raw(ws_, b, "det.head.deconv2.b", 1);
 }
@@ -351,11 +433,19 @@ float* DetNet::run(RunCtx& c, const float* x, Level& L0, const nn::U8Page* pages
   // RSEFPN.  The squeeze-excite factors of the lateral (ins) and output (inp) convs are not applied in a pass
   // of their own: ins[j]'s go into the top-down add that consumes it (out = ins[j] * s + up(ins[j+1]); the
   // coarsest level, which has no add, is rescaled in place), inp[j]'s into the concat gather.
-  float* in[4];
+  // Upsampling-aware forms (nn_fpn.hip): every level exactly half of the finer one (det inputs are multiples of 32), lateral
+  // convs without bias.  RT_FPN_PHASE=0 / rt_debug_set_variants bit 11 keep the round-3 launch series.
+  bool phase = nn::fpn_phase_supported(out_[0].N, 96) && nn::fpn_phase_supported(out_[1].N, 96) && nn::fpn_phase_supported(24, 24) &&
+               !nn::g_fpn_phase_off && !has_bias_[0] && !has_bias_[1];
+  for (int j = 0; j < 3 && phase; j++)
+    for (size_t i = 0; i < tap_lv[j]->h.size(); i++)
+      if (tap_lv[j]->h[i].H != 2 * tap_lv[j + 1]->h[i].H || tap_lv[j]->h[i].W != 2 * tap_lv[j + 1]->h[i].W) phase = false;
+  float* in[4] = {nullptr, nullptr, nullptr, nullptr};
+  float* lat_scale[4] = {nullptr, nullptr, nullptr, nullptr};
   for (int j = 3; j >= 0; j--) {
-    in[j] = c.arena->alloc<float>((size_t)tap_lv[j]->total * 96);
     const int cin = out_[j].N, cin_p = round_up(cin, 4);
     if (j == 3 || has_bias_[j]) {  // coarsest level (no add to fold into), or a lateral conv that carries a bias: GEMM + SE in place
+      in[j] = c.arena->alloc<float>((size_t)tap_lv[j]->total * 96);
       { ProfScope ps(c.prof, c.st, "gemm_misc", shape_str(tap_lv[j]->total, ins_[j].K, 96, 0));
         nn::gemm(c.st, taps[j], cin_p, tap_lv[j]->total, ins_[j].K, ins_[j].w, 96, ins_[j].Npad, in[j], 96, 0, make_epi(ins_[j], ACT_NONE)); }
       float* sc = run_se(c, in[j], *tap_lv[j], ins_se_[j], HSIG_MBV3, 1, j == 3);
@@ -370,23 +460,62 @@ float* DetNet::run(RunCtx& c, const float* x, Level& L0, const nn::U8Page* pages
     const Level& L = *tap_lv[j];
     float* partial = c.arena->alloc<float>((size_t)L.n() * nn::pool_chunks(L.maxPix) * cin_p);
     float* scale = c.arena->alloc<float>((size_t)L.n() * 96);
+    lat_scale[j] = scale;
     { ProfScope ps(c.prof, c.st, "se_pool_fc");
       nn::se_scale_projected(c.st, taps[j], L.d, L.n(), L.maxPix, cin, cin_p, ins_lin_[j], 96, 96, ins_se_[j].w1, ins_se_[j].b1,
                              ins_se_[j].w2, ins_se_[j].b2, ins_se_[j].Cr, HSIG_MBV3, 1, partial, scale); }
+    if (phase && j == 0) continue;   // the finest lateral tensor is never built: inp0 convolves the tap tensor itself (below)
+    in[j] = c.arena->alloc<float>((size_t)L.total * 96);
     { ProfScope ps(c.prof, c.st, "lateral_add", shape_str(L.total, cin, 96, 0));
       nn::lateral_add(c.st, taps[j], cin, cin_p, ins_lin_[j], 96, scale, in[j + 1], L.d, tap_lv[j + 1]->d, L.n(), L.maxPix, in[j]); }
   }
   float* p[4];
   const float* p_scale[4];
   for (int j = 3; j >= 0; j--) {
-    p[j] = c.arena->alloc<float>((size_t)tap_lv[j]->total * 24);
-    { ProfScope ps(c.prof, c.st, "conv3x3", shape_str(tap_lv[j]->total, 9 * 96, 24, 0));
-      nn::conv_sp(c.st, 3, 3, in[j], 96, tap_lv[j]->d, tap_lv[j]->n(), tap_lv[j]->maxH, tap_lv[j]->maxW, 96, inp_[j].w, 24,
+    const Level& L = *tap_lv[j];
+    p[j] = c.arena->alloc<float>((size_t)L.total * 24);
+    if (phase && j < 2) {
+      // p_j = conv3x3(lateral(c_j) * s + up2(in_{j+1})) = conv3x3(c_j; per-image composed weights) + four 2 x 2 phase convs of in_{j+1}
+      const int cin = out_[j].N, cf = round_up(cin, 4);
+      float* wimg = c.arena->alloc<float>((size_t)L.n() * 9 * 24 * cf);
+      const int tiles = ((L.maxW + 15) / 16) * ((L.maxH + 15) / 16);
+      float* pool = c.arena->alloc<float>((size_t)L.n() * tiles * 24);
+      float* scale = c.arena->alloc<float>((size_t)L.n() * 24);
+      { ProfScope ps(c.prof, c.st, "fpn_compose");
+        nn::fpn_compose(c.st, ins_lin_[j], cin, 96, lat_scale[j], inp_wm_[j], cf, L.n(), wimg); }
+      { ProfScope ps(c.prof, c.st, "conv3x3_phase", shape_str(L.total, 9 * cf + 4 * 96, 24, 0));
+        nn::FpnPhaseArgs a;
+        a.fine = taps[j]; a.ld_fine = cf; a.Wf = wimg; a.wf_img = (long long)9 * 24 * cf;
+        a.coarse = in[j + 1]; a.ld_coarse = 96; a.Wc = inp_wc_[j];
+        a.bias = inp_[j].b; a.y = p[j]; a.ldy = 24; a.pool = pool; a.pool_tiles = tiles; a.act = ACT_NONE;
+        nn::fpn_phase(c.st, a, cin, 96, L.d, tap_lv[j + 1]->d, L.n(), L.maxH, L.maxW); }
+      { ProfScope ps(c.prof, c.st, "se_pool_fc");
+        nn::se_fc_from_tiles(c.st, pool, L.d, L.n(), tiles, 24, 24, inp_se_[j].w1, inp_se_[j].b1, inp_se_[j].w2, inp_se_[j].b2,
+                             inp_se_[j].Cr, HSIG_MBV3, 1, scale); }
+      p_scale[3 - j] = scale;
+      continue;
+    }
+    { ProfScope ps(c.prof, c.st, "conv3x3", shape_str(L.total, 9 * 96, 24, 0));
+      nn::conv_sp(c.st, 3, 3, in[j], 96, L.d, L.n(), L.maxH, L.maxW, 96, inp_[j].w, 24,
                   inp_[j].Npad, p[j], 24, make_epi(inp_[j], ACT_NONE)); }
-    p_scale[3 - j] = run_se(c, p[j], *tap_lv[j], inp_se_[j], HSIG_MBV3, 1, false);  // order p5, p4, p3, p2
+    p_scale[3 - j] = run_se(c, p[j], L, inp_se_[j], HSIG_MBV3, 1, false);  // order p5, p4, p3, p2
   }
   float* h1 = c.arena->alloc<float>((size_t)L4.total * 24);
-  if (nn::conv3_fpn_fused_supported(24, 24)) {   // the head conv gathers the four levels itself: no 96-channel fuse tensor
+  if (phase) {
+    // head conv over concat(up8(p5), up4(p4), up2(p3), p2) * scales: p2 at its own resolution, p3 as phase convs, p4 / p5 through
+    // their class tensors (bias folded in)
+    float* V5 = c.arena->alloc<float>((size_t)L32.total * 9 * 24);
+    float* V45 = c.arena->alloc<float>((size_t)L16.total * 9 * 24);
+    { ProfScope ps(c.prof, c.st, "fpn_class");
+      nn::fpn_class(c.st, p[3], 24, p_scale[0], 24, L32.d, L32.n(), L32.maxPix, head_cls5_, nullptr, nullptr, nullptr, 0, V5, L32.total);
+      nn::fpn_class(c.st, p[2], 24, p_scale[1], 24, L16.d, L16.n(), L16.maxPix, head_cls4_, head_conv1_.b, V5, L32.d, L32.total, V45, L16.total); }
+    ProfScope ps(c.prof, c.st, "conv3x3_phase", shape_str(L4.total, 9 * 24 + 4 * 24, 24, 1));
+    nn::FpnPhaseArgs a;
+    a.fine = p[0]; a.ld_fine = 24; a.fine_scale = p_scale[3]; a.ld_fs = 24; a.Wf = head_wf_; a.wf_img = 0;
+    a.coarse = p[1]; a.ld_coarse = 24; a.coarse_scale = p_scale[2]; a.ld_cs = 24; a.Wc = head_wc_;
+    a.G = V45; a.gg = L16.d; a.g_plane = L16.total; a.y = h1; a.ldy = 24; a.act = ACT_RELU;
+    nn::fpn_phase(c.st, a, 24, 24, L4.d, L8.d, L4.n(), L4.maxH, L4.maxW);
+  } else if (nn::conv3_fpn_fused_supported(24, 24)) {   // the head conv gathers the four levels itself: no 96-channel fuse tensor
     ProfScope ps(c.prof, c.st, "conv3x3", shape_str(L4.total, 9 * 96, 24, 1));
     nn::conv3_fpn_fused(c.st, p[3], p[2], p[1], p[0], L32.d, L16.d, L8.d, L4.d, L4.n(), L4.maxH, L4.maxW, 24, p_scale,
                         head_conv1_.w, 24, head_conv1_.Npad, h1, 24, make_epi(head_conv1_, ACT_RELU));

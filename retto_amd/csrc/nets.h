@@ -142,6 +142,9 @@ class DetNet : public DetModel {
   bool has_bias_[4] = {false, false, false, false};
   SeW ins_se_[4], inp_se_[4];
   float *dc1_w_, *dc1_b_, *dc2_w_, *dc2_b_;
+  // nn_fpn.hip operands: head conv split by level (p2 fine / p3 phase / p4, p5 class), inp0 / inp1 phase weights + [tap][n][m] form
+  float *head_wf_ = nullptr, *head_wc_ = nullptr, *head_cls4_ = nullptr, *head_cls5_ = nullptr;
+  float *inp_wc_[2] = {nullptr, nullptr}, *inp_wm_[2] = {nullptr, nullptr};
 };
 
 class RecNet : public RecModel {

@@ -125,6 +125,39 @@ bool conv3_fpn_fused_supported(int Cq, int N);
 void conv3_fpn_fused(hipStream_t st, const float* p5, const float* p4, const float* p3, const float* p2, const ImgGeom* g5,
                      const ImgGeom* g4, const ImgGeom* g3, const ImgGeom* g2, int n_img, int maxH, int maxW, int Cq,
                      const float* const* scales, const float* Wp, int N, int Npad16, float* y, int ldy, const Epilogue& epi);
+// RSEFPN / DB-head 3x3 convs restructured around the nearest-neighbour upsampling (nn_fpn.hip).  k_fpn_phase computes, for the
+// pixels of a level gf whose next coarser level gc is exactly half its size,
+//   y = act( conv3x3(fine * fine_scale; Wf) + conv3x3(up2(coarse * coarse_scale)) [as four 2 x 2 phase convs; Wc pre-summed]
+//            + (G ? G[pixel >> 2][class of (y & 3, x & 3)] : bias) )                                  onto 24 output channels.
+struct FpnPhaseArgs {
+  const float* fine = nullptr; int ld_fine = 0;        // fine tensor, cf channels (cf4 = ceil(cf / 4) 16-byte chunks read per pixel)
+  const float* fine_scale = nullptr; int ld_fs = 0;    // [image][ld_fs] or null
+  const float* Wf = nullptr; long long wf_img = 0;     // [9 taps][24][4 cf4] (+ image * wf_img: per-image composed weights)
+  const float* coarse = nullptr; int ld_coarse = 0;    // coarse tensor, cc = 24 or 96 channels
+  const float* coarse_scale = nullptr; int ld_cs = 0;
+  const float* Wc = nullptr;                           // [cc / 24 slabs][4 phases][4 taps][24 n][24 k]
+  const float* G = nullptr; const ImgGeom* gg = nullptr;  // class tensor [9][pixel of gg = gf / 4][24] (fpn_class), bias included
+  long long g_plane = 0;                               // pixels of the level behind G (stride between its class planes)
+  const float* bias = nullptr;                         // [24], used when G is null
+  float* y = nullptr; int ldy = 0;
+  float* pool = nullptr; int pool_tiles = 0;           // optional [image][pool_tiles][24]: per-tile channel sums of y (16 x 16 tiles, raster order)
+  int act = ACT_NONE;                                  // ACT_NONE / ACT_RELU
+};
+extern int g_fpn_phase_off;   // A/B (rt_debug_set_variants bit 11): 1 = the round-3 launch series
+bool fpn_phase_supported(int cf, int cc);
+void fpn_phase(hipStream_t st, const FpnPhaseArgs& a, int cf, int cc, const ImgGeom* gf, const ImgGeom* gc, int n_img, int maxH, int maxW);
+// V[9][pixel][24] (plane = pixels of the level) = class tensor of z (24 channels, x scale) for the head conv's up4 / up8 inputs; Wcls [9][9][24 n][24 k];
+// + bias, + lower[implied class][(y >> 1, x >> 1)] (the next coarser level's class tensor) when given.
+void fpn_class(hipStream_t st, const float* z, int ldz, const float* scale, int ld_s, const ImgGeom* geom, int n_img,
+               long long max_pix, const float* Wcls, const float* bias, const float* lower, const ImgGeom* glow, long long low_plane,
+               float* V, long long plane);
+// out[img][9][24][cf] = sum_m Wlat[c][m] * scale[img][m] * Wm[tap][n][m]: the lateral 1x1 conv, its squeeze-excite factor and the
+// 3x3 conv that follows composed into one 3x3 conv of the narrow tap tensor
+void fpn_compose(hipStream_t st, const float* Wlat, int cin, int C, const float* scale, const float* Wm, int cf, int n_img, float* out);
+// squeeze-excite FCs from per-tile channel sums (FpnPhaseArgs::pool; tiles = 16 x 16 pixels in raster order)
+void se_fc_from_tiles(hipStream_t st, const float* partial, const ImgGeom* geom, int n_img, int tiles_alloc, int C, int Cp,
+                      const float* w1, const float* b1, const float* w2, const float* b2, int Cr, float slope, int residual,
+                      float* scale);
 // DB head tail: convT2x2s2(24->24)+relu, convT2x2s2(24->1), sigmoid. in [.,.,24] at 1/4 res,
 // out f32 map at full res (geometry gout, one float per pixel).
 void db_head_tail(hipStream_t st, const float* x, const ImgGeom* gin, const ImgGeom* gout, int n_img, long long max_pix,

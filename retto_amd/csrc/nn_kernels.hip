@@ -1653,7 +1653,9 @@ __global__ __launch_bounds__(256) void k_se_fc(const float* __restrict__ partial
   const long long npix = (long long)g.H * g.W;
   // partial sums come from k_pool_partial (POOL_PIX pixels each) or, strip_R > 0, from the blocks of the
   // depthwise kernel that produced the tensor (32 strips of strip_R x 4 pixels each)
+  // ... or, strip_R < 0, from the 16 x 16-pixel tiles of the kernel that produced it (k_fpn_phase)
   const int chunks = strip_R > 0 ? (((g.W + 3) >> 2) * ((g.H + strip_R - 1) / strip_R) + strips_per_block - 1) / strips_per_block
+                     : strip_R < 0 ? ((g.W + 15) >> 4) * ((g.H + 15) >> 4)
                                  : (int)((npix + POOL_PIX - 1) / POOL_PIX);
   const float inv = 1.0f / (float)npix;
   if (Wlin) {
@@ -1743,6 +1745,13 @@ void se_fc_from_dw(hipStream_t st, const float* partial, const ImgGeom* geom, in
   if (n_img <= 0) return;
   RT_LAUNCH(k_se_fc, dim3(n_img), dim3(256), (Cp + Cr + 4) * sizeof(float), st, partial, geom, chunks, C, Cp,
                      w1, b1, w2, b2, Cr, slope, residual, scale, strip_R, strips_per_block, (const float*)nullptr, 0, 0);
+}
+void se_fc_from_tiles(hipStream_t st, const float* partial, const ImgGeom* geom, int n_img, int tiles_alloc, int C, int Cp,
+                      const float* w1, const float* b1, const float* w2, const float* b2, int Cr, float slope, int residual,
+                      float* scale) {
+  if (n_img <= 0) return;
+  RT_LAUNCH(k_se_fc, dim3(n_img), dim3(256), (Cp + Cr + 4) * sizeof(float), st, partial, geom, tiles_alloc, C, Cp,
+                     w1, b1, w2, b2, Cr, slope, residual, scale, -16, 32, (const float*)nullptr, 0, 0);
 }
 void global_mean(hipStream_t st, const float* x, const ImgGeom* geom, int n_img, long long max_pix, int Cp,
                  float* partial, float* out) {

@@ -757,6 +757,30 @@ def test_round3_kernels_are_bit_identical_to_the_ones_they_replaced(hip_session,
         assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), f"{name}: max |diff| {np.abs(a.astype(np.float64) - b).max()}"
 
 
+@pytest.mark.parametrize("n,h,w", [(2, 416, 352), (1, 736, 1312), (3, 960, 960)])
+def test_upsampling_aware_fpn_convs_against_the_launch_series(hip_session, n, h, w):
+    """nn_fpn.hip (round 4): the RSEFPN output convs and the DB head's first conv as phase / class convs of the un-upsampled
+    levels with pre-summed weights, the finest lateral tensor composed away -- against the round-3 launch series (lateral_add +
+    k_conv3_few + the fused four-level gather; rt_debug_set_variants bit 11).  Same mathematics, another summation order: equal
+    to fp32 rounding on the probability map (logit-level differences ~1e-6), the thresholded mask equal wherever the map is not
+    within 1e-5 of the threshold.  416 x 352 / 736 x 1312: partial 16 x 16 tiles at the 1/4-resolution level (104 x 88, 184 x 328)."""
+    lib = hip_session._hd.lib
+    x = np.random.default_rng(n * h + w).uniform(-1, 1, (n, 3, h, w)).astype(np.float32)
+    new = hip_session.worker.det(x)
+    try:
+        lib.rt_debug_set_variants(0, 0, 2048)
+        old = hip_session.worker.det(x)
+    finally:
+        lib.rt_debug_set_variants(0, 0, 0)
+    assert np.isfinite(new).all()
+    d = np.abs(new.astype(np.float64) - old)
+    assert d.max() <= 2e-5, d.max()
+    far = np.abs(old - 0.3) > 1e-5
+    assert np.array_equal((new > 0.3)[far], (old > 0.3)[far])
+    again = hip_session.worker.det(x)
+    assert np.array_equal(new.view(np.uint32), again.view(np.uint32))   # fixed summation orders (incl. the per-tile SE sums)
+
+
 @pytest.mark.parametrize("n", [1, 9, 700])
 def test_fused_classifier_blocks_against_the_launch_series(hip_session, n):
     """k_cls_block (one kernel per MobileNetV3 block, a workgroup per crop) against the unfused expand / depthwise / SE / linear
