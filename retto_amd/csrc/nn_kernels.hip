@@ -1565,11 +1565,149 @@ __global__ __launch_bounds__(256) void k_stem_u8(const U8Page* __restrict__ page
     *reinterpret_cast<f32x4*>(o + c) = t;
   }
 }
+// ---------------------------------------------------------------------------
+// Stem on the matrix cores (round 4): 3x3 stride 2, 3 -> 16 channels = a [pixels, 27] x [27, 16] contraction, seven
+// v_mfma_f32_16x16x4_f32 steps per 16 pixels.  The thread-per-pixel kernels above ran at 2.1 TB/s of their bytes: 27 strided
+// byte loads + 27 IEEE divisions (U8) and 432 scalar FMAs per output pixel.  Here a workgroup stages the (2 TH + 1) x (2 TW + 1)
+// input patch of a TH x TW = 8 x 32 output tile ONCE into LDS as normalised floats (coalesced byte / 16-byte loads, each input
+// element converted once), and lane (r, q) of a wave reads operand k = 4 step + q of pixel r with one ds_read_b32 per step
+// (consecutive pixels are 6 floats apart: 16 distinct banks); the weights are the MFMA "A" operand (seven registers for the
+// whole kernel), so a lane ends with 4 consecutive channels of a pixel and a wave stores 1 KB of contiguous output.
+// U8 = 1: the RGB8 page with DetProcessor::preprocess's normalise (det_processor.rs:151-155) applied while staging, same three
+// separately rounded operations as k_det_normalize; U8 = 0: the f32 NHWC-4 tensor.  Both stage the same floats and run the same
+// MFMA code: bit-identical results (test_det_stem_from_u8_pages_matches_tensor_path).
+// ---------------------------------------------------------------------------
+template <int U8>
+__global__ __launch_bounds__(256) void k_stem_mfma(const float* __restrict__ x, const U8Page* __restrict__ pages, float scale, float m0,
+                                                   float m1, float m2, float s0, float s1, float s2, const ImgGeom* __restrict__ gin,
+                                                   const ImgGeom* __restrict__ gout, const float* __restrict__ Ws,
+                                                   const float* __restrict__ bias, int act, float* __restrict__ y) {
+  constexpr int TH = 8, TW = 32, PH = 2 * TH + 1, PW = 2 * TW + 1, PITCH = PW * 3 + 1;   // 196 floats per patch row
+  __shared__ float patch[PH * PITCH];
+  const ImgGeom gi = gin[blockIdx.y], go = gout[blockIdx.y];
+  const int tiles_x = (go.W + TW - 1) / TW, tiles_y = (go.H + TH - 1) / TH;
+  if ((int)blockIdx.x >= tiles_x * tiles_y) return;
+  const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, q = lane >> 4;
+  const int iy0 = ty * TH * 2 - 1, ix0 = tx * TW * 2 - 1;   // input coordinates of the patch origin (pad 1)
+  // staging: a thread per patch PIXEL (index arithmetic once per pixel, carried from one pixel to the next without divisions)
+  constexpr int NP = PH * PW, NL = (NP + 255) / 256;
+  int pr = tid / PW, pc = tid - pr * PW;
+  if (U8) {
+    // the normalised value of a page byte depends on (channel, byte) only: a 3 x 256 table per workgroup, every entry computed
+    // with DetProcessor::preprocess's three separately rounded operations, replaces ~15 VALU ops (an IEEE division) per byte
+    __shared__ float lut[3 * 256];
+    {
+      const float mean[3] = {m0, m1, m2}, stdv[3] = {s0, s1, s2};
+#pragma unroll
+      for (int ci = 0; ci < 3; ci++) {
+        float t, u;
+        const float xf = (float)tid, mc = mean[ci];
+        // (this file is compiled with -ffp-contract=fast: the multiply and the subtract are pinned as separate instructions so
+        //  that the value is k_det_normalize's)
+        asm volatile("v_mul_f32_e32 %0, %1, %2" : "=v"(t) : "v"(xf), "v"(scale));
+        asm volatile("v_sub_f32_e32 %0, %1, %2" : "=v"(u) : "v"(t), "v"(mc));
+        lut[ci * 256 + tid] = u / stdv[ci];
+      }
+    }
+    const uint8_t* rgb = pages[blockIdx.y].rgb;
+    uint8_t raw[NL][3];
+    unsigned okm = 0;
+    {
+      int r_ = pr, c_ = pc;
+#pragma unroll
+      for (int i = 0; i < NL; i++) {
+        const int iy = iy0 + min(r_, PH - 1), ix = ix0 + c_;
+        const bool ok = iy >= 0 && iy < gi.H && ix >= 0 && ix < gi.W;
+        const uint8_t* px = rgb + (ok ? ((long long)iy * gi.W + ix) * 3 : 0);
+        raw[i][0] = px[0]; raw[i][1] = px[1]; raw[i][2] = px[2];
+        okm |= (ok ? 1u : 0u) << i;
+        r_ += 256 / PW; c_ += 256 % PW;
+        if (c_ >= PW) { c_ -= PW; r_++; }
+      }
+    }
+    __syncthreads();   // the table
+    {
+      int r_ = pr, c_ = pc;
+#pragma unroll
+      for (int i = 0; i < NL; i++) {
+        if (r_ < PH) {
+          const bool ok = (okm >> i) & 1;
+          float* d = patch + r_ * PITCH + c_ * 3;   // tensor channel ci = page byte 2 - ci (BGR)
+          d[0] = ok ? lut[raw[i][2]] : 0.f; d[1] = ok ? lut[256 + raw[i][1]] : 0.f; d[2] = ok ? lut[512 + raw[i][0]] : 0.f;
+        }
+        r_ += 256 / PW; c_ += 256 % PW;
+        if (c_ >= PW) { c_ -= PW; r_++; }
+      }
+    }
+  } else {
+    f32x4 raw[NL];
+    unsigned okm = 0;
+    {
+      int r_ = pr, c_ = pc;
+#pragma unroll
+      for (int i = 0; i < NL; i++) {
+        const int iy = iy0 + min(r_, PH - 1), ix = ix0 + c_;
+        const bool ok = iy >= 0 && iy < gi.H && ix >= 0 && ix < gi.W;
+        raw[i] = *reinterpret_cast<const f32x4*>(x + (gi.off + (ok ? (long long)iy * gi.W + ix : 0)) * 4);
+        okm |= (ok ? 1u : 0u) << i;
+        r_ += 256 / PW; c_ += 256 % PW;
+        if (c_ >= PW) { c_ -= PW; r_++; }
+      }
+    }
+    {
+      int r_ = pr, c_ = pc;
+#pragma unroll
+      for (int i = 0; i < NL; i++) {
+        if (r_ < PH) {
+          const bool ok = (okm >> i) & 1;
+          float* d = patch + r_ * PITCH + c_ * 3;
+          d[0] = ok ? raw[i][0] : 0.f; d[1] = ok ? raw[i][1] : 0.f; d[2] = ok ? raw[i][2] : 0.f;
+        }
+        r_ += 256 / PW; c_ += 256 % PW;
+        if (c_ >= PW) { c_ -= PW; r_++; }
+      }
+    }
+  }
+  // operand maps: k = 4 step + q = (dy * 3 + dx) * 3 + ci; k = 27 is padding (zero weight, any finite pixel value)
+  float wa[7];
+  int off[7];
+#pragma unroll
+  for (int sidx = 0; sidx < 7; sidx++) {
+    const int k = 4 * sidx + q, kk = min(k, 26);
+    const int tap = kk / 3, ci = kk - tap * 3, dy = tap / 3, dx = tap - dy * 3;
+    wa[sidx] = k < 27 ? Ws[k * 16 + r] : 0.f;
+    off[sidx] = dy * PITCH + dx * 3 + ci;
+  }
+  const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + 4 * q);
+  __syncthreads();
+#pragma unroll
+  for (int gidx = 0; gidx < 4; gidx++) {   // this wave: rows 2 wave, 2 wave + 1; 32 pixels each = 2 groups of 16
+    const int ly = 2 * wave + (gidx >> 1), lx = (gidx & 1) * 16 + r;
+    const float* pb = patch + (2 * ly) * PITCH + (2 * lx) * 3;
+    f32x4 acc = bv;
+#pragma unroll
+    for (int sidx = 0; sidx < 7; sidx++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[sidx], pb[off[sidx]], acc, 0, 0, 0);
+    const int oy = ty * TH + ly, ox = tx * TW + lx;
+    if (oy < go.H && ox < go.W) {
+      f32x4 o = {act_apply(acc[0], act), act_apply(acc[1], act), act_apply(acc[2], act), act_apply(acc[3], act)};
+      *reinterpret_cast<f32x4*>(y + (go.off + (long long)oy * go.W + ox) * 16 + 4 * q) = o;
+    }
+  }
+}
+static const int g_stem_mfma = getenv("RT_STEM_MFMA") ? atoi(getenv("RT_STEM_MFMA")) : 1;   // A/B: 0 = thread-per-pixel stems
+
 void stem_conv_u8(hipStream_t st, const U8Page* pages, float scale, const float* mean3, const float* std3, const ImgGeom* gin,
                   const ImgGeom* gout, int n_img, int maxHo, int maxWo, int COUT, const float* Ws, const float* bias, int act,
                   float* y) {
   if (n_img <= 0) return;
   if (COUT != 16) throw RtError(8, "stem_conv_u8: unsupported COUT");
+  if (g_stem_mfma) {
+    dim3 gridm((unsigned)(((maxWo + 31) / 32) * ((maxHo + 7) / 8)), n_img);
+    RT_LAUNCH(k_stem_mfma<1>, gridm, dim3(256), 0, st, (const float*)nullptr, pages, scale, mean3[0], mean3[1], mean3[2], std3[0],
+              std3[1], std3[2], gin, gout, Ws, bias, act, y);
+    return;
+  }
   dim3 grid((unsigned)(((long long)maxHo * maxWo + 255) / 256), n_img);
   RT_LAUNCH(k_stem_u8<16>, grid, dim3(256), 0, st, pages, scale, mean3[0], mean3[1], mean3[2], std3[0], std3[1],
                      std3[2], gin, gout, Ws, bias, act, y);
@@ -1578,6 +1716,12 @@ void stem_conv_u8(hipStream_t st, const U8Page* pages, float scale, const float*
 void stem_conv(hipStream_t st, const float* x, const ImgGeom* gin, const ImgGeom* gout, int n_img, int maxHo, int maxWo,
                int COUT, const float* Ws, const float* bias, int act, float* y) {
   if (n_img <= 0) return;
+  if (COUT == 16 && g_stem_mfma) {
+    dim3 gridm((unsigned)(((maxWo + 31) / 32) * ((maxHo + 7) / 8)), n_img);
+    RT_LAUNCH(k_stem_mfma<0>, gridm, dim3(256), 0, st, x, (const U8Page*)nullptr, 0.f, 0.f, 0.f, 0.f, 1.f, 1.f, 1.f, gin, gout, Ws,
+              bias, act, y);
+    return;
+  }
   dim3 grid((unsigned)(((long long)maxHo * maxWo + 255) / 256), n_img);
   if (COUT == 16) RT_LAUNCH(k_stem<16>, grid, dim3(256), 0, st, x, gin, gout, Ws, bias, act, y);
   else if (COUT == 8) RT_LAUNCH(k_stem<8>, grid, dim3(256), 0, st, x, gin, gout, Ws, bias, act, y);
@@ -1638,19 +1782,24 @@ __global__ __launch_bounds__(256) void k_pool_partial(const float* __restrict__ 
   }
 }
 
-// block per image: mean -> fc1 -> relu -> fc2 -> hardsigmoid
+// block per image: mean -> fc1 -> relu -> fc2 -> hardsigmoid.  Round 4: every phase on all 256 threads (the first form summed the
+// chunks with one thread per channel and ran each hidden unit's C-long dot product on one thread: 14 us per launch, 23 launches
+// per C3 step) -- the chunk sums by 256 / C threads per channel, fc1 by 8 lanes per hidden unit (shuffle tree); every order of
+// summation is fixed by the thread layout: repeatable, and independent of the batch the image is in.
 __global__ __launch_bounds__(256) void k_se_fc(const float* __restrict__ partial, const ImgGeom* __restrict__ geom,
                                                int chunks_alloc, int C, int Cp, const float* __restrict__ w1,
                                                const float* __restrict__ b1, const float* __restrict__ w2,
                                                const float* __restrict__ b2, int Cr, float slope, int residual,
                                                float* __restrict__ scale, int strip_R, int strips_per_block,
                                                const float* __restrict__ Wlin, int Cin, int Cin_p) {
-  extern __shared__ float sm[];  // mean[Cp] + hid[Cr] (+ mean_in[Cin_p] when projecting)
+  extern __shared__ float sm[];  // mean[Cp] + hid[Cr + 4] + mean_in[Cin_p + 4] (when projecting) + red[256]
   float* mean = sm;
   float* hid = sm + Cp;
   float* mean_in = sm + Cp + Cr + 4;
+  float* red = mean_in + (Wlin ? Cin_p + 4 : 0);
   const ImgGeom g = geom[blockIdx.x];
   const long long npix = (long long)g.H * g.W;
+  const int tid = threadIdx.x;
   // partial sums come from k_pool_partial (POOL_PIX pixels each) or, strip_R > 0, from the blocks of the
   // depthwise kernel that produced the tensor (32 strips of strip_R x 4 pixels each)
   // ... or, strip_R < 0, from the 16 x 16-pixel tiles of the kernel that produced it (k_fpn_phase)
@@ -1658,44 +1807,69 @@ __global__ __launch_bounds__(256) void k_se_fc(const float* __restrict__ partial
                      : strip_R < 0 ? ((g.W + 15) >> 4) * ((g.H + 15) >> 4)
                                  : (int)((npix + POOL_PIX - 1) / POOL_PIX);
   const float inv = 1.0f / (float)npix;
+  {
+    // channel sums: Cs channels (of the narrow tensor when projecting), `parts` threads per channel each adding every parts-th
+    // chunk, then the parts in order
+    const int Cs = Wlin ? Cin_p : Cp;
+    float* dst = Wlin ? mean_in : mean;
+    const float* part = partial + (long long)blockIdx.x * chunks_alloc * Cs;
+    if (Cs <= 128) {
+      const int parts = 256 / Cs, c = tid % Cs, pp = tid / Cs;
+      float s0 = 0.f;
+      if (pp < parts)
+        for (int k = pp; k < chunks; k += parts) s0 += part[(long long)k * Cs + c];
+      red[tid] = s0;
+      __syncthreads();
+      if (tid < Cs) {
+        float t = 0.f;
+        for (int i = 0; i < parts; i++) t += red[i * Cs + tid];
+        dst[tid] = t * inv;
+      }
+    } else {
+      for (int c = tid; c < Cs; c += 256) {
+        float s0 = 0.f;
+        for (int k = 0; k < chunks; k++) s0 += part[(long long)k * Cs + c];
+        dst[c] = s0 * inv;
+      }
+    }
+    __syncthreads();
+  }
   if (Wlin) {
     // The pooled tensor is a bias-free 1x1 conv of a narrower one (FPN lateral: y = x . Wlin): mean(y) = mean(x) . Wlin,
     // so the partial sums are those of x (pitch Cin_p) and y itself never has to exist for the squeeze.
-    for (int c = threadIdx.x; c < Cin_p; c += 256) {
-      float s = 0.f;
-      for (int k = 0; k < chunks; k++) s += partial[((long long)blockIdx.x * chunks_alloc + k) * Cin_p + c];
-      mean_in[c] = s * inv;
+    for (int c = tid; c < Cp; c += 256) {
+      float s0 = 0.f;
+      if (c < C) for (int k = 0; k < Cin; k++) s0 = fmaf(mean_in[k], Wlin[k * C + c], s0);
+      mean[c] = s0;
     }
     __syncthreads();
-    for (int c = threadIdx.x; c < Cp; c += 256) {
-      float s = 0.f;
-      if (c < C) for (int k = 0; k < Cin; k++) s = fmaf(mean_in[k], Wlin[k * C + c], s);
-      mean[c] = s;
-    }
-  } else {
-    for (int c = threadIdx.x; c < Cp; c += 256) {
-      float s = 0.f;
-      for (int k = 0; k < chunks; k++) s += partial[((long long)blockIdx.x * chunks_alloc + k) * Cp + c];
-      mean[c] = s * inv;
-    }
   }
-  __syncthreads();
   if (w1 == nullptr) {  // plain global mean
-    for (int c = threadIdx.x; c < Cp; c += 256) scale[(long long)blockIdx.x * Cp + c] = mean[c];
+    for (int c = tid; c < Cp; c += 256) scale[(long long)blockIdx.x * Cp + c] = mean[c];
     return;
   }
-  for (int j = threadIdx.x; j < Cr; j += 256) {  // w1 [Cr][C]
-    float s = b1[j];
-    for (int c = 0; c < C; c++) s = fmaf(mean[c], w1[j * C + c], s);
-    hid[j] = fmaxf(s, 0.f);
+  {  // fc1, w1 [Cr][C]: 8 adjacent lanes per hidden unit, 32 units per pass
+    const int l = tid & 7;
+    for (int j0 = 0; j0 < Cr; j0 += 32) {
+      const int j = j0 + (tid >> 3);
+      float s0 = 0.f;
+      if (j < Cr) {
+        const float* wr = w1 + (long long)j * C;
+        for (int c = l; c < C; c += 8) s0 = fmaf(mean[c], wr[c], s0);
+      }
+      s0 += __shfl_xor(s0, 4); s0 += __shfl_xor(s0, 2); s0 += __shfl_xor(s0, 1);
+      if (j < Cr && l == 0) hid[j] = fmaxf(s0 + b1[j], 0.f);
+    }
   }
   __syncthreads();
-  for (int c = threadIdx.x; c < Cp; c += 256) {  // w2 [C][Cr]
+  for (int c = tid; c < Cp; c += 256) {  // w2 [C][Cr]
     float o = 0.f;
     if (c < C) {
-      float s = b2[c];
-      for (int j = 0; j < Cr; j++) s = fmaf(hid[j], w2[c * Cr + j], s);
-      o = fminf(fmaxf(fmaf(s, slope, 0.5f), 0.f), 1.f);
+      float s0 = b2[c];
+      const float* wr = w2 + (long long)c * Cr;
+#pragma unroll 4
+      for (int j = 0; j < Cr; j++) s0 = fmaf(hid[j], wr[j], s0);
+      o = fminf(fmaxf(fmaf(s0, slope, 0.5f), 0.f), 1.f);
       if (residual) o += 1.0f;
     }
     scale[(long long)blockIdx.x * Cp + c] = o;
@@ -1708,7 +1882,7 @@ void se_scale(hipStream_t st, const float* x, const ImgGeom* geom, int n_img, lo
   if (n_img <= 0) return;
   int chunks = pool_chunks(max_pix);
   RT_LAUNCH(k_pool_partial, dim3(chunks, n_img), dim3(256), 0, st, x, geom, Cp, chunks, partial);
-  RT_LAUNCH(k_se_fc, dim3(n_img), dim3(256), (Cp + Cr + 4) * sizeof(float), st, partial, geom, chunks, C, Cp,
+  RT_LAUNCH(k_se_fc, dim3(n_img), dim3(256), (Cp + Cr + 4 + 256) * sizeof(float), st, partial, geom, chunks, C, Cp,
                      w1, b1, w2, b2, Cr, slope, residual, scale, 0, 32, (const float*)nullptr, 0, 0);
 }
 void se_scale_projected(hipStream_t st, const float* x_in, const ImgGeom* geom, int n_img, long long max_pix, int Cin,
@@ -1717,7 +1891,7 @@ void se_scale_projected(hipStream_t st, const float* x_in, const ImgGeom* geom, 
   if (n_img <= 0) return;
   int chunks = pool_chunks(max_pix);
   RT_LAUNCH(k_pool_partial, dim3(chunks, n_img), dim3(256), 0, st, x_in, geom, Cin_p, chunks, partial);
-  RT_LAUNCH(k_se_fc, dim3(n_img), dim3(256), (Cp + Cr + 4 + Cin_p + 4) * sizeof(float), st, partial, geom, chunks, C, Cp,
+  RT_LAUNCH(k_se_fc, dim3(n_img), dim3(256), (Cp + Cr + 4 + Cin_p + 4 + 256) * sizeof(float), st, partial, geom, chunks, C, Cp,
                      w1, b1, w2, b2, Cr, slope, residual, scale, 0, 32, Wlin, Cin, Cin_p);
 }
 // Lanes side by side on a pixel in k_dwconv_rows for this layer: 16 / 32 (64- / 128-channel slabs) where the tensor is
@@ -1743,14 +1917,14 @@ void se_fc_from_dw(hipStream_t st, const float* partial, const ImgGeom* geom, in
                    int strips_per_block, int C, int Cp, const float* w1, const float* b1, const float* w2, const float* b2,
                    int Cr, float slope, int residual, float* scale) {
   if (n_img <= 0) return;
-  RT_LAUNCH(k_se_fc, dim3(n_img), dim3(256), (Cp + Cr + 4) * sizeof(float), st, partial, geom, chunks, C, Cp,
+  RT_LAUNCH(k_se_fc, dim3(n_img), dim3(256), (Cp + Cr + 4 + 256) * sizeof(float), st, partial, geom, chunks, C, Cp,
                      w1, b1, w2, b2, Cr, slope, residual, scale, strip_R, strips_per_block, (const float*)nullptr, 0, 0);
 }
 void se_fc_from_tiles(hipStream_t st, const float* partial, const ImgGeom* geom, int n_img, int tiles_alloc, int C, int Cp,
                       const float* w1, const float* b1, const float* w2, const float* b2, int Cr, float slope, int residual,
                       float* scale) {
   if (n_img <= 0) return;
-  RT_LAUNCH(k_se_fc, dim3(n_img), dim3(256), (Cp + Cr + 4) * sizeof(float), st, partial, geom, tiles_alloc, C, Cp,
+  RT_LAUNCH(k_se_fc, dim3(n_img), dim3(256), (Cp + Cr + 4 + 256) * sizeof(float), st, partial, geom, tiles_alloc, C, Cp,
                      w1, b1, w2, b2, Cr, slope, residual, scale, -16, 32, (const float*)nullptr, 0, 0);
 }
 void global_mean(hipStream_t st, const float* x, const ImgGeom* geom, int n_img, long long max_pix, int Cp,
@@ -1758,7 +1932,7 @@ void global_mean(hipStream_t st, const float* x, const ImgGeom* geom, int n_img,
   if (n_img <= 0) return;
   int chunks = pool_chunks(max_pix);
   RT_LAUNCH(k_pool_partial, dim3(chunks, n_img), dim3(256), 0, st, x, geom, Cp, chunks, partial);
-  RT_LAUNCH(k_se_fc, dim3(n_img), dim3(256), (Cp + 4) * sizeof(float), st, partial, geom, chunks, Cp, Cp,
+  RT_LAUNCH(k_se_fc, dim3(n_img), dim3(256), (Cp + 4 + 256) * sizeof(float), st, partial, geom, chunks, Cp, Cp,
                      (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, 0,
                      0.f, 0, out, 0, 32, (const float*)nullptr, 0, 0);
 }
@@ -1961,9 +2135,91 @@ __global__ __launch_bounds__(256) void k_db_head_tail(const float* __restrict__ 
     *reinterpret_cast<f32x4*>(out + go.off + (long long)(iy * 4 + r) * go.W + ix * 4) = v;
   }
 }
+// The same tail on the matrix cores (round 4).  Both transposed convs are per-pixel maps (2 x 2 kernels at stride 2 do not
+// overlap): 24 -> 4 x 24 -> 4 x 4 values, 2688 MACs per input pixel, which the VALU form above pays as scalar FMAs (0.22 ms per 32
+// pages for 0.3 GB of traffic).  v_mfma_f32_4x4x1_16B_f32 with the A-operand broadcast (as k_conv3_few: lane = pixel, D[i] =
+// output 4 g + i): the pixel's own 24 channels are the B operands straight from its registers, the weights come from LDS
+// ([position][output][k] rows, one ds_read_b128 per four k), the ReLU'd first-stage accumulators are the B operands of the second
+// stage.  672 MFMAs per 64 pixels; loads and stores are whole contiguous runs per wave.
+__global__ __launch_bounds__(256) void k_db_head_tail_mfma(const float* __restrict__ x, const ImgGeom* __restrict__ gin,
+                                                           const ImgGeom* __restrict__ gout, const float* __restrict__ w1,
+                                                           const float* __restrict__ b1, const float* __restrict__ w2,
+                                                           const float* __restrict__ b2, float* __restrict__ out) {
+  constexpr int RW = 28;
+  __shared__ __attribute__((aligned(16))) float sw1[4 * 24 * RW];  // [pos][co][ci]
+  __shared__ __attribute__((aligned(16))) float sw2[4 * RW];       // [pos2][co]
+  __shared__ __attribute__((aligned(16))) float sb1[24];
+  for (int i = threadIdx.x; i < 4 * 24 * 24; i += 256) {
+    const int pos = i / 576, co = (i / 24) % 24, ci = i % 24;
+    sw1[(pos * 24 + co) * RW + ci] = w1[(ci * 24 + co) * 4 + pos];
+  }
+  for (int i = threadIdx.x; i < 96; i += 256) { const int pos = i / 24, co = i % 24; sw2[pos * RW + co] = w2[co * 4 + pos]; }
+  if (threadIdx.x < 24) sb1[threadIdx.x] = b1[threadIdx.x];
+  const ImgGeom gi = gin[blockIdx.y], go = gout[blockIdx.y];
+  const long long npix = (long long)gi.H * gi.W;
+  const long long p = (long long)blockIdx.x * 256 + threadIdx.x;
+  const bool valid = p < npix;
+  const long long pc = valid ? p : npix - 1;
+  f32x4 in[6];
+  const f32x4* src = reinterpret_cast<const f32x4*>(x + (gi.off + pc) * 24);
+#pragma unroll
+  for (int i = 0; i < 6; i++) in[i] = src[i];
+  const float bias2 = b2[0];
+  __syncthreads();
+  if ((long long)blockIdx.x * 256 + (threadIdx.x & ~63) >= npix) return;   // whole wave past the image (after the only barrier)
+  const int lane = threadIdx.x & 63;
+  const float* w1r = sw1 + (lane < 24 ? lane : 0) * RW;
+  const float* w2r = sw2 + (lane < 4 ? lane : 0) * RW;
+  f32x4 bq[6];
+#pragma unroll
+  for (int g = 0; g < 6; g++) bq[g] = *reinterpret_cast<const f32x4*>(sb1 + g * 4);
+  f32x4 o[4];
+#pragma unroll
+  for (int pos1 = 0; pos1 < 4; pos1++) {
+    f32x4 mid[6];
+#pragma unroll
+    for (int g = 0; g < 6; g++) mid[g] = bq[g];
+#pragma unroll
+    for (int kk = 0; kk < 6; kk++) {
+      const f32x4 wv = *reinterpret_cast<const f32x4*>(w1r + pos1 * 24 * RW + kk * 4);
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        mid[0] = __builtin_amdgcn_mfma_f32_4x4x1f32(wv[e], in[kk][e], mid[0], 4, 0, 0);
+        mid[1] = __builtin_amdgcn_mfma_f32_4x4x1f32(wv[e], in[kk][e], mid[1], 4, 1, 0);
+        mid[2] = __builtin_amdgcn_mfma_f32_4x4x1f32(wv[e], in[kk][e], mid[2], 4, 2, 0);
+        mid[3] = __builtin_amdgcn_mfma_f32_4x4x1f32(wv[e], in[kk][e], mid[3], 4, 3, 0);
+        mid[4] = __builtin_amdgcn_mfma_f32_4x4x1f32(wv[e], in[kk][e], mid[4], 4, 4, 0);
+        mid[5] = __builtin_amdgcn_mfma_f32_4x4x1f32(wv[e], in[kk][e], mid[5], 4, 5, 0);
+      }
+    }
+    f32x4 s = {bias2, bias2, bias2, bias2};   // the four second-stage positions of this first-stage position
+#pragma unroll
+    for (int kk = 0; kk < 6; kk++) {
+      const f32x4 wv = *reinterpret_cast<const f32x4*>(w2r + kk * 4);
+#pragma unroll
+      for (int e = 0; e < 4; e++) s = __builtin_amdgcn_mfma_f32_4x4x1f32(wv[e], fmaxf(mid[kk][e], 0.f), s, 4, 0, 0);
+    }
+#pragma unroll
+    for (int e = 0; e < 4; e++) o[pos1][e] = __builtin_amdgcn_rcpf(1.0f + __expf(-s[e]));   // act_apply's sigmoid (v_exp + v_rcp, <= 2 ulp)
+  }
+  if (!valid) return;
+  const int iy = (int)(p / gi.W), ix = (int)(p - (long long)iy * gi.W);
+#pragma unroll
+  for (int r = 0; r < 4; r++) {   // output row r of the pixel's 4 x 4 block: first-stage row r >> 1, second-stage row r & 1
+    const int pa = (r >> 1) * 2, sb = (r & 1) * 2;
+    const f32x4 v = {o[pa][sb], o[pa][sb + 1], o[pa + 1][sb], o[pa + 1][sb + 1]};
+    *reinterpret_cast<f32x4*>(out + go.off + (long long)(iy * 4 + r) * go.W + ix * 4) = v;
+  }
+}
+static const int g_tail_mfma = getenv("RT_TAIL_MFMA") ? atoi(getenv("RT_TAIL_MFMA")) : 1;   // A/B: 0 = the VALU form
+
 void db_head_tail(hipStream_t st, const float* x, const ImgGeom* gin, const ImgGeom* gout, int n_img, long long max_pix,
                   const float* w1, const float* b1, const float* w2, const float* b2, float* out) {
   if (n_img <= 0) return;
+  if (g_tail_mfma) {
+    RT_LAUNCH(k_db_head_tail_mfma, dim3((unsigned)((max_pix + 255) / 256), n_img), dim3(256), 0, st, x, gin, gout, w1, b1, w2, b2, out);
+    return;
+  }
   RT_LAUNCH(k_db_head_tail, dim3((unsigned)((max_pix + 255) / 256), n_img), dim3(256), 0, st, x, gin, gout, w1,
                      b1, w2, b2, out);
 }
