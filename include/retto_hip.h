@@ -179,6 +179,20 @@ typedef void (*rt_stage_callback)(void* user, int page, int stage, const char* j
 RT_API int rt_run_batch_stream(rt_session* s, const uint8_t* const* rgb, const int* hs, const int* ws, int n_pages,
                                int mem, const float* const* det_map_override, rt_stage_callback cb, void* user,
                                rt_results** out);
+/* Asynchronous form of rt_run_batch (round 4) -- the counterpart of RettoSession::run_stream's worker thread + channel
+ * (session.rs:108-143): rt_submit_batch splits the pages over the session's lanes exactly as rt_run_batch does and returns at
+ * once; rt_wait_batch blocks until that batch is complete and returns its results (same object, same order, same values as
+ * rt_run_batch).  Up to RT_MAX_INFLIGHT batches may be submitted ahead: a lane works through its parts of consecutive batches
+ * back to back, so the host-side result assembly of batch i and the first kernels of batch i + 1 overlap with the other lanes'
+ * work.  The argument ARRAYS are copied by rt_submit_batch; the PAGES (and override maps) they point to must stay valid and
+ * unchanged until rt_wait_batch has returned for that ticket.  Every ticket must be waited for exactly once (any order); until
+ * then every other call on the session except rt_submit_batch / rt_wait_batch fails with RT_ERR_INVALID.  rt_wait_batch of a
+ * failed batch returns the failing stage's status (the other batches in flight are not affected). */
+#define RT_MAX_INFLIGHT 4
+typedef struct rt_ticket rt_ticket;
+RT_API int rt_submit_batch(rt_session* s, const uint8_t* const* rgb, const int* hs, const int* ws, int n_pages, int mem,
+                           const float* const* det_map_override, rt_ticket** out);
+RT_API int rt_wait_batch(rt_session* s, rt_ticket* ticket, rt_results** out);
 RT_API void rt_results_free(rt_results* r);
 RT_API int rt_results_pages(const rt_results* r);
 RT_API int rt_results_count(const rt_results* r, int page);

@@ -375,7 +375,7 @@ class RettoSession:
         return idx, pr, [tok[i, :tn[i]].copy() for i in range(n)], sc
 
     # -- pipeline ---------------------------------------------------------------------------
-    def run_batch_raw(self, pages, hs, ws, mem=RT_MEM_HOST, det_map_override=None):
+    def run_batch_raw(self, pages, hs, ws, mem=RT_MEM_HOST, det_map_override=None, submit=False):
         """pages: sequence of host arrays or device pointers (ints). Returns an opaque results handle."""
         lib, h = self._hd.lib, self._hd.h
         n = len(pages)
@@ -398,7 +398,22 @@ class RettoSession:
                 else:
                     ov[i] = int(m)
         out = C.c_void_p()
+        if submit:   # rt_submit_batch: returns (ticket, the arrays that must stay alive until wait_batch)
+            _check(lib.rt_submit_batch(h, arr_p, arr_h, arr_w, n, mem, ov, C.byref(out)), h)
+            return out, keep
         _check(lib.rt_run_batch(h, arr_p, arr_h, arr_w, n, mem, ov, C.byref(out)), h)
+        return out
+
+    def submit_batch_raw(self, pages, hs, ws, mem=RT_MEM_HOST, det_map_override=None):
+        """rt_submit_batch (the counterpart of RettoSession::run_stream's worker thread, session.rs:108-143): the batch is
+        split over the session's lanes and this returns at once with a ticket; wait_batch_raw(ticket) gives the results
+        handle.  Up to RT_MAX_INFLIGHT (4) batches ahead; nothing else may be called on the session in between."""
+        return self.run_batch_raw(pages, hs, ws, mem, det_map_override, submit=True)
+
+    def wait_batch_raw(self, ticket):
+        t, _keep = ticket
+        out = C.c_void_p()
+        _check(self._hd.lib.rt_wait_batch(self._hd.h, t, C.byref(out)), self._hd.h)
         return out
 
     def _collect(self, r, page: int) -> RettoWorkerResult:

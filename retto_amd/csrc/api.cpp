@@ -28,8 +28,14 @@ static void quiesce(rt_session* s) {
     if (h->st) (void)hipStreamSynchronize(h->st);
   (void)hipGetLastError();
 }
-template <typename F>
+// ALLOW_INFLIGHT: only rt_submit_batch / rt_wait_batch may run while submitted batches are in flight -- every other entry point
+// uses the main lane's stream and arenas, which lane 0's worker thread owns until the last ticket has been waited for.
+template <bool ALLOW_INFLIGHT = false, typename F>
 static int guarded(rt_session* s, F&& f) {
+  if (!ALLOW_INFLIGHT && s && s->inflight.load() > 0) {
+    s->last_error = "batches submitted with rt_submit_batch are in flight: call rt_wait_batch for every ticket first";
+    return RT_ERR_INVALID;
+  }
   try {
     f();
     return RT_OK;
@@ -93,6 +99,8 @@ int rt_create(const rt_config* cfg, rt_session** out) {
 void rt_destroy(rt_session* s) {
   if (!s) return;
   (void)hipSetDevice(s->device);
+  for (auto& w : s->workers) w->shutdown();   // lanes finish what was submitted (tickets never waited for are leaked, not raced)
+  s->workers.clear();
   if (s->st) { (void)hipStreamSynchronize(s->st); }
   for (auto& h : s->helpers) {
     if (h->st) (void)hipStreamSynchronize(h->st);
@@ -199,6 +207,20 @@ int rt_run_batch_stream(rt_session* s, const uint8_t* const* rgb, const int* hs,
   RT_REQUIRE(mem == RT_MEM_HOST || mem == RT_MEM_DEVICE, s, "rt_run_batch_stream: bad mem kind");
   *out = nullptr;
   return guarded(s, [&] { *out = s->run_batch(rgb, hs, ws, n_pages, mem, det_map_override, cb, user); });
+}
+int rt_submit_batch(rt_session* s, const uint8_t* const* rgb, const int* hs, const int* ws, int n_pages, int mem,
+                    const float* const* det_map_override, rt_ticket** out) {
+  RT_REQUIRE(s && out && n_pages >= 0 && (n_pages == 0 || (rgb && hs && ws)), s, "rt_submit_batch: bad argument");
+  RT_REQUIRE(mem == RT_MEM_HOST || mem == RT_MEM_DEVICE, s, "rt_submit_batch: bad mem kind");
+  RT_REQUIRE(s->inflight.load() < RT_MAX_INFLIGHT, s, "rt_submit_batch: too many batches in flight (RT_MAX_INFLIGHT)");
+  *out = nullptr;
+  return guarded<true>(s, [&] { *out = s->submit_batch(rgb, hs, ws, n_pages, mem, det_map_override); });
+}
+int rt_wait_batch(rt_session* s, rt_ticket* ticket, rt_results** out) {
+  RT_REQUIRE(s && ticket && out, s, "rt_wait_batch: bad argument");
+  *out = nullptr;
+  // (a failed batch: its own lanes have drained their streams in the worker; quiesce() in guarded() drains the rest)
+  return guarded<true>(s, [&] { *out = s->wait_batch(ticket); });
 }
 int rt_decode_image(const void* data, size_t len, uint8_t** rgb, int* h, int* w, char* err, size_t err_cap) {
   if (err && err_cap) err[0] = 0;

@@ -830,20 +830,54 @@ rt_results* rt_session::run_pages(const uint8_t* const* rgb, const int* hs, cons
 // Splits the pages over the lanes (contiguous ranges, order preserved) and runs the lanes on
 // concurrent host threads; every lane is a full pipeline on its own stream, so one lane's
 // small kernels, launch gaps and host sync points overlap the other lanes' large kernels.
-rt_results* rt_session::run_batch(const uint8_t* const* rgb, const int* hs, const int* ws, int n_pages, int mem,
-                                  const float* const* det_map_override, rt_stage_callback cb, void* user) {
+// ---------------------------------------------------------------------------
+// Lanes.  rt_run_batch splits the pages over the lanes; round 4: the lanes' host threads are persistent (round 3 created and
+// joined them on every call) and batches can be SUBMITTED ahead (rt_submit_batch / rt_wait_batch, the counterpart of
+// RettoSession::run_stream's worker thread + channel, session.rs:108-143): a lane that has finished its part of batch i starts
+// on batch i + 1 at once, so the lanes drift apart in phase and the call boundary (result assembly on the host, descriptors of
+// the next call) no longer idles the GPU.
+// ---------------------------------------------------------------------------
+void LaneWorker::start(int device) {
+  th = std::thread([this, device] {
+    (void)hipSetDevice(device);
+    for (;;) {
+      std::function<void()> f;
+      {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return stop || !q.empty(); });
+        if (q.empty()) return;   // stop requested and nothing left
+        f = std::move(q.front()); q.pop_front();
+      }
+      f();
+    }
+  });
+}
+void LaneWorker::push(std::function<void()> f) {
+  { std::lock_guard<std::mutex> lk(mu); q.push_back(std::move(f)); }
+  cv.notify_one();
+}
+void LaneWorker::shutdown() {
+  { std::lock_guard<std::mutex> lk(mu); stop = true; }
+  cv.notify_all();
+  if (th.joinable()) th.join();
+}
+void rt_session::ensure_workers() {
+  while (workers.size() < helpers.size() + 1) {
+    std::unique_ptr<LaneWorker> w(new LaneWorker());
+    w->start(device);
+    workers.push_back(std::move(w));
+  }
+}
+
+rt_ticket* rt_session::submit_batch(const uint8_t* const* rgb, const int* hs, const int* ws, int n_pages, int mem,
+                                    const float* const* det_map_override, rt_stage_callback cb, void* user) {
+  ensure_workers();
+  std::unique_ptr<rt_ticket> t(new rt_ticket());
   const int nl = std::max(1, std::min<int>(std::min<int>((int)helpers.size() + 1, active_lanes), std::max(n_pages, 1)));
-  std::mutex cb_mu;
-  auto arm = [&](rt_session* s, int base) { s->stage_cb = cb; s->stage_user = user; s->stage_mu = &cb_mu; s->page_base = base; };
-  struct Disarm {  // the callback never outlives the call
-    rt_session* self;
-    ~Disarm() { self->stage_cb = nullptr; self->stage_mu = nullptr; for (auto& h : self->helpers) { h->stage_cb = nullptr; h->stage_mu = nullptr; } }
-  } disarm{this};
-  arm(this, 0);
-  if (nl <= 1) return run_pages(rgb, hs, ws, n_pages, mem, det_map_override);
-  std::vector<rt_results*> parts((size_t)nl, nullptr);
-  std::vector<std::exception_ptr> errs((size_t)nl);
-  std::vector<int> first((size_t)nl + 1, 0);
+  t->nl = nl; t->n_pages = n_pages; t->mem = mem; t->cb = cb; t->user = user;
+  t->rgb.assign(rgb, rgb + n_pages); t->hs.assign(hs, hs + n_pages); t->ws.assign(ws, ws + n_pages);
+  if (det_map_override) t->maps.assign(det_map_override, det_map_override + n_pages);
+  t->parts.assign((size_t)nl, nullptr); t->errs.resize((size_t)nl); t->first.assign((size_t)nl + 1, 0);
   {
     // contiguous ranges of about equal work: det pixels after the session size limit (a2) plus a constant per page
     // for its lines; equal page counts when the pages are all one size
@@ -859,35 +893,77 @@ rt_results* rt_session::run_batch(const uint8_t* const* rgb, const int* hs, cons
     for (int i = 0; i < n_pages && l < nl; i++) {
       acc += cost[(size_t)i];
       // close range l-1 after page i once its share is reached, leaving at least one page for each later lane
-      if (acc >= total * l / nl - 1e-6 || n_pages - (i + 1) <= nl - l) first[l++] = i + 1;  // one range per page: none empty
+      if (acc >= total * l / nl - 1e-6 || n_pages - (i + 1) <= nl - l) t->first[l++] = i + 1;  // one range per page: none empty
     }
-    for (; l <= nl; l++) first[l] = n_pages;
-    for (int k = 1; k <= nl; k++) first[k] = std::max(first[k], first[k - 1]);
+    for (; l <= nl; l++) t->first[l] = n_pages;
+    for (int k = 1; k <= nl; k++) t->first[k] = std::max(t->first[k], t->first[k - 1]);
   }
-  auto work = [&](int l) {
-    rt_session* s = l == 0 ? this : helpers[(size_t)l - 1].get();
-    arm(s, first[l]);
-    try {
-      parts[l] = s->run_pages(rgb + first[l], hs + first[l], ws + first[l], first[l + 1] - first[l], mem,
-                              det_map_override ? det_map_override + first[l] : nullptr);
-    } catch (...) { errs[l] = std::current_exception(); }
-  };
-  std::vector<std::thread> th;
-  for (int l = 1; l < nl; l++) th.emplace_back(work, l);
-  work(0);
-  for (auto& t : th) t.join();
+  t->remaining = nl;
+  rt_ticket* tp = t.get();
+  inflight.fetch_add(1);
+  // parts go to consecutive lanes starting behind the previous batch's last one: batches that fill fewer lanes than the session
+  // has (single pages: one lane each) run side by side instead of queueing on lane 0
+  const int total_lanes = (int)helpers.size() + 1;
+  const int base = next_lane;
+  next_lane = (next_lane + nl) % total_lanes;
+  for (int l = 0; l < nl; l++) {
+    const int li = (base + l) % total_lanes;
+    rt_session* s = li == 0 ? this : helpers[(size_t)li - 1].get();
+    workers[(size_t)li]->push([tp, s, l] {
+      const int f0 = tp->first[l], f1 = tp->first[l + 1];
+      s->stage_cb = tp->cb; s->stage_user = tp->user; s->stage_mu = &tp->cb_mu; s->page_base = f0;
+      try {
+        tp->parts[l] = s->run_pages(tp->rgb.data() + f0, tp->hs.data() + f0, tp->ws.data() + f0, f1 - f0, tp->mem,
+                                    tp->maps.empty() ? nullptr : tp->maps.data() + f0);
+      } catch (...) {
+        tp->errs[l] = std::current_exception();
+        // work of the failed part may still be queued on the lane's stream: drain it before the lane's next job rewinds the
+        // arenas and the pinned staging it reads
+        if (s->st) (void)hipStreamSynchronize(s->st);
+        (void)hipGetLastError();
+      }
+      s->stage_cb = nullptr; s->stage_mu = nullptr;   // the callback never outlives the batch
+      { std::lock_guard<std::mutex> lk(tp->mu); tp->remaining--; }
+      tp->cv.notify_all();
+    });
+  }
+  return t.release();
+}
+
+rt_results* rt_session::wait_batch(rt_ticket* tp) {
+  std::unique_ptr<rt_ticket> t(tp);
+  {
+    std::unique_lock<std::mutex> lk(t->mu);
+    t->cv.wait(lk, [&] { return t->remaining == 0; });
+  }
+  inflight.fetch_sub(1);
   std::unique_ptr<rt_results> res(new rt_results());
   std::exception_ptr err;
-  for (int l = 0; l < nl; l++) {
-    if (errs[l] && !err) err = errs[l];
-    if (parts[l]) {
-      for (auto& p : parts[l]->pages) res->pages.push_back(std::move(p));
-      res->det_checksum += parts[l]->det_checksum;
-      delete parts[l];
+  for (int l = 0; l < t->nl; l++) {
+    if (t->errs[l] && !err) err = t->errs[l];
+    if (t->parts[l]) {
+      for (auto& p : t->parts[l]->pages) res->pages.push_back(std::move(p));
+      res->det_checksum += t->parts[l]->det_checksum;
+      delete t->parts[l];
     }
   }
   if (err) std::rethrow_exception(err);
   return res.release();
+}
+
+rt_results* rt_session::run_batch(const uint8_t* const* rgb, const int* hs, const int* ws, int n_pages, int mem,
+                                  const float* const* det_map_override, rt_stage_callback cb, void* user) {
+  const int nl = std::max(1, std::min<int>(std::min<int>((int)helpers.size() + 1, active_lanes), std::max(n_pages, 1)));
+  if (nl <= 1) {   // one lane: on the caller's thread (no hand-over in the single-page latency path)
+    std::mutex cb_mu;
+    struct Disarm {  // the callback never outlives the call
+      rt_session* self;
+      ~Disarm() { self->stage_cb = nullptr; self->stage_mu = nullptr; }
+    } disarm{this};
+    stage_cb = cb; stage_user = user; stage_mu = &cb_mu; page_base = 0;
+    return run_pages(rgb, hs, ws, n_pages, mem, det_map_override);
+  }
+  return wait_batch(submit_batch(rgb, hs, ws, n_pages, mem, det_map_override, cb, user));
 }
 
 // RettoWorkerStageResult JSON (serde derive shapes; retto-wasm/fe/index.ts:5-42)

@@ -2,10 +2,15 @@
 // (/root/reference/retto-core/src/session.rs:75-106) over a batch of pages, plus the
 // tensor-level worker entry points (worker.rs:69-73) and the stage functions.
 #pragma once
+#include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <deque>
+#include <functional>
 #include <memory>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/retto_hip.h"
@@ -27,6 +32,39 @@ struct rt_results {
   };
   std::vector<Page> pages;
   double det_checksum = 0.0;
+};
+
+// A lane's host thread: created once per session (rt_session::ensure_workers), parked on a condition variable between jobs.
+// Jobs run in submission order; a lane works through the parts of consecutive batches back to back, so the result assembly of
+// batch i (host) and the det phase of batch i + 1 overlap with the other lanes' kernels.
+struct LaneWorker {
+  std::thread th;
+  std::mutex mu;
+  std::condition_variable cv;
+  std::deque<std::function<void()>> q;
+  bool stop = false;
+  void start(int device);
+  void push(std::function<void()> f);
+  void shutdown();
+  ~LaneWorker() { shutdown(); }
+};
+
+// One submitted batch (rt_submit_batch): the argument arrays are copied (the PAGES must stay valid until rt_wait_batch), the
+// pages are split over the lanes exactly as rt_run_batch splits them, each lane leaves its part here.
+struct rt_ticket {
+  int nl = 0, n_pages = 0, mem = 0;
+  std::vector<const uint8_t*> rgb;
+  std::vector<int> hs, ws;
+  std::vector<const float*> maps;   // empty: no override
+  std::vector<int> first;
+  std::vector<rt_results*> parts;
+  std::vector<std::exception_ptr> errs;
+  rt_stage_callback cb = nullptr;
+  void* user = nullptr;
+  std::mutex cb_mu;                 // callbacks of concurrent lanes are serialised
+  std::mutex mu;
+  std::condition_variable cv;
+  int remaining = 0;
 };
 
 struct rt_session {
@@ -79,6 +117,14 @@ struct rt_session {
   void ctc_decode(const float* probs, int n, int t, int c, int32_t* idx, float* prob, int32_t* tokens,
                   int32_t* n_tokens, float* scores);
   // L2
+  // persistent lane threads (index 0 = this session's own lane) and the number of submitted, not yet waited batches
+  std::vector<std::unique_ptr<LaneWorker>> workers;
+  std::atomic<int> inflight{0};
+  int next_lane = 0;               // first lane of the next submitted batch
+  void ensure_workers();
+  rt_ticket* submit_batch(const uint8_t* const* rgb, const int* hs, const int* ws, int n_pages, int mem,
+                          const float* const* det_map_override, rt_stage_callback cb = nullptr, void* user = nullptr);
+  rt_results* wait_batch(rt_ticket* t);   // consumes the ticket
   rt_results* run_batch(const uint8_t* const* rgb, const int* hs, const int* ws, int n_pages, int mem,
                         const float* const* det_map_override, rt_stage_callback cb = nullptr, void* user = nullptr);
   rt_results* run_pages(const uint8_t* const* rgb, const int* hs, const int* ws, int n_pages, int mem,

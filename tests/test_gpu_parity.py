@@ -807,3 +807,51 @@ def test_fused_classifier_blocks_are_repeatable(hip_session):
     for _ in range(11):
         again = hip_session.worker.cls(x)
         assert np.array_equal(first.view(np.uint32), again.view(np.uint32))
+
+
+def test_submit_wait_equals_run_batch(hip_session):
+    """rt_submit_batch / rt_wait_batch (round 4; the counterpart of run_stream's worker thread, session.rs:108-143): three batches
+    of different composition submitted ahead on the persistent lane threads must give, ticket by ticket, exactly what
+    rt_run_batch gives for the same pages -- boxes, scores, labels, token ids bit for bit -- whatever order the tickets are
+    waited in; single-page batches are spread over the lanes; other calls are refused while tickets are open."""
+    import ctypes as C
+    lib, h = hip_session._hd.lib, hip_session._hd.h
+    batches = []
+    for b, (n, hh, ww) in enumerate(((7, 480, 640), (1, 320, 480), (5, 640, 480), (1, 352, 512))):
+        pages, maps = [], []
+        for i in range(n):
+            page, rects = workload.planted_page(hh, ww, 3 + (i + b) % 4, seed=100 * b + i)
+            dh, dw = R.resize_either_dims(hh, ww)
+            pages.append(page); maps.append(workload.planted_map(dh, dw, hh, ww, rects))
+        batches.append((pages, maps))
+
+    def digest(r, n):
+        out = []
+        for i in range(n):
+            k = lib.rt_results_count(r, i)
+            boxes = np.ctypeslib.as_array(lib.rt_results_boxes(r, i), (k, 8)).copy() if k else np.zeros((0, 8), np.float32)
+            rs = np.ctypeslib.as_array(lib.rt_results_rec_scores(r, i), (k,)).copy() if k else np.zeros(0, np.float32)
+            lab = np.ctypeslib.as_array(lib.rt_results_cls_labels(r, i), (k,)).copy() if k else np.zeros(0, np.uint16)
+            toks = []
+            for j in range(k):
+                tp = C.POINTER(C.c_int32)()
+                nt = lib.rt_results_rec_tokens(r, i, j, C.byref(tp))
+                toks.append(tuple(np.ctypeslib.as_array(tp, (nt,)).tolist()) if nt else ())
+            out.append((boxes.tobytes(), rs.view(np.uint32).tobytes(), lab.tobytes(), tuple(toks)))
+        return out
+
+    ref = []
+    for pages, maps in batches:
+        r = hip_session.run_batch_raw(pages, [p.shape[0] for p in pages], [p.shape[1] for p in pages], retto_amd.RT_MEM_HOST, maps)
+        ref.append(digest(r, len(pages))); lib.rt_results_free(r)
+        assert sum(len(d[3]) for d in ref[-1]) > 0
+    for order in ((0, 1, 2, 3), (3, 1, 0, 2)):
+        tickets = [hip_session.submit_batch_raw(pages, [p.shape[0] for p in pages], [p.shape[1] for p in pages], retto_amd.RT_MEM_HOST, maps)
+                   for pages, maps in batches]
+        with pytest.raises(retto_amd.RettoError):   # the session is busy until every ticket has been waited for
+            hip_session.worker.cls(np.zeros((1, 3, 48, 192), np.float32))
+        for b in order:
+            r = hip_session.wait_batch_raw(tickets[b])
+            assert digest(r, len(batches[b][0])) == ref[b], "batch %d differs between rt_run_batch and submit / wait" % b
+            lib.rt_results_free(r)
+    assert hip_session.worker.cls(np.zeros((1, 3, 48, 192), np.float32)).shape == (1, 2)
