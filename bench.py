@@ -370,10 +370,20 @@ def main():
     # ---- timed region: EXACTLY K steps at the production setting (concurrent lanes) -------
     on_host = a.pages_on == "host"
     barrier()
+    import resource
+    ru0 = resource.getrusage(resource.RUSAGE_SELF)
     t0 = time.perf_counter()
     run_steps(a.steps, on_host)
     barrier()
     elapsed = time.perf_counter() - t0
+    ru1 = resource.getrusage(resource.RUSAGE_SELF)
+    # host budget of one rank: CPU time (user + system, all threads) per step and the threads it keeps -- eight ranks share the
+    # node's CPUs (the pod on the MI355X box: 16), so a rank that needs more than cpus / 8 of a core-second per second is the limit
+    host_cpu_ms = 1000.0 * ((ru1.ru_utime - ru0.ru_utime) + (ru1.ru_stime - ru0.ru_stime)) / a.steps
+    try:
+        host_threads = int([ln for ln in open("/proc/self/status") if ln.startswith("Threads:")][0].split()[1])
+    except Exception:
+        host_threads = None
     # spread: the same K steps again, `--repeat` more times (each bracketed like the timed region); `value` stays the FIRST region
     rep_ms = [1000.0 * elapsed / a.steps]
     for _ in range(max(0, a.repeat)):
@@ -467,25 +477,12 @@ def main():
                            "digest_of_all_pages": hashlib.sha256("".join(g[1] for g in gathered).encode()).hexdigest()[:16]}
 
     # ---- work model of what ran (rank 0's pages) ------------------------------------------------------------
-    widths = []
+    widths, crops = [], []
     if a.lines > 0:
         res = []
         for c0 in range(0, n_my, 32):
             res += sess.run_batch(pages[c0:c0 + 32], det_map_override=maps[c0:c0 + 32])
-        for pr in res:
-            dims = []
-            for d in pr.det_result:
-                b = d.boxes.as_array().reshape(1, 8).astype(np.float32)
-                wv = np.zeros(1, np.int32); hv = np.zeros(1, np.int32)
-                lib.rt_crop_dims(b.ctypes.data, 1, wv.ctypes.data, hv.ctypes.data)
-                dims.append((int(hv[0]), int(wv[0])))
-            order = sorted(range(len(dims)), key=lambda i: -(dims[i][0] / dims[i][1]))
-            ratio = np.float32(320) / np.float32(48)
-            for s0 in range(0, len(order), 6):
-                idx = order[s0:s0 + 6]
-                for i in idx:
-                    ratio = max(ratio, np.float32(dims[i][1]) / np.float32(dims[i][0]))
-                widths += [lib.rt_resize_norm_width(48, 320, float(ratio))] * len(idx)
+        crops, widths = workmodel.line_geometry(lib, res)
     if a.models == "server":
         det_w, rec_w = workmodel.sdet_work(det_dims), workmodel.srec_work(widths)
     elif a.dtype == "f16":
@@ -493,11 +490,17 @@ def main():
     else:
         det_w, rec_w = workmodel.det_work(det_dims), workmodel.rec_work(widths)
     work = {k: dict(v) for k, v in det_w.items()}
-    for k, v in rec_w.items():
-        if k in work:
-            work[k]["bytes"] += v["bytes"]; work[k]["flops"] += v["flops"]
-        else:
-            work[k] = dict(v)
+    extra = [rec_w]
+    if a.models == "mobile" and a.dtype == "f32":   # the classifier and the u8 <-> f32 stages are priced for the fp32 path
+        extra += [workmodel.cls_work(len(crops)),
+                  workmodel.prepost_work([(p.shape[0], p.shape[1]) for p in pages], det_dims, crops, widths,
+                                         sum(workmodel.tokens_for_width(w_) for w_ in widths))]
+    for part in extra:
+        for k, v in part.items():
+            if k in work:
+                work[k]["bytes"] += v["bytes"]; work[k]["flops"] += v["flops"]
+            else:
+                work[k] = dict(v)
     psteps = min(a.steps, 20)
     nets = {name[4:]: ms / psteps for name, (ms, calls) in prof.items() if calls and name.startswith("net/")}
     fams = sorted(((ms, calls, name) for name, (ms, calls) in prof.items() if calls and not name.startswith("net/")), reverse=True)
@@ -557,6 +560,20 @@ def main():
                              "algorithmic_bytes_per_launch": int(bytes_per_launch),
                              "algorithmic_flops_per_launch": int(flops_per_launch)})
             break
+
+    # ---- the whole step against both roofs: every launch family's algorithmic FLOPs / bytes (retto_amd/workmodel.py) over the
+    #      PRODUCTION step time (the timed region, all lanes, batches in flight)
+    roofline_e2e = None
+    if work:
+        fl = sum(v["flops"] for v in work.values()); by = sum(v["bytes"] for v in work.values())
+        mfma_peak_e2e = FP16_PEAK_TFLOPS if a.dtype == "f16" else FP32_PEAK_TFLOPS
+        unpriced = sorted(name for _ms, _calls, name in fams if name not in work)
+        roofline_e2e = {"flops_per_step": int(fl), "bytes_per_step": int(by), "ms_per_step": round(ms_per_step, 3),
+                        "tflops": round(fl / (ms_per_step * 1e-3) / 1e12, 2), "frac_of_mfma_peak": round(fl / (ms_per_step * 1e-3) / 1e12 / mfma_peak_e2e, 4),
+                        "gbs": round(by / (ms_per_step * 1e-3) / 1e9, 1), "frac_of_hbm_peak": round(by / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                        "families_without_a_price": unpriced,
+                        "note": "sum over every launch family of the step as executed; the det FPN convs are priced by the upsampling-aware "
+                                "algorithm that runs (7.6 GFLOP per 960x960 page, 10.4 for the reference graph's convs)"}
 
     # ---- whole networks (HIP events around the det / cls / rec forward in the same serial pass) -----------
     # north_star's "DBNet-backbone achieved HBM": B_layer = 500 MB per 960x960 page (every conv layer's
@@ -641,12 +658,18 @@ def main():
                    "parallelism": "dp%d (pages sharded, no per-step collective)" % world,
                    "batches_in_flight": 1 if global_mode else max(1, a.inflight)},
         "roofline": roofline,
+        "roofline_e2e": roofline_e2e,
         "cpu_baseline": cpu_baseline,
         "networks": networks,
         "selfcheck": selfcheck,
     }
     out["repeat"] = {"ms_per_step": [round(x, 3) for x in rep_ms], "min": round(min(rep_ms), 3), "median": round(float(np.median(rep_ms)), 3),
                      "note": "the timed region (first entry, = ms_per_step) and %d more regions of %d steps on this rank" % (len(rep_ms) - 1, a.steps)}
+    out["host"] = {"cpu_ms_per_step": round(host_cpu_ms, 2), "cpu_cores_busy": round(host_cpu_ms / ms_per_step, 2), "threads": host_threads,
+                   "cpu_budget": lib.rt_host_cpu_budget(),
+                   "note": "rank 0, timed region: process CPU time (user + system, all threads) per step, the same as a fraction of one core "
+                           "(cpu_ms / ms_per_step), threads of the process, and rt_host_cpu_budget() = CPUs this process may plan with "
+                           "(affinity mask capped by the cgroup quota, / LOCAL_WORLD_SIZE)"}
     if sync_ms is not None:
         out["synchronous_calls"] = {"ms_per_step": round(sync_ms, 3), "value": round(n_my * world * 1000.0 / sync_ms, 3), "unit": "images/s",
                                     "note": "the same %d steps on this rank as one synchronous rt_run_batch per step (nothing submitted ahead: what rounds "

@@ -244,6 +244,11 @@ RT_API void rt_buffer_free(void* p);
  * rt_buffer_free.  Unknown / corrupt input: RT_ERR_IMAGE with the reason in err (optional).
  * rt_run_encoded_batch is RettoSession::run / run_stream (session.rs:108-143) over encoded
  * bytes: pages are decoded on host threads, then processed as by rt_run_batch_stream (cb may be NULL). */
+/* Host CPUs this process should plan with: the affinity mask capped by the cgroup CPU quota, divided by LOCAL_WORLD_SIZE (one
+ * process per GPU on a node).  rt_run_encoded_batch sizes its decode-thread pool with it (at most 16); std::thread::
+ * hardware_concurrency() would report the machine (256 on the MI355X box) to a pod that owns 16 CPUs.  No reference counterpart
+ * (retto-cli decodes on the calling thread, retto-cli/src/main.rs:80-86). */
+RT_API int rt_host_cpu_budget(void);
 RT_API int rt_decode_image(const void* data, size_t len, uint8_t** rgb, int* h, int* w, char* err, size_t err_cap);
 RT_API int rt_run_encoded_batch(rt_session* s, const void* const* files, const size_t* lens, int n_pages,
                                 rt_stage_callback cb, void* user, rt_results** out);

@@ -45,7 +45,7 @@ EXPORTS = [
     "rt_resize_both_dims", "rt_resize_both", "rt_det_input_dims", "rt_det_preprocess", "rt_det_postprocess",
     "rt_crop_dims", "rt_crop_images", "rt_scale_and_clip", "rt_resize_norm_width", "rt_resize_norm_image",
     "rt_ctc_decode",
-    "rt_run_batch", "rt_run_batch_stream", "rt_submit_batch", "rt_wait_batch", "rt_results_free", "rt_results_pages", "rt_results_count", "rt_results_boxes",
+    "rt_run_batch", "rt_run_batch_stream", "rt_submit_batch", "rt_wait_batch", "rt_host_cpu_budget", "rt_results_free", "rt_results_pages", "rt_results_count", "rt_results_boxes",
     "rt_results_det_scores", "rt_results_cls_labels", "rt_results_cls_scores", "rt_results_rec_scores",
     "rt_results_rec_tokens", "rt_results_rec_text", "rt_results_det_checksum", "rt_results_json",
     "rt_device_malloc", "rt_device_free", "rt_memcpy_h2d", "rt_memcpy_d2h", "rt_synchronize",

@@ -1,5 +1,6 @@
 // extern "C" surface of libretto_hip.so (include/retto_hip.h).
 #include <thread>
+#include <sched.h>
 #include <atomic>
 #include <cmath>
 #include <cstdio>
@@ -222,6 +223,27 @@ int rt_wait_batch(rt_session* s, rt_ticket* ticket, rt_results** out) {
   // (a failed batch: its own lanes have drained their streams in the worker; quiesce() in guarded() drains the rest)
   return guarded<true>(s, [&] { *out = s->wait_batch(ticket); });
 }
+int rt_host_cpu_budget(void) {
+  int n = (int)std::thread::hardware_concurrency();
+  cpu_set_t set;
+  CPU_ZERO(&set);
+  if (sched_getaffinity(0, sizeof(set), &set) == 0) { const int c = CPU_COUNT(&set); if (c > 0) n = c; }
+  double quota = 0.0;
+  if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {   // cgroup v2: "max <period>" or "<quota> <period>"
+    char q[64]; double per = 0.0;
+    if (fscanf(f, "%63s %lf", q, &per) == 2 && strcmp(q, "max") != 0 && per > 0) quota = atof(q) / per;
+    fclose(f);
+  } else {
+    double q = -1, per = 0;
+    if (FILE* fq = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) { if (fscanf(fq, "%lf", &q) != 1) q = -1; fclose(fq); }
+    if (FILE* fp = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(fp, "%lf", &per) != 1) per = 0; fclose(fp); }
+    if (q > 0 && per > 0) quota = q / per;
+  }
+  if (quota > 0) n = std::max(1, std::min(n, (int)(quota + 0.5)));
+  int ranks = 1;
+  if (const char* e = getenv("LOCAL_WORLD_SIZE")) ranks = std::max(1, atoi(e));
+  return std::max(1, n / ranks);
+}
 int rt_decode_image(const void* data, size_t len, uint8_t** rgb, int* h, int* w, char* err, size_t err_cap) {
   if (err && err_cap) err[0] = 0;
   if (!data || !rgb || !h || !w) { if (err && err_cap) snprintf(err, err_cap, "rt_decode_image: null argument"); return RT_ERR_INVALID; }
@@ -287,7 +309,9 @@ int rt_run_encoded_batch(rt_session* s, const void* const* files, const size_t* 
         } catch (...) { errs[(size_t)i] = std::current_exception(); }
       }
     };
-    const int nt = std::max(1, std::min<int>(n_pages, std::min<int>(16, (int)std::thread::hardware_concurrency())));
+    // decode threads: the CPUs this PROCESS may use (affinity mask capped by the cgroup quota -- the GPU box shows 256 logical
+    // CPUs to a pod that owns 16), shared among the ranks of the node (LOCAL_WORLD_SIZE: one process per GPU), at most 16
+    const int nt = std::max(1, std::min<int>(n_pages, std::min<int>(16, rt_host_cpu_budget())));
     std::vector<std::thread> th;
     for (int t = 1; t < nt; t++) th.emplace_back(work);
     work();

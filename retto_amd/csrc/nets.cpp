@@ -716,7 +716,7 @@ float* ClsNet::run(RunCtx& c, const float* x, Level& L0) {
       const int co = b.linear.N;
       float* y = c.arena->alloc<float>((size_t)Lout.total * co);
       float* dscr = b.se ? c.arena->alloc<float>((size_t)Lout.total * round_up(b.dw.C, 16)) : nullptr;
-      ProfScope ps(c.prof, c.st, "cls_block", shape_str(Lin.total, b.dw.C, co, b.dw.k * 100 + b.sh * 10 + (b.se ? 1 : 0)));
+      ProfScope ps(c.prof, c.st, "cls_block", shape_str(Lin.total, b.dw.C, co, cin * 1000 + b.dw.k * 100 + b.sh * 10 + (b.se ? 1 : 0)));
       nn::cls_block(c.st, b.dw.k, b.sh, b.se, b.act, t, Lin.d, Lout.d, Lout.n(), Lin.maxH, Lin.maxW, (int)Lout.maxPix, cin, b.dw.C, b.dw.Cp, co, b.expand.w,
                     b.expand.b, b.dw.w, b.dw.b, b.se ? b.sew.w1 : nullptr, b.se ? b.sew.b1 : nullptr, b.se ? b.sew.w2 : nullptr,
                     b.se ? b.sew.b2 : nullptr, b.se ? b.sew.Cr : 0, HSIG_MBV3, b.linear.w, b.linear.b, b.shortcut, y, dscr);

@@ -52,6 +52,14 @@ def lc_thin_fused(k: int, sh: int, sw: int, cin: int, cout: int, se: bool) -> bo
     return False
 
 
+def _adder():
+    w = defaultdict(lambda: {"bytes": 0.0, "flops": 0.0})
+
+    def add(fam, b, f=0.0):
+        w[fam]["bytes"] += b; w[fam]["flops"] += f
+    return w, add
+
+
 DET_GROUP_PX = 32 * 960 * 960   # session.cpp: det launch-group budget (det-input pixels)
 REC_GROUP_PX = 24000000         # session.cpp: rec launch-group budget (48 x W pixels)
 
@@ -67,8 +75,10 @@ def _groups(sizes, budget):
     return out
 
 
-def det_work(pages: Iterable[Tuple[int, int]]) -> Dict[str, Dict[str, float]]:
-    """pages: det-input (H, W) per page.  Returns family -> {bytes, flops}."""
+def det_work(pages: Iterable[Tuple[int, int]], phase=None) -> Dict[str, Dict[str, float]]:
+    """pages: det-input (H, W) per page.  Returns family -> {bytes, flops}.  phase: True = the launch series as executed since round
+    4 (nn_fpn.hip: upsampling-aware FPN convs, 7.59 GFLOP per 960x960 page), False = the reference graph's convs as rounds 1-3 ran
+    them (10.36 GFLOP); None = what the library does (RT_FPN_PHASE)."""
     w = defaultdict(lambda: {"bytes": 0.0, "flops": 0.0})
 
     def add(fam, b, f=0.0):
@@ -99,8 +109,11 @@ def det_work(pages: Iterable[Tuple[int, int]]) -> Dict[str, Dict[str, float]]:
                 if tn == name:
                     add("gemm_misc", h * ww * (tc + oc) * F + tc * oc * F, 2 * h * ww * tc * oc)
                     taps[j] = (h, ww, oc)
+        if phase is None:
+            phase = os.environ.get("RT_FPN_PHASE", "1") != "0"   # nn_fpn.hip: upsampling-aware forms of inp0 / inp1 / the head conv
         for j in range(4):
             h, ww, oc = taps[j]
+            cf = (oc + 3) // 4 * 4
             if j == 3:  # coarsest level: lateral GEMM, squeeze-excite pooled on its output and applied in place
                 add("gemm_misc", h * ww * (oc + 96) * F + oc * 96 * F, 2 * h * ww * oc * 96)
                 add("se_pool_fc", h * ww * 96 * F)
@@ -108,12 +121,31 @@ def det_work(pages: Iterable[Tuple[int, int]]) -> Dict[str, Dict[str, float]]:
             else:  # lateral conv + SE factor + top-down add in one pass (squeeze from the narrow tap tensor)
                 h2, w2, _ = taps[j + 1]
                 add("se_pool_fc", h * ww * oc * F)
-                add("lateral_add", (h * ww * (oc + 96) + h2 * w2 * 96) * F + oc * 96 * F, 2 * h * ww * oc * 96)
-            add("conv3x3", h * ww * (96 + 24) * F + 9 * 96 * 24 * F, 2 * h * ww * 9 * 96 * 24)
-            add("se_pool_fc", h * ww * 24 * F)
+                if not (phase and j == 0):   # the finest lateral tensor is never built on the phase path
+                    add("lateral_add", (h * ww * (oc + 96) + h2 * w2 * 96) * F + oc * 96 * F, 2 * h * ww * oc * 96)
+            if phase and j < 2:
+                # p_j = conv3x3(tap_j; per-image composed weights) + four 2x2 phase convs of in_{j+1}: FLOPs of the algorithm as
+                # executed (9 cf + 4 x 96 deep instead of 9 x 96)
+                h2, w2, _ = taps[j + 1]
+                add("fpn_compose", (oc * 96 + 9 * 24 * 96 + 9 * 24 * cf) * F, 2 * 9 * 24 * oc * 96)
+                add("conv3x3_phase", (h * ww * (cf + 24) + h2 * w2 * 96) * F + (9 * 24 * cf + 16 * 96 * 24) * F,
+                    2 * h * ww * 24 * (9 * cf + 4 * 96))
+                add("se_pool_fc", ((h + 15) // 16) * ((ww + 15) // 16) * 24 * F)
+            else:
+                add("conv3x3", h * ww * (96 + 24) * F + 9 * 96 * 24 * F, 2 * h * ww * 9 * 96 * 24)
+                add("se_pool_fc", h * ww * 24 * F)
         h4, w4, _ = taps[0]
-        add("fpn_concat", sum(taps[j][0] * taps[j][1] for j in range(4)) * 24 * F + h4 * w4 * 96 * F)
-        add("conv3x3", h4 * w4 * (96 + 24) * F + 9 * 96 * 24 * F, 2 * h4 * w4 * 9 * 96 * 24)
+        if phase:
+            # head conv: p2 at its own resolution (9 x 24 deep), p3 as phase convs (4 x 24), p4 / p5 through their class tensors
+            # (9 classes x <= 4 taps x 24 x 24 MACs per coarse pixel; written once, gathered once per output pixel)
+            (h3, w3, _), (h16, w16, _), (h32, w32, _) = taps[1], taps[2], taps[3]
+            add("fpn_class", ((h16 * w16 + h32 * w32) * (24 + 9 * 24) + h16 * w16 * 24) * F + 2 * 81 * 576 * F,
+                2 * (h16 * w16 + h32 * w32) * 25 * 576)
+            add("conv3x3_phase", (h4 * w4 * (24 + 24 + 24) + h3 * w3 * 24) * F + (9 * 24 * 24 + 16 * 24 * 24) * F,
+                2 * h4 * w4 * 24 * (9 * 24 + 4 * 24))
+        else:
+            add("fpn_concat", sum(taps[j][0] * taps[j][1] for j in range(4)) * 24 * F + h4 * w4 * 96 * F)
+            add("conv3x3", h4 * w4 * (96 + 24) * F + 9 * 96 * 24 * F, 2 * h4 * w4 * 9 * 96 * 24)
         add("db_head_tail", h4 * w4 * 24 * F + H * W * F, 2 * h4 * w4 * 4 * (24 * 24 + 4 * 24))
     return dict(w)
 
@@ -156,6 +188,95 @@ def rec_work(widths: Iterable[int], classes: int = synth.REC_CLASSES) -> Dict[st
         add("gemm_ctc_fc", T * 120 * F + 120 * classes * F + T * tiles * 12, 2 * T * 120 * classes)
         add("ctc_argmax", T * tiles * 12 + T * 8)
     return dict(w)
+
+
+def cls_work(n_crops: int, H: int = 48, W: int = 192) -> Dict[str, Dict[str, float]]:
+    """Angle classifier (MobileNetV3-small x0.35) over n_crops crops of H x W: one fused kernel per block (k_cls_block):
+    block input read + output written once (+ the depthwise scratch round trip of the squeeze-excite blocks), expand +
+    depthwise + linear FLOPs."""
+    w, add = _adder()
+    h, ww = _down(H, 2), _down(W, 2)
+    add("stem", n_crops * (H * W * 4 * F + h * ww * synth.CLS_STEM * F), n_crops * 2 * h * ww * 27 * synth.CLS_STEM)
+    cin = synth.CLS_STEM
+    for k, mid, cout, se, _act, sh, sw in synth.CLS_BLOCKS:
+        ho, wo = _down(h, sh), _down(ww, sw)
+        by = (h * ww * cin + ho * wo * cout) * F + (2 * ho * wo * mid * F if se else 0) + (cin * mid + k * k * mid + mid * cout) * F
+        fl = 2 * h * ww * cin * mid + 2 * ho * wo * mid * (k * k + cout)
+        add("cls_block", n_crops * by, n_crops * fl)
+        h, ww, cin = ho, wo, cout
+    add("gemm_cls", n_crops * (h * ww * (cin + synth.CLS_LAST) * F + 202 * F) + cin * synth.CLS_LAST * F,
+        n_crops * (2 * h * ww * cin * synth.CLS_LAST + 2 * synth.CLS_LAST * 2))
+    hp, wp = h // 2, ww // 2
+    add("maxpool", n_crops * (h * ww + hp * wp) * synth.CLS_LAST * F)
+    add("global_mean", n_crops * (hp * wp + 1) * synth.CLS_LAST * F)
+    add("softmax", n_crops * 6 * F)
+    return dict(w)
+
+
+def prepost_work(pages: Iterable[Tuple[int, int]], det_pages: Iterable[Tuple[int, int]], crops: Iterable[Tuple[int, int]],
+                 rec_widths: Iterable[int], tokens: int) -> Dict[str, Dict[str, float]]:
+    """The u8 <-> f32 stages around the networks, as executed.  pages: (H, W) after the size limits; det_pages: det-input dims;
+    crops: (h, w) of every text-line crop; rec_widths: padded width of every line tensor; tokens: time steps over all lines.
+    db_postprocess: the full-map passes of dbpost_kernels.hip per det pixel -- map read (4 B), mask written and read (1 + 1),
+    labels written (4) and read by the link / statistics / row-extent passes (3 x 4): 22 B; the per-contour geometry is not
+    bandwidth."""
+    w, add = _adder()
+    for (H, W), (dh, dw) in zip(pages, det_pages):
+        if (H, W) != (dh, dw):
+            add("thumbnail", (H * W + dh * dw) * 3)
+        add("db_postprocess", dh * dw * 22)
+    crops = list(crops)
+    crop_bytes = sum(h * ww_ * 3 for h, ww_ in crops)
+    add("warp_crops", 2 * crop_bytes, 0.0)                       # source pixels under the quad read once, crop written once
+    add("resize_norm", 2 * crop_bytes + len(crops) * 48 * 192 * 4 * F + sum(48 * wv * 4 * F for wv in rec_widths))  # cls + rec launches
+    add("cls_post_rotate", len(crops) * 16)
+    add("ctc_decode", tokens * 12)
+    return dict(w)
+
+
+def line_geometry(lib, results_per_page, rec_batch_num: int = 6, rec_h: int = 48, rec_w: int = 320):
+    """(crops, widths): the (h, w) of every text-line crop and the padded width of its recognition tensor, from the boxes of
+    RettoWorkerResult pages -- the session's own batching (rec_processor.rs:214-270: aspect-sorted chunks of rec_batch_num, running
+    max_wh_ratio), restated here so that the work model prices exactly the tensors the session built."""
+    import numpy as np
+    crops, widths = [], []
+    for pr in results_per_page:
+        dims = []
+        for d in pr.det_result:
+            b = d.boxes.as_array().reshape(1, 8).astype(np.float32)
+            wv = np.zeros(1, np.int32); hv = np.zeros(1, np.int32)
+            lib.rt_crop_dims(b.ctypes.data, 1, wv.ctypes.data, hv.ctypes.data)
+            dims.append((int(hv[0]), int(wv[0])))
+        crops += dims
+        order = sorted(range(len(dims)), key=lambda i: -(dims[i][0] / dims[i][1]))
+        ratio = np.float32(rec_w) / np.float32(rec_h)
+        for s0 in range(0, len(order), rec_batch_num):
+            idx = order[s0:s0 + rec_batch_num]
+            for i in idx:
+                ratio = max(ratio, np.float32(dims[i][1]) / np.float32(dims[i][0]))
+            widths += [lib.rt_resize_norm_width(rec_h, rec_w, float(ratio))] * len(idx)
+    return crops, widths
+
+
+def tokens_for_width(w: int) -> int:
+    wa = (w - 1) // 2 + 1
+    wc = (wa - 1) // 2 + 1
+    return (wc - 2) // 2 + 1 if wc >= 2 else 0
+
+
+def step_work(det_pages, crops, widths, pages=None) -> Dict[str, Dict[str, float]]:
+    """Every launch family of a mobile fp32 step: det + cls + rec networks and the u8 <-> f32 stages around them."""
+    det_pages = list(det_pages)
+    work: Dict[str, Dict[str, float]] = {}
+    parts = [det_work(det_pages), rec_work(widths), cls_work(len(crops)),
+             prepost_work(pages if pages is not None else det_pages, det_pages, crops, widths, sum(tokens_for_width(w) for w in widths))]
+    for part in parts:
+        for k, v in part.items():
+            if k in work:
+                work[k]["bytes"] += v["bytes"]; work[k]["flops"] += v["flops"]
+            else:
+                work[k] = dict(v)
+    return work
 
 
 def page_flops(det_hw: Tuple[int, int], widths: Iterable[int]) -> float:
@@ -214,14 +335,6 @@ def _neck16(add, T, C, classes):
     tiles = ((classes + 15) // 16 * 16 + 127) // 128
     add("gemm_ctc_fc", T * 120 * F + 120 * classes * F + T * tiles * 12, 2.0 * T * 120 * classes)
     add("ctc_argmax", T * tiles * 12 + T * 8)
-
-
-def _adder():
-    w = defaultdict(lambda: {"bytes": 0.0, "flops": 0.0})
-
-    def add(fam, b, f=0.0):
-        w[fam]["bytes"] += b; w[fam]["flops"] += f
-    return w, add
 
 
 def det16_work(pages: Iterable[Tuple[int, int]]) -> Dict[str, Dict[str, float]]:

@@ -855,3 +855,32 @@ def test_submit_wait_equals_run_batch(hip_session):
             assert digest(r, len(batches[b][0])) == ref[b], "batch %d differs between rt_run_batch and submit / wait" % b
             lib.rt_results_free(r)
     assert hip_session.worker.cls(np.zeros((1, 3, 48, 192), np.float32)).shape == (1, 2)
+
+
+def test_two_sessions_on_two_devices(hip_session):
+    """One process, two GPUs (what a multi-GPU host that does not use one process per GPU would do, and what the per-device
+    state of the library must survive: > 64 KB dynamic-LDS opt-in per (device, kernel), streams and arenas bound to the session's
+    device, lane threads that set their device): the same pages through a session on device 0 and one on device 1 give identical
+    results.  Skipped on a box with fewer than two GPUs (the round's GPU box has one)."""
+    import torch as _t
+    if _t.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs (hipGetDeviceCount() = %d)" % _t.cuda.device_count())
+    other = retto_amd.RettoSession(retto_amd.synthetic_session_config(0, device=1))
+    try:
+        pages, maps = [], []
+        for i in range(5):
+            page, rects = workload.planted_page(480, 640, 4, seed=40 + i)
+            dh, dw = R.resize_either_dims(480, 640)
+            pages.append(page); maps.append(workload.planted_map(dh, dw, 480, 640, rects))
+        a = hip_session.run_batch(pages, det_map_override=maps)
+        b = other.run_batch(pages, det_map_override=maps)
+        for pa, pb in zip(a, b):
+            assert len(pa.det_result) == len(pb.det_result) > 0
+            assert np.array_equal(np.stack([d.boxes.as_array() for d in pa.det_result]), np.stack([d.boxes.as_array() for d in pb.det_result]))
+            assert [c.label.label for c in pa.cls_result] == [c.label.label for c in pb.cls_result]
+            for ta, tb in zip(pa.rec_result, pb.rec_result):
+                assert np.array_equal(ta.tokens, tb.tokens) and ta.text == tb.text
+        x = np.random.default_rng(3).uniform(-1, 1, (1, 3, 320, 320)).astype(np.float32)
+        assert np.array_equal(hip_session.worker.det(x).view(np.uint32), other.worker.det(x).view(np.uint32))
+    finally:
+        other.close()

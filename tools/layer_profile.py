@@ -40,6 +40,15 @@ for _ in range(2):
 s.profile_enable(True)
 for _ in range(steps):
     lib.rt_results_free(s.run_batch_raw(d_pages, hs, hs, retto_amd.RT_MEM_DEVICE, d_maps))
+# families whose ProfScope carries no shape are priced from the work model of the workload that just ran (retto_amd/workmodel.py):
+# the family's algorithmic bytes / FLOPs per step over its launches per step
+fam_work = {}
+if not F16:
+    from retto_amd import workmodel
+    res1 = s.run_batch([workload.planted_page(960, 960, lines_n, seed=i)[0] for i in range(pages_n)],
+                       det_map_override=[workload.planted_map(960, 960, 960, 960, workload.planted_page(960, 960, lines_n, seed=i)[1]) for i in range(pages_n)]) if lines_n else []
+    crops, widths = workmodel.line_geometry(lib, res1) if lines_n else ([], [])
+    fam_work = workmodel.step_work([(960, 960)] * pages_n, crops, widths)
 rows = []
 for name, (ms, calls) in s.profile_get().items():
     if calls == 0 or name.startswith("net/"):
@@ -55,9 +64,24 @@ for name, (ms, calls) in s.profile_get().items():
             fl = 2.0 * a * b * c          # fp16 family: the MFMA side is what binds; bytes depend on the window and are left out
         elif fam.startswith("dwconv"):
             k = int(fam[-1]); by = (a + b) * c * 4.0; fl = 2.0 * b * c * k * k
+        elif fam == "conv3x3_phase":      # a output pixels, b = depth per output (9 cf + 4 cc), 24 outputs; d = 1: the head conv
+            fl = 2.0 * a * b * c
+            by = (a * (72.0 if d else (b - 384) / 9.0 + 24) + a / 4.0 * (24.0 if d else 96.0)) * 4.0
+        elif fam == "lc_thin":            # a OUTPUT pixels, b -> c channels, d = 10 sh + sw: the input has sh * sw times the pixels
+            sh, sw = d // 10, d % 10
+            by = (a * sh * sw * b + a * c) * 4.0
+            fl = 2.0 * a * b * (9 + c)
+        elif fam == "cls_block":          # a INPUT pixels, b = expanded channels, c = output channels, d = cin * 1000 + k * 100 + sh * 10 + se
+            cin, k, sh, se = d // 1000, (d // 100) % 10, (d // 10) % 10, d % 10
+            ao = a / sh
+            by = (a * cin + ao * c) * 4.0 + (2.0 * ao * b * 4.0 if se else 0.0)   # (+ the depthwise scratch round trip of an SE block)
+            fl = 2.0 * a * cin * b + 2.0 * ao * b * (k * k + c)
         else:
             by = a * (b + c) * 4.0 if not fam.startswith("conv3x3") else a * (96 + 24) * 4.0
             fl = 2.0 * a * b * c
+    elif fam in fam_work:
+        by = fam_work[fam]["bytes"] * steps / calls
+        fl = fam_work[fam]["flops"] * steps / calls
     rows.append((ms / steps, fam, shape, calls // steps, per, by / per / 1e6 if by else 0, fl / per / 1e6 if fl else 0))
 rows.sort(reverse=True)
 tot = sum(r[0] for r in rows)
