@@ -371,12 +371,28 @@ def main():
     on_host = a.pages_on == "host"
     barrier()
     import resource
+
+    def thread_cpu():
+        out = {}
+        try:
+            tck = os.sysconf("SC_CLK_TCK")
+            for tid in os.listdir("/proc/self/task"):
+                f = open("/proc/self/task/%s/stat" % tid).read()
+                name = f[f.index("(") + 1:f.rindex(")")]
+                fld = f[f.rindex(")") + 2:].split()
+                out[tid] = (name, (int(fld[11]) + int(fld[12])) / tck)
+        except Exception:
+            pass
+        return out
+    th0 = thread_cpu()
     ru0 = resource.getrusage(resource.RUSAGE_SELF)
     t0 = time.perf_counter()
     run_steps(a.steps, on_host)
     barrier()
     elapsed = time.perf_counter() - t0
     ru1 = resource.getrusage(resource.RUSAGE_SELF)
+    th1 = thread_cpu()
+    per_thread = sorted(((th1[t][1] - th0.get(t, (None, 0.0))[1], th1[t][0]) for t in th1), reverse=True)[:6]
     # host budget of one rank: CPU time (user + system, all threads) per step and the threads it keeps -- eight ranks share the
     # node's CPUs (the pod on the MI355X box: 16), so a rank that needs more than cpus / 8 of a core-second per second is the limit
     host_cpu_ms = 1000.0 * ((ru1.ru_utime - ru0.ru_utime) + (ru1.ru_stime - ru0.ru_stime)) / a.steps
@@ -667,6 +683,7 @@ def main():
                      "note": "the timed region (first entry, = ms_per_step) and %d more regions of %d steps on this rank" % (len(rep_ms) - 1, a.steps)}
     out["host"] = {"cpu_ms_per_step": round(host_cpu_ms, 2), "cpu_cores_busy": round(host_cpu_ms / ms_per_step, 2), "threads": host_threads,
                    "cpu_budget": lib.rt_host_cpu_budget(),
+                   "busiest_threads_cores": [[n_, round(dt / elapsed, 2)] for dt, n_ in per_thread if dt > 0],
                    "note": "rank 0, timed region: process CPU time (user + system, all threads) per step, the same as a fraction of one core "
                            "(cpu_ms / ms_per_step), threads of the process, and rt_host_cpu_budget() = CPUs this process may plan with "
                            "(affinity mask capped by the cgroup quota, / LOCAL_WORLD_SIZE)"}

@@ -106,11 +106,13 @@ void rt_destroy(rt_session* s) {
   for (auto& h : s->helpers) {
     if (h->st) (void)hipStreamSynchronize(h->st);
     if (h->d_flags) (void)hipFree(h->d_flags);
+    if (h->ev_block) (void)hipEventDestroy(h->ev_block);
     if (h->st) (void)hipStreamDestroy(h->st);
   }
   s->helpers.clear();
   s->det.reset(); s->cls.reset(); s->rec.reset();
   if (s->d_flags) (void)hipFree(s->d_flags);
+  if (s->ev_block) (void)hipEventDestroy(s->ev_block);
   if (s->st) (void)hipStreamDestroy(s->st);
   delete s;
 }

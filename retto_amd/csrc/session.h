@@ -71,6 +71,7 @@ struct rt_session {
   rt_config cfg{};
   int device = 0;
   hipStream_t st = nullptr;
+  hipEvent_t ev_block = nullptr;   // blocking-sync event behind sync(): the lane's host thread sleeps instead of spinning
   rt::Arena arena;      // lives for one API call: pages, maps, crops, descriptors, outputs
   rt::Arena scratch;    // network activations; rewound per launch group
   rt::Arena dbws;       // DB post-processing workspace (stream-ordered reuse across pages)
