@@ -243,6 +243,9 @@ __global__ __launch_bounds__(512, 1) void k_conv16v2(const ConvArgs2 c2) {
     mfmas(Af[0], Bf[0]);
     __builtin_amdgcn_sched_barrier(0);
     // ---- requests for later stages (the buffers they overwrite were last read before the barrier this wave just passed) ----
+    // (round 4: letting the upper four waves -- each shares a SIMD with wave w - 4 and leaves the barrier with it -- make their
+    //  requests two MFMA groups later, under the lower waves' MFMAs, changed nothing: 74.3 / 74.3 / 73.7 vs 74.1 / 74.6 / 73.7 ms
+    //  per C5 step; removed)
     if (rr + D < nrows) dma_wrow(rr + D);
     bool halo_now = false;
     if (c2.hbufs == 2) { if (dy == 0 && s + 1 < nslab) { dma_halo(s + 1); halo_now = true; } }

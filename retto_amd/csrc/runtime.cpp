@@ -16,6 +16,11 @@ void allow_big_lds(const void* kernel, int bytes) {
   static std::set<std::pair<int, const void*>> done;
   int dev = 0;
   RT_HIP_CHECK(hipGetDevice(&dev));
+  // fast path without the lock: what THIS thread has already seen set (a lane thread launches these kernels thousands of
+  // times per second; the three lanes of a session used to meet on the mutex eleven times per fp16 conv launch)
+  thread_local std::set<std::pair<int, const void*>> seen;
+  if (seen.count({dev, kernel})) return;
+  seen.insert({dev, kernel});
   std::lock_guard<std::mutex> lk(mu);
   if (done.count({dev, kernel})) return;
   RT_HIP_CHECK(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
