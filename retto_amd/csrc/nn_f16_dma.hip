@@ -236,9 +236,15 @@ __global__ __launch_bounds__(512, 1) void k_conv16v2(const ConvArgs2 c2) {
         for (int j = 0; j < NTP; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[i], B[j], acc[i][j], 0, 0, 0);
     };
     // (sched_barrier: hipcc otherwise sinks every fragment read down to its first use and waits lgkmcnt(0) there)
-    h8 Af[2][NTN], Bf[2][NTP];
+    // fragment ring of PF + 1 sets: the fragments of k-step it + PF are requested before the MFMAs of step it.  PF = 1.  (Round 4
+    // measured PF = 2 -- a step's reads get two MFMA groups instead of one to come back from LDS -- on every form that has the
+    // registers for a third set (NTN <= 3): 75.4 / 76.1 / 75.3 ms per C5 step against 73.0 / 73.7 / 73.8: the LDS read latency
+    // is not what the k-steps wait for.)
+    constexpr int PF = 1, NR = PF + 1;
+    h8 Af[NR][NTN], Bf[NR][NTP];
     frags(0, Af[0], Bf[0]);
     frags(1, Af[1], Bf[1]);
+    if (PF == 2) frags(2, Af[2 % NR], Bf[2 % NR]);
     __builtin_amdgcn_sched_barrier(0);
     mfmas(Af[0], Bf[0]);
     __builtin_amdgcn_sched_barrier(0);
@@ -253,9 +259,9 @@ __global__ __launch_bounds__(512, 1) void k_conv16v2(const ConvArgs2 c2) {
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int it = 1; it < NK; it++) {
-      if (it + 1 < NK) frags(it + 1, Af[(it + 1) & 1], Bf[(it + 1) & 1]);
+      if (it + PF < NK) frags(it + PF, Af[(it + PF) % NR], Bf[(it + PF) % NR]);
       __builtin_amdgcn_sched_barrier(0);
-      mfmas(Af[it & 1], Bf[it & 1]);
+      mfmas(Af[it % NR], Bf[it % NR]);
       __builtin_amdgcn_sched_barrier(0);
     }
     if (stamp) { a.stamps[rr * 5 + 2] = __builtin_amdgcn_s_memtime(); a.stamps[rr * 5 + 3] = a.stamps[rr * 5 + 2]; }
