@@ -30,7 +30,14 @@ constexpr int ROW = 28;                        // floats per LDS row: 24 channel
                                                // never share a 16-byte bank group within 8 lanes)
 constexpr int FT = 18 * 18, CT = 10 * 10;      // pixels of the fine halo tile (4 phase planes of 9 x 9) / the coarse halo tile
 constexpr int FW = 9 * 24, CW = 16 * 24;       // weight rows: fine 9 taps x 24 outputs; coarse 4 phases x 4 taps x 24 outputs
-constexpr int LDS_ROWS = (FT + FW) > (CT + CW) ? (FT + FW) : (CT + CW);
+// Tile images in LDS: a tile row (9 pixels of a phase plane, 10 of the coarse tile) has a pitch of 72 sixteen-byte slots = 288
+// floats, a pixel 7 slots.  ds_read_b128 serves the lanes in fixed groups of 16 ({0-3, 12-15, 20-27}, ...: MI355X_MICROARCH.md,
+// LDS): with lane = Y * 8 + X a group holds half-rows of four consecutive Y; their slots (8 Y + 7 X) mod 16 are all different
+// exactly when the row pitch is 8 mod 16 slots.  (The first version packed the rows at 63 / 70 slots: PMC showed 45 % of the
+// LDS cycles of these kernels as bank conflicts.)
+constexpr int TPITCH = 288, FPLANE = 9 * TPITCH;
+constexpr int FT_FLOATS = 4 * FPLANE, CT_FLOATS = 10 * TPITCH;
+constexpr int LDS_FLOATS = (FT_FLOATS + FW * ROW) > (CT_FLOATS + CW * ROW) ? (FT_FLOATS + FW * ROW) : (CT_FLOATS + CW * ROW);
 constexpr int NPF = 14, NPS = 8;               // prefetch registers (16-byte vectors) per thread: operands / scale vectors
 }  // namespace
 
@@ -44,7 +51,7 @@ constexpr int NPF = 14, NPS = 8;               // prefetch registers (16-byte ve
 template <int CF4, int NS, int HASG>
 __global__ __launch_bounds__(256, 2) void k_fpn_phase(FpnPhaseArgs a, const ImgGeom* __restrict__ gf,
                                                       const ImgGeom* __restrict__ gc) {
-  __shared__ __attribute__((aligned(16))) float lds[LDS_ROWS * ROW];
+  extern __shared__ __attribute__((aligned(16))) float lds[];   // LDS_FLOATS (65.7 KB: two workgroups per CU)
   const int img = blockIdx.y;
   const ImgGeom g = gf[img], gcs = gc[img];
   const int tiles_x = (g.W + 15) >> 4, tiles_y = (g.H + 15) >> 4;
@@ -116,11 +123,11 @@ __global__ __launch_bounds__(256, 2) void k_fpn_phase(FpnPhaseArgs a, const ImgG
       if (idx < FT * CF4) {
         const int hp = idx / CF4, c4 = idx - hp * CF4;
         const int hy = hp / 18, hx = hp - hy * 18;
-        const int e = ((hy & 1) * 2 + (hx & 1)) * 81 + (hy >> 1) * 9 + (hx >> 1);
+        const int e = ((hy & 1) * 2 + (hx & 1)) * FPLANE + (hy >> 1) * TPITCH + (hx >> 1) * ROW;
         f32x4 v = pf[i];
         if (a.fine_scale) v *= sf[i];
         if (!((vmask >> i) & 1)) v = f32x4{0.f, 0.f, 0.f, 0.f};
-        *reinterpret_cast<f32x4*>(lds + e * ROW + c4 * 4) = v;
+        *reinterpret_cast<f32x4*>(lds + e + c4 * 4) = v;
       }
     }
 #pragma unroll
@@ -128,7 +135,7 @@ __global__ __launch_bounds__(256, 2) void k_fpn_phase(FpnPhaseArgs a, const ImgG
       const int idx = tid + 256 * i;
       if (idx < FW * CF4) {
         const int row = idx / CF4, c4 = idx - row * CF4;
-        *reinterpret_cast<f32x4*>(lds + (FT + row) * ROW + c4 * 4) = pf[FXL + i];
+        *reinterpret_cast<f32x4*>(lds + FT_FLOATS + row * ROW + c4 * 4) = pf[FXL + i];
       }
     }
   };
@@ -164,21 +171,23 @@ __global__ __launch_bounds__(256, 2) void k_fpn_phase(FpnPhaseArgs a, const ImgG
       const int idx = tid + 256 * i;
       if (idx < CT * 6) {
         const int cp = idx / 6, c4 = idx - cp * 6;
+        const int cy = cp / 10, cx = cp - cy * 10;
         f32x4 v = pf[i];
         if (a.coarse_scale) v *= sf[i];
         if (!((vmask >> i) & 1)) v = f32x4{0.f, 0.f, 0.f, 0.f};
-        *reinterpret_cast<f32x4*>(lds + cp * ROW + c4 * 4) = v;
+        *reinterpret_cast<f32x4*>(lds + cy * TPITCH + cx * ROW + c4 * 4) = v;
       }
     }
 #pragma unroll
     for (int i = 0; i < CWL; i++) {
       const int idx = tid + 256 * i;
       const int row = idx / 6, c4 = idx - row * 6;
-      *reinterpret_cast<f32x4*>(lds + (CT + row) * ROW + c4 * 4) = pf[CXL + i];
+      *reinterpret_cast<f32x4*>(lds + CT_FLOATS + row * ROW + c4 * 4) = pf[CXL + i];
     }
   };
-  // A operand: lane 4 g + i holds output channel 4 g + i (lanes >= 24 are never selected by abid)
-  const int wl = lane < 24 ? lane : 0;
+  // A operand: lane 4 g + i holds output channel 4 g + i (lanes >= 24 are never selected by abid; they read rows that their
+  // ds_read_b128 lane group does not touch otherwise: no bank conflict from the idle lanes either)
+  const int wl = (lane & 31) < 24 ? (lane & 31) : (lane & 15);
 #define RT_FPN_MFMA6(av, bv)                                                             \
   acc[0] = __builtin_amdgcn_mfma_f32_4x4x1f32(av, bv, acc[0], 4, 0, 0);                  \
   acc[1] = __builtin_amdgcn_mfma_f32_4x4x1f32(av, bv, acc[1], 4, 1, 0);                  \
@@ -192,14 +201,14 @@ __global__ __launch_bounds__(256, 2) void k_fpn_phase(FpnPhaseArgs a, const ImgG
   __syncthreads();
   fetch_coarse(0);
   {
-    const float* xb = lds + (Y * 9 + X) * ROW;
-    const float* wb = lds + (FT + wl) * ROW;
+    const float* xb = lds + Y * TPITCH + X * ROW;
+    const float* wb = lds + FT_FLOATS + wl * ROW;
 #pragma unroll
     for (int dy = 0; dy < 3; dy++)
 #pragma unroll
       for (int dx = 0; dx < 3; dx++) {
         const int sy = py + dy, sx = px + dx;   // wave-uniform: halo-tile coordinates of this tap = (2 Y + sy, 2 X + sx)
-        const int toff = (((sy & 1) * 2 + (sx & 1)) * 81 + (sy >> 1) * 9 + (sx >> 1)) * ROW;
+        const int toff = ((sy & 1) * 2 + (sx & 1)) * FPLANE + (sy >> 1) * TPITCH + (sx >> 1) * ROW;
         const float* xr = xb + toff;
         const float* wr = wb + (dy * 3 + dx) * 24 * ROW;
 #pragma unroll
@@ -217,11 +226,11 @@ __global__ __launch_bounds__(256, 2) void k_fpn_phase(FpnPhaseArgs a, const ImgG
     stash_coarse();
     __syncthreads();
     if (s + 1 < NS) fetch_coarse(s + 1);
-    const float* cb = lds + (Y * 10 + X) * ROW;
-    const float* wb = lds + (CT + wave * 96 + wl) * ROW;
+    const float* cb = lds + Y * TPITCH + X * ROW;
+    const float* wb = lds + CT_FLOATS + (wave * 96 + wl) * ROW;
 #pragma unroll
     for (int t = 0; t < 4; t++) {
-      const int toff = ((py + (t >> 1)) * 10 + px + (t & 1)) * ROW;   // coarse pixel (Y + py + ty - 1, X + px + tx - 1), tile origin at -1
+      const int toff = (py + (t >> 1)) * TPITCH + (px + (t & 1)) * ROW;   // coarse pixel (Y + py + ty - 1, X + px + tx - 1), tile origin at -1
       const float* xr = cb + toff;
       const float* wr = wb + t * 24 * ROW;
 #pragma unroll
@@ -285,12 +294,15 @@ void fpn_phase(hipStream_t st, const FpnPhaseArgs& a, int cf, int cc, const ImgG
   if (n_img <= 0) return;
   const int cf4 = (cf + 3) / 4, ns = cc / 24;
   dim3 grid(((maxW + 15) / 16) * ((maxH + 15) / 16), n_img);
+  constexpr int LB = LDS_FLOATS * 4;
+  for (const void* f : {(const void*)k_fpn_phase<6, 1, 1>, (const void*)k_fpn_phase<3, 4, 0>, (const void*)k_fpn_phase<5, 4, 0>, (const void*)k_fpn_phase<6, 1, 0>})
+    allow_big_lds(f, LB);
   if (a.G) {
-    if (cf4 == 6 && ns == 1) { RT_LAUNCH((k_fpn_phase<6, 1, 1>), grid, dim3(256), 0, st, a, gf, gc); return; }
+    if (cf4 == 6 && ns == 1) { RT_LAUNCH((k_fpn_phase<6, 1, 1>), grid, dim3(256), LB, st, a, gf, gc); return; }
   } else {
-    if (cf4 == 3 && ns == 4) { RT_LAUNCH((k_fpn_phase<3, 4, 0>), grid, dim3(256), 0, st, a, gf, gc); return; }
-    if (cf4 == 5 && ns == 4) { RT_LAUNCH((k_fpn_phase<5, 4, 0>), grid, dim3(256), 0, st, a, gf, gc); return; }
-    if (cf4 == 6 && ns == 1) { RT_LAUNCH((k_fpn_phase<6, 1, 0>), grid, dim3(256), 0, st, a, gf, gc); return; }
+    if (cf4 == 3 && ns == 4) { RT_LAUNCH((k_fpn_phase<3, 4, 0>), grid, dim3(256), LB, st, a, gf, gc); return; }
+    if (cf4 == 5 && ns == 4) { RT_LAUNCH((k_fpn_phase<5, 4, 0>), grid, dim3(256), LB, st, a, gf, gc); return; }
+    if (cf4 == 6 && ns == 1) { RT_LAUNCH((k_fpn_phase<6, 1, 0>), grid, dim3(256), LB, st, a, gf, gc); return; }
   }
   throw RtError(8, "fpn_phase: no instance for this channel split");
 }
@@ -324,7 +336,7 @@ __global__ __launch_bounds__(256) void k_fpn_class(const float* __restrict__ z, 
   const bool valid = p < npix;
   const long long pc = valid ? p : npix - 1;
   const int y = (int)(pc / g.W), x = (int)(pc - (long long)y * g.W);
-  const int lane = tid & 63, wl = lane < 24 ? lane : 0;
+  const int lane = tid & 63, wl = (lane & 31) < 24 ? (lane & 31) : (lane & 15);   // (idle lanes on rows their ds_read_b128 group does not use: no bank conflict)
   const int ry0 = rc == 0 ? -1 : 0, ry1 = rc == 2 ? 1 : 0, rx0 = cc == 0 ? -1 : 0, rx1 = cc == 2 ? 1 : 0;
   // slot (ty, tx) -> relative pixel (ty ? ry1 : ry0, tx ? rx1 : rx0); a slot that repeats the previous one is skipped
   const bool two_y = ry1 != ry0, two_x = rx1 != rx0;

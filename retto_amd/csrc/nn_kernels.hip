@@ -1423,6 +1423,14 @@ void dwconv(hipStream_t st, int K, int sh, int sw, const float* x, const ImgGeom
       else RT_LAUNCH((k_dwconv_sweep<5, 16, 2, 4>), grids, dim3(256), 0, st, x, gin, gout, Cp, C, Wd, bias, act, has_lab, lab_a, lab_c, y);
       return;
     }
+    // (round 4) the same sweep for the 3x3 stride-1 layer on the 12-row, 128-channel maps of the recognition net: k_dwconv_rows
+    // fetched 1.33x its output there (6-row patches of 4-row strips, PMC)
+    if (g_dw_sweep && K == 3 && sh == 1 && sw == 1 && !pool && lp == 16 && maxHo >= 3 && maxHo <= 24) {
+      const int spb = 256 / 16;
+      dim3 grids((unsigned)(((maxWo + 3) / 4 + spb - 1) / spb), n_img, (Cp + 63) / 64);
+      RT_LAUNCH((k_dwconv_sweep<3, 16, 4, 4>), grids, dim3(256), 0, st, x, gin, gout, Cp, C, Wd, bias, act, has_lab, lab_a, lab_c, y);
+      return;
+    }
     if (lp != 8) {
       const int spb = 256 / lp;
       dim3 gridw((unsigned)((strips + spb - 1) / spb), n_img, (Cp + lp * 4 - 1) / (lp * 4));

@@ -37,9 +37,6 @@ for i in range(pages_n):
 hs = [960] * pages_n
 for _ in range(2):
     lib.rt_results_free(s.run_batch_raw(d_pages, hs, hs, retto_amd.RT_MEM_DEVICE, d_maps))
-s.profile_enable(True)
-for _ in range(steps):
-    lib.rt_results_free(s.run_batch_raw(d_pages, hs, hs, retto_amd.RT_MEM_DEVICE, d_maps))
 # families whose ProfScope carries no shape are priced from the work model of the workload that just ran (retto_amd/workmodel.py):
 # the family's algorithmic bytes / FLOPs per step over its launches per step
 fam_work = {}
@@ -49,6 +46,9 @@ if not F16:
                        det_map_override=[workload.planted_map(960, 960, 960, 960, workload.planted_page(960, 960, lines_n, seed=i)[1]) for i in range(pages_n)]) if lines_n else []
     crops, widths = workmodel.line_geometry(lib, res1) if lines_n else ([], [])
     fam_work = workmodel.step_work([(960, 960)] * pages_n, crops, widths)
+s.profile_enable(True)
+for _ in range(steps):
+    lib.rt_results_free(s.run_batch_raw(d_pages, hs, hs, retto_amd.RT_MEM_DEVICE, d_maps))
 rows = []
 for name, (ms, calls) in s.profile_get().items():
     if calls == 0 or name.startswith("net/"):
