@@ -299,8 +299,10 @@ RT_API int rt_debug_conv16(rt_session* s, const float* x, int n, int cin, int h,
 /* times nn::gemm (M x K x N, random data) over `iters` launches on the session's stream and
  * returns the average ms and the max |diff| against variant 0 */
 RT_API int rt_bench_gemm(rt_session* s, long long M, int K, int N, int variant, int iters, float* ms_out, float* maxdiff_out);
-/* times the fused thin LCNetV3 block (3x3 depthwise -> 1x1 conv; n images of h x w, random data): form 0 = LDS-staged kernel,
- * 1 = one-wave-per-tile kernel; returns the average ms and the max |diff| against form 0 */
+/* times the fused thin LCNetV3 block (3x3 depthwise -> 1x1 conv; n images of h x w, random data).  form: 0 = k_lc_thin
+ * (workgroup-staged; the unfused depthwise + GEMM pair where it has no instance), 1 = k_lc_wave (direct loads, stride 1 only),
+ * 3 = k_lc_lds (production), 5 = k_lc_lds incl. the opt-in 128 -> 128 split.  stride: 1, 2, or 21 = (2, 1).  Returns the average
+ * ms and the max |diff| against form RT_BENCH_LC_REF (environment, default 0); RT_BENCH_LC_DUMP=1 prints where they differ. */
 RT_API int rt_bench_lc(rt_session* s, int n, int h, int w, int cin, int cout, int stride, int form, int iters, float* ms_out, float* maxdiff_out);
 
 #ifdef __cplusplus

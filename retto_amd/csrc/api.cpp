@@ -16,6 +16,7 @@
 using namespace rt;
 
 static thread_local std::string g_create_error;
+static void capture_variant_defaults();   // the A/B switches' load-time values (rt_debug_set_variants restores to them)
 const char* rt_results_json_impl(rt_results* r, int page, int stage);
 
 // A call that fails after work was enqueued must not leave kernels or H2D copies in flight: the next
@@ -62,6 +63,18 @@ static int guarded(rt_session* s, F&& f) {
     }                                                                         \
   } while (0)
 
+// RAII for the diagnostic hooks below: a process-wide A/B switch is put back and the scratch buffers are freed on EVERY way
+// out of the hook (an RT_HIP_CHECK that throws used to leave the switch at the benchmark's value for every later call).
+namespace {
+struct RestoreInt { int& ref; int old; explicit RestoreInt(int& r) : ref(r), old(r) {} ~RestoreInt() { ref = old; } };
+struct DevBufs {
+  std::vector<void*> p;
+  template <typename T> T* alloc(size_t n) { void* q = nullptr; RT_HIP_CHECK(hipMalloc(&q, std::max<size_t>(n, 1) * sizeof(T))); p.push_back(q); return (T*)q; }
+  ~DevBufs() { for (void* q : p) (void)hipFree(q); }
+};
+struct Events { hipEvent_t a = nullptr, b = nullptr; ~Events() { if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); } };
+}  // namespace
+
 extern "C" {
 
 void rt_config_default(rt_config* c) {
@@ -95,6 +108,7 @@ int rt_create(const rt_config* cfg, rt_session** out) {
   RT_REQUIRE(cfg->dtype == RT_DTYPE_F32 || cfg->dtype == RT_DTYPE_F16, (rt_session*)nullptr, "dtype must be RT_DTYPE_F32 or RT_DTYPE_F16");
   RT_REQUIRE(cfg->max_boxes_per_page >= 0 && cfg->max_boxes_per_page <= 65536, (rt_session*)nullptr,
              "max_boxes_per_page must be in [0, 65536]");
+  capture_variant_defaults();
   return guarded(nullptr, [&] { *out = rt_session_create(cfg); });
 }
 void rt_destroy(rt_session* s) {
@@ -422,7 +436,19 @@ size_t rt_model_manifest(int which, char* buf, size_t cap) {
 }
 
 // A/B switches for tools/ (include/retto_hip.h, diagnostics section)
+// what the environment selected when the library was loaded (dynamic initialisation runs after the nn:: globals of the other
+// translation units only by luck of link order, so these are read on the first call of rt_create -- before any hook can have
+// changed them -- see capture_variant_defaults())
+static int g_default_lc_wave = 3, g_default_gemm_dma = 1, g_default_dw_sweep = 4, g_default_cls_fused = 1;
+static void capture_variant_defaults() {
+  static const bool once = [] {
+    g_default_lc_wave = nn::g_lc_wave; g_default_gemm_dma = nn::g_gemm_dma; g_default_dw_sweep = nn::g_dw_sweep; g_default_cls_fused = nn::g_cls_fused;
+    return true;
+  }();
+  (void)once;
+}
 RT_API void rt_debug_set_variants(int gemm_variant, int dw_variant, int flags) {
+  capture_variant_defaults();
   nn::g_gemm_variant = gemm_variant;
   nn::g_dw_variant = dw_variant;
   nn::g_lc_thin = (flags & 2) ? 0 : ((flags & 4) ? 2 : 4);
@@ -432,7 +458,7 @@ RT_API void rt_debug_set_variants(int gemm_variant, int dw_variant, int flags) {
   nn::g_dw_wide_lp = (flags & 32) ? 32 : 16;
   nn::g_argmax_wide = (flags & 64) ? 2 : 0;
   // round-3 kernels: bits 7-9 send their layers back to the kernels they replaced (defaults = what the environment selected at load)
-  static const int lc_wave0 = nn::g_lc_wave, gemm_dma0 = nn::g_gemm_dma, dw_sweep0 = nn::g_dw_sweep, cls_fused0 = nn::g_cls_fused;
+  const int lc_wave0 = g_default_lc_wave, gemm_dma0 = g_default_gemm_dma, dw_sweep0 = g_default_dw_sweep, cls_fused0 = g_default_cls_fused;
   nn::g_lc_wave = (flags & 128) ? 0 : lc_wave0;
   nn::g_gemm_dma = (flags & 256) ? 0 : gemm_dma0;
   nn::g_dw_sweep = (flags & 512) ? 0 : dw_sweep0;
@@ -521,10 +547,10 @@ RT_API int rt_bench_gemm(rt_session* s, long long M, int K, int N, int variant, 
     auto rnd = [&]() { st = st * 1664525u + 1013904223u; return ((st >> 8) & 0xffff) / 32768.0f - 1.0f; };
     for (long long m = 0; m < M; m++) for (int k = 0; k < K; k++) ha[(size_t)m * lda + k] = rnd();
     for (int k = 0; k < K; k++) for (int n = 0; n < N; n++) hw[((size_t)(k / nn::KC) * Np + n) * nn::KC + k % nn::KC] = rnd() * 0.1f;
-    float *dA, *dW, *dB, *dC, *dC0;
-    RT_HIP_CHECK(hipMalloc((void**)&dA, ha.size() * 4)); RT_HIP_CHECK(hipMalloc((void**)&dW, hw.size() * 4));
-    RT_HIP_CHECK(hipMalloc((void**)&dB, hb.size() * 4)); RT_HIP_CHECK(hipMalloc((void**)&dC, (size_t)M * ldc * 4));
-    RT_HIP_CHECK(hipMalloc((void**)&dC0, (size_t)M * ldc * 4));
+    DevBufs bufs;
+    RestoreInt keep_variant(nn::g_gemm_variant);
+    float *dA = bufs.alloc<float>(ha.size()), *dW = bufs.alloc<float>(hw.size()), *dB = bufs.alloc<float>(hb.size()),
+          *dC = bufs.alloc<float>((size_t)M * ldc), *dC0 = bufs.alloc<float>((size_t)M * ldc);
     RT_HIP_CHECK(hipMemset(dC, 0, (size_t)M * ldc * 4)); RT_HIP_CHECK(hipMemset(dC0, 0, (size_t)M * ldc * 4));
     RT_HIP_CHECK(hipMemcpy(dA, ha.data(), ha.size() * 4, hipMemcpyHostToDevice));
     RT_HIP_CHECK(hipMemcpy(dW, hw.data(), hw.size() * 4, hipMemcpyHostToDevice));
@@ -533,12 +559,12 @@ RT_API int rt_bench_gemm(rt_session* s, long long M, int K, int N, int variant, 
     nn::g_gemm_variant = 1; nn::gemm(s->st, dA, lda, M, Kp, dW, N, Np, dC0, ldc, 0, e);
     nn::g_gemm_variant = variant;
     nn::gemm(s->st, dA, lda, M, Kp, dW, N, Np, dC, ldc, 0, e);
-    hipEvent_t a, b; RT_HIP_CHECK(hipEventCreate(&a)); RT_HIP_CHECK(hipEventCreate(&b));
+    Events ev; RT_HIP_CHECK(hipEventCreate(&ev.a)); RT_HIP_CHECK(hipEventCreate(&ev.b));
+    hipEvent_t a = ev.a, b = ev.b;
     RT_HIP_CHECK(hipEventRecord(a, s->st));
     for (int i = 0; i < iters; i++) nn::gemm(s->st, dA, lda, M, Kp, dW, N, Np, dC, ldc, 0, e);
     RT_HIP_CHECK(hipEventRecord(b, s->st));
     RT_HIP_CHECK(hipStreamSynchronize(s->st));
-    nn::g_gemm_variant = 0;
     float ms = 0; RT_HIP_CHECK(hipEventElapsedTime(&ms, a, b)); *ms_out = ms / iters;
     if (maxdiff_out) {
       // the first and the last 4 M elements (the last row block is the partial one)
@@ -551,13 +577,13 @@ RT_API int rt_bench_gemm(rt_session* s, long long M, int K, int N, int variant, 
       }
       *maxdiff_out = md;
     }
-    (void)hipEventDestroy(a); (void)hipEventDestroy(b);
-    (void)hipFree(dA); (void)hipFree(dW); (void)hipFree(dB); (void)hipFree(dC); (void)hipFree(dC0);
   });
 }
 
 // Kernel micro-benchmark: the fused thin LCNetV3 block (3x3 depthwise -> pointwise) on n images of h x w pixels, random data.
-// form 0 = k_lc_thin (LDS staged), 1 = k_lc_wave; maxdiff compares with form 0.
+// form = nn::g_lc_wave for the timed launches: 0 = k_lc_thin (workgroup-staged; the unfused depthwise + GEMM pair where it has no
+// instance), 1 = k_lc_wave (direct loads, stride 1), 3 = k_lc_lds (production), 5 = also the opt-in 128 -> 128 split; stride 21
+// means (2, 1).  maxdiff compares with form RT_BENCH_LC_REF (default 0); RT_BENCH_LC_DUMP prints where the two differ.
 RT_API int rt_bench_lc(rt_session* s, int n, int h, int w, int cin, int cout, int stride, int form, int iters, float* ms_out, float* maxdiff_out) {
   RT_REQUIRE(s && ms_out && n > 0 && h > 0 && w > 0 && (stride == 1 || stride == 2 || stride == 21), s, "rt_bench_lc: bad argument");
   return guarded(s, [&] {
@@ -574,11 +600,11 @@ RT_API int rt_bench_lc(rt_session* s, int n, int h, int w, int cin, int cout, in
     for (auto& v : hx) v = rnd();
     for (auto& v : hwd) v = rnd() * 0.3f;
     for (int k = 0; k < cin; k++) for (int c = 0; c < cout; c++) hw[((size_t)(k / nn::KC) * Np + c) * nn::KC + k % nn::KC] = rnd() * 0.1f;
-    float *dx, *dwd, *dbd, *dw, *db, *dy, *dy0; ImgGeom *dgi, *dgo;
-    RT_HIP_CHECK(hipMalloc((void**)&dx, nin * 4)); RT_HIP_CHECK(hipMalloc((void**)&dwd, hwd.size() * 4)); RT_HIP_CHECK(hipMalloc((void**)&dbd, hbd.size() * 4));
-    RT_HIP_CHECK(hipMalloc((void**)&dw, hw.size() * 4)); RT_HIP_CHECK(hipMalloc((void**)&db, hb.size() * 4));
-    RT_HIP_CHECK(hipMalloc((void**)&dy, nout * 4)); RT_HIP_CHECK(hipMalloc((void**)&dy0, nout * 4));
-    RT_HIP_CHECK(hipMalloc((void**)&dgi, n * sizeof(ImgGeom))); RT_HIP_CHECK(hipMalloc((void**)&dgo, n * sizeof(ImgGeom)));
+    DevBufs bufs;
+    RestoreInt keep_form(nn::g_lc_wave);
+    float *dx = bufs.alloc<float>(nin), *dwd = bufs.alloc<float>(hwd.size()), *dbd = bufs.alloc<float>(hbd.size()), *dw = bufs.alloc<float>(hw.size()),
+          *db = bufs.alloc<float>(hb.size()), *dy = bufs.alloc<float>(nout), *dy0 = bufs.alloc<float>(nout);
+    ImgGeom *dgi = bufs.alloc<ImgGeom>(n), *dgo = bufs.alloc<ImgGeom>(n);
     RT_HIP_CHECK(hipMemset(dy, 0, nout * 4)); RT_HIP_CHECK(hipMemset(dy0, 0, nout * 4));
     RT_HIP_CHECK(hipMemcpy(dx, hx.data(), nin * 4, hipMemcpyHostToDevice)); RT_HIP_CHECK(hipMemcpy(dwd, hwd.data(), hwd.size() * 4, hipMemcpyHostToDevice));
     RT_HIP_CHECK(hipMemcpy(dbd, hbd.data(), hbd.size() * 4, hipMemcpyHostToDevice)); RT_HIP_CHECK(hipMemcpy(dw, hw.data(), hw.size() * 4, hipMemcpyHostToDevice));
@@ -589,22 +615,21 @@ RT_API int rt_bench_lc(rt_session* s, int n, int h, int w, int cin, int cout, in
     float* dy1 = nullptr;   // unfused reference: depthwise output
     auto run = [&](float* out) {
       if (nn::g_lc_wave == 0 && !nn::lc_thin_supported(3, sh, sw, Cp, cin, Np)) {   // no k_lc_thin instance: depthwise + GEMM
-        if (!dy1) RT_HIP_CHECK(hipMalloc((void**)&dy1, (size_t)n * ho * wo * Cp * 4));
+        if (!dy1) dy1 = bufs.alloc<float>((size_t)n * ho * wo * Cp);
         nn::dwconv(s->st, 3, sh, sw, dx, dgi, dgo, n, ho, wo, Cp, cin, dwd, dbd, dw_act, dw_lab, 0.99f, 0.01f, dy1, nullptr);
         nn::gemm(s->st, dy1, Cp, (long long)n * ho * wo, Cp, dw, cout, Np, out, ldy, 0, e);
         return;
       }
       nn::lc_thin(s->st, sh, sw, dx, dgi, dgo, n, ho, wo, Cp, cin, dwd, dbd, dw_act, dw_lab, 0.99f, 0.01f, dw, cout, Np, out, ldy, e);
     };
-    const int keep = nn::g_lc_wave;
     nn::g_lc_wave = getenv("RT_BENCH_LC_REF") ? atoi(getenv("RT_BENCH_LC_REF")) : 0; run(dy0);
     nn::g_lc_wave = form; run(dy);
-    hipEvent_t a, b; RT_HIP_CHECK(hipEventCreate(&a)); RT_HIP_CHECK(hipEventCreate(&b));
+    Events ev; RT_HIP_CHECK(hipEventCreate(&ev.a)); RT_HIP_CHECK(hipEventCreate(&ev.b));
+    hipEvent_t a = ev.a, b = ev.b;
     RT_HIP_CHECK(hipEventRecord(a, s->st));
     for (int i = 0; i < iters; i++) run(dy);
     RT_HIP_CHECK(hipEventRecord(b, s->st));
     RT_HIP_CHECK(hipStreamSynchronize(s->st));
-    nn::g_lc_wave = keep;
     float ms = 0; RT_HIP_CHECK(hipEventElapsedTime(&ms, a, b)); *ms_out = ms / iters;
     if (maxdiff_out) {
       const size_t cnt = std::min<size_t>(nout, (size_t)1 << 22);
@@ -627,8 +652,6 @@ RT_API int rt_bench_lc(rt_session* s, int n, int h, int w, int cin, int cout, in
       }
       *maxdiff_out = md;
     }
-    (void)hipEventDestroy(a); (void)hipEventDestroy(b);
-    for (void* p : {(void*)dx, (void*)dwd, (void*)dbd, (void*)dw, (void*)db, (void*)dy, (void*)dy0, (void*)dgi, (void*)dgo, (void*)dy1}) (void)hipFree(p);
   });
 }
 

@@ -20,18 +20,26 @@ def _down(v: int, s: int) -> int:
     return (v - 1) // s + 1
 
 
-def gemm_pw_label(M: int, N: int, se: bool = False) -> str:
-    """Mirror of nn::gemm_pw_label (retto_amd/csrc/nn_kernels.hip): which kernel symbol the
-    dispatcher picks for a pointwise conv of M rows and N output channels.  `se`: the block has a
-    squeeze-excite whose scale is folded into the GEMM's A staging (wide tiles, every image
-    >= 128 rows at that level -- true for the bench workloads)."""
+def gemm_pw_label(M: int, N: int, se: bool = False, K: int = 0, min_pix: int = 1 << 30) -> str:
+    """Mirror of nn::gemm_pw_label + the predicates behind it (retto_amd/csrc/nn_kernels.hip gemm_dispatch / gemm_se_tile_rows,
+    nn_gemm_dma.hip gemm_dma_supported): which kernel symbol the dispatcher picks for a pointwise conv of M rows, K input and
+    N output channels.  `se`: the block has a squeeze-excite whose scale is folded into the GEMM's A staging; `min_pix`: rows
+    of the smallest image of the level (the fused form needs every image to cover a row tile).  K = 0: unknown, assumed to
+    satisfy the K conditions (callers inside this module always pass it)."""
     npad = (N + 15) // 16 * 16
-    if se and npad % 240 == 0 and M >= 131072 and os.environ.get("RT_GEMM_DMA", "1") != "0":
-        return "gemm_pw/k_gemm32p+se"   # (images of >= 128 rows at that level: true for the bench workloads)
-    if se and M >= 8192 and npad >= 128:
-        return "gemm_pw/k_gemm_wide<2,5,4,3>+se" if npad % 240 == 0 and M >= 16384 else "gemm_pw/k_gemm_wide<2,4,4,2>+se"
-    if npad % 240 == 0 and M >= 131072:   # (the persistent LDS-DMA form unless RT_GEMM_DMA=0 keeps the register-staged tile)
-        return "gemm_pw/k_gemm32p" if os.environ.get("RT_GEMM_DMA", "1") != "0" else "gemm_pw/k_gemm_wide<4,5,4,3>"
+    dma_on = os.environ.get("RT_GEMM_DMA", "1") != "0"
+    # k_gemm32p: N == Npad16 a multiple of 240 (<= 480 per bias table), whole 16-deep K groups, more than 3 slabs of 32, M >= 131072
+    dma_shape = npad == N and N % 240 == 0 and M >= 131072 and (K == 0 or (K % 16 == 0 and K > 96))
+    if se:
+        if dma_on and dma_shape and min_pix >= 128 and (K == 0 or K <= 512):
+            return "gemm_pw/k_gemm32p+se"
+        wide = npad % 240 == 0 and M >= 16384
+        rows_ok = min_pix >= 128
+        if rows_ok and (K == 0 or K <= 512) and (wide or (M >= 8192 and npad >= 128)):
+            return "gemm_pw/k_gemm_wide<2,5,4,3>+se" if wide else "gemm_pw/k_gemm_wide<2,4,4,2>+se"
+        # no fused form: the tensor is scaled in a pass of its own and the GEMM is the plain one
+    if npad % 240 == 0 and M >= 131072:   # (the persistent LDS-DMA form unless RT_GEMM_DMA=0 / an unsupported K keeps the register-staged tile)
+        return "gemm_pw/k_gemm32p" if (dma_on and dma_shape) else "gemm_pw/k_gemm_wide<4,5,4,3>"
     if npad % 240 == 0 and M >= 16384:
         return "gemm_pw/k_gemm_wide<2,5,4,3>"
     return "gemm_pw/thin"
@@ -103,7 +111,8 @@ def det_work(pages: Iterable[Tuple[int, int]], phase=None) -> Dict[str, Dict[str
                 add("dwconv%d" % k, (h * ww + ho * wo) * cin * F + k * k * cin * F, 2 * ho * wo * cin * k * k)
                 scale = (ho * wo) / float(H * W)
                 m_group = int(round(sum(gh * gw for gh, gw in grp) * scale))
-                add(gemm_pw_label(m_group, cout, se), ho * wo * (cin + cout) * F + cin * cout * F, 2 * ho * wo * cin * cout)
+                min_pix = int(round(min(gh * gw for gh, gw in grp) * scale))
+                add(gemm_pw_label(m_group, cout, se, cin, min_pix), ho * wo * (cin + cout) * F + cin * cout * F, 2 * ho * wo * cin * cout)
             h, ww = ho, wo
             for j, (tn, tc, oc) in enumerate(synth.DET_TAPS):
                 if tn == name:
@@ -150,6 +159,16 @@ def det_work(pages: Iterable[Tuple[int, int]], phase=None) -> Dict[str, Dict[str
     return dict(w)
 
 
+def _rows_at(W: int, block: str) -> int:
+    """Pixels of a 48 x W line at the output of recognition block `block` (the stem halves both sides first)."""
+    h, ww = _down(48, 2), _down(W, 2)
+    for name, _k, _cin, _cout, sh, sw, _se in synth.REC_BLOCKS:
+        h, ww = _down(h, sh), _down(ww, sw)
+        if name == block:
+            break
+    return h * ww
+
+
 def rec_work(widths: Iterable[int], classes: int = synth.REC_CLASSES) -> Dict[str, Dict[str, float]]:
     """widths: padded width W of every 48-high line tensor."""
     w = defaultdict(lambda: {"bytes": 0.0, "flops": 0.0})
@@ -174,7 +193,8 @@ def rec_work(widths: Iterable[int], classes: int = synth.REC_CLASSES) -> Dict[st
             else:
                 add("dwconv%d" % k, (h * ww + ho * wo) * cin * F + k * k * cin * F, 2 * ho * wo * cin * k * k)
                 m_group = int(round(grp_px * (ho * wo) / float(H * W)))
-                add(gemm_pw_label(m_group, cout, se), ho * wo * (cin + cout) * F + cin * cout * F, 2 * ho * wo * cin * cout)
+                min_pix = min(_rows_at(widths[i], name) for i in group_of[wi])
+                add(gemm_pw_label(m_group, cout, se, cin, min_pix), ho * wo * (cin + cout) * F + cin * cout * F, 2 * ho * wo * cin * cout)
             h, ww = ho, wo
         T = (ww - 2) // 2 + 1
         add("avgpool", (h * ww + T) * 480 * F)

@@ -7,12 +7,12 @@ tag=${1:-round}
 out=gpurun_out/$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-C3="--steps 4 --warmup 3 --no-cpu-baseline --no-c5 --lanes 1"
-C5="--workload c5 --pages 32 --steps 2 --warmup 3 --no-cpu-baseline --lanes 1"   # (32 pages: the leg the default bench.py run appends as `c5`)
+C3="--steps 4 --warmup 3 --no-cpu-baseline --no-c5 --lanes 1 --inflight 1"
+C5="--workload c5 --pages 32 --steps 2 --warmup 3 --no-cpu-baseline --lanes 1 --inflight 1"   # (32 pages: the leg the default bench.py run appends as `c5`)
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/c3_trace -o t -- python3 bench.py $C3 > $out/c3_bench.log 2> $out/c3_bench.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/c5_trace -o t -- python3 bench.py $C5 > $out/c5_bench.log 2> $out/c5_bench.err
 for w in c3 c5; do
-  if [ $w = c3 ]; then F="--steps 2 --warmup 2 --no-cpu-baseline --no-c5 --lanes 1"; else F="--workload c5 --pages 32 --steps 1 --warmup 3 --no-cpu-baseline --lanes 1"; fi
+  if [ $w = c3 ]; then F="--steps 2 --warmup 2 --no-cpu-baseline --no-c5 --lanes 1 --inflight 1"; else F="--workload c5 --pages 32 --steps 1 --warmup 3 --no-cpu-baseline --lanes 1 --inflight 1"; fi
   rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/${w}_fetch -o f -- python3 bench.py $F > /dev/null 2>&1
   rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/${w}_write -o w -- python3 bench.py $F > /dev/null 2>&1
   rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d $out/${w}_sq -o s -- python3 bench.py $F > /dev/null 2>&1
