@@ -103,9 +103,10 @@ Arena::~Arena() {
 }
 void Arena::reserve(size_t bytes) {
   if (bytes <= cap_) return;
-  if (base_) old_.push_back(base_);
   void* p = nullptr;
-  RT_HIP_CHECK(hipMalloc(&p, bytes));
+  RT_HIP_CHECK(hipMalloc(&p, bytes));   // (first: a refused allocation leaves the arena as it was -- the old block must not end up
+                                        //  both current and on the superseded list, which reset() frees)
+  if (base_) old_.push_back(base_);
   base_ = (char*)p; cap_ = bytes; off_ = 0;
 }
 void* Arena::alloc_bytes(size_t bytes) {
@@ -129,7 +130,7 @@ void Arena::reset() {
     size_t want = need_ + need_ / 8 + ((size_t)1 << 20);
     if (want > cap_) {
       (void)hipFree(base_);
-      base_ = nullptr; cap_ = 0;
+      base_ = nullptr; cap_ = 0; pass_ = 0; off_ = 0;   // (consistent even if the allocation below throws)
       void* q = nullptr;
       RT_HIP_CHECK(hipMalloc(&q, want));
       base_ = (char*)q; cap_ = want;

@@ -47,6 +47,9 @@ class Arena {
   // largest pass seen; steady state never allocates.
   void reset();
   void rewind() { if (pass_ > need_) need_ = pass_; pass_ = 0; off_ = 0; }  // stream-ordered reuse inside a call
+  // A call that FAILED must not size the arena for the calls after it (a page whose size limits explode -- 1 x 4000 becomes
+  // 736 x 2.76 M det pixels, as in the reference -- asked for tens of GB before hipMalloc refused): forget the pass.
+  void abandon_pass() { pass_ = 0; }
   size_t used() const { return off_; }
   size_t peak() const { return need_; }
   size_t capacity() const { return cap_; }

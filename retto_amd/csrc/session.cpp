@@ -150,6 +150,9 @@ rt_session* rt_session_create(const rt_config* cfg) {
 
 void rt_session::begin_call() {
   RT_HIP_CHECK(hipSetDevice(device));
+  (void)hipGetLastError();   // HIP's last error is sticky per host thread: a failure of the PREVIOUS call on this thread (a refused
+                             // hipMalloc, say) must not be what the first RT_LAUNCH of this call reports
+  if (failed) { arena.abandon_pass(); scratch.abandon_pass(); dbws.abandon_pass(); failed = false; }
   arena.reset(); scratch.reset(); pinned.reset();
   last_error.clear();
 }
@@ -938,6 +941,7 @@ rt_ticket* rt_session::submit_batch(const uint8_t* const* rgb, const int* hs, co
                                     tp->maps.empty() ? nullptr : tp->maps.data() + f0);
       } catch (...) {
         tp->errs[l] = std::current_exception();
+        s->failed = true;
         // work of the failed part may still be queued on the lane's stream: drain it before the lane's next job rewinds the
         // arenas and the pinned staging it reads
         if (s->st) (void)hipStreamSynchronize(s->st);
@@ -982,7 +986,9 @@ rt_results* rt_session::run_batch(const uint8_t* const* rgb, const int* hs, cons
       ~Disarm() { self->stage_cb = nullptr; self->stage_mu = nullptr; }
     } disarm{this};
     stage_cb = cb; stage_user = user; stage_mu = &cb_mu; page_base = 0;
-    return run_pages(rgb, hs, ws, n_pages, mem, det_map_override);
+    try {
+      return run_pages(rgb, hs, ws, n_pages, mem, det_map_override);
+    } catch (...) { failed = true; throw; }
   }
   return wait_batch(submit_batch(rgb, hs, ws, n_pages, mem, det_map_override, cb, user));
 }

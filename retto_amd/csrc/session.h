@@ -122,6 +122,7 @@ struct rt_session {
   std::vector<std::unique_ptr<LaneWorker>> workers;
   std::atomic<int> inflight{0};
   int next_lane = 0;               // first lane of the next submitted batch
+  bool failed = false;             // the lane's previous call threw: its arena statistics are discarded at the next begin_call
   void ensure_workers();
   rt_ticket* submit_batch(const uint8_t* const* rgb, const int* hs, const int* ws, int n_pages, int mem,
                           const float* const* det_map_override, rt_stage_callback cb = nullptr, void* user = nullptr);

@@ -884,3 +884,34 @@ def test_two_sessions_on_two_devices(hip_session):
         assert np.array_equal(hip_session.worker.det(x).view(np.uint32), other.worker.det(x).view(np.uint32))
     finally:
         other.close()
+
+
+def test_submit_wait_failed_batch_does_not_poison_the_session():
+    """A batch that fails on one lane (an empty page: ImageError) returns ITS error from
+    rt_wait_batch; the batch submitted behind it on the same lanes completes with the right results, and the session stays
+    usable (the failed lane drains its stream before its next job rewinds the arenas)."""
+    sess = retto_amd.RettoSession(retto_amd.synthetic_session_config(0))
+    try:
+        lib = sess._hd.lib
+        good, gmaps = [], []
+        for i in range(4):
+            page, rects = workload.planted_page(320, 480, 3, seed=60 + i)
+            dh, dw = R.resize_either_dims(320, 480)
+            good.append(page); gmaps.append(workload.planted_map(dh, dw, 320, 480, rects))
+        ref = sess.run_batch(good, det_map_override=gmaps)
+        bad = list(good)
+        bad_h = [p.shape[0] for p in bad]; bad_h[2] = 0   # an empty page: ImageError on the lane that gets it, after its neighbours started
+        t_bad = sess.submit_batch_raw(bad, bad_h, [p.shape[1] for p in bad], retto_amd.RT_MEM_HOST, None)
+        t_ok = sess.submit_batch_raw(good, [p.shape[0] for p in good], [p.shape[1] for p in good], retto_amd.RT_MEM_HOST, gmaps)
+        with pytest.raises(retto_amd.ImageError):
+            sess.wait_batch_raw(t_bad)
+        r = sess.wait_batch_raw(t_ok)
+        for i, pr in enumerate(ref):
+            n = lib.rt_results_count(r, i)
+            assert n == len(pr.det_result) > 0
+            assert np.array_equal(np.ctypeslib.as_array(lib.rt_results_boxes(r, i), (n, 8)), np.stack([d.boxes.as_array().reshape(8) for d in pr.det_result]))
+        lib.rt_results_free(r)
+        again = sess.run_batch(good, det_map_override=gmaps)
+        assert [len(p.det_result) for p in again] == [len(p.det_result) for p in ref]
+    finally:
+        sess.close()
