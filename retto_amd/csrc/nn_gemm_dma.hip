@@ -65,7 +65,9 @@ struct GemmPArgs {
   // a_tab holds 3 ints per row block: {image of the block's first row, first row of the next image, of the one after}
   // (INT_MAX when there is none); every image has >= 128 rows, so a 256-row block touches at most 3.
   const float* a_scale; const int* a_tab; int ld_scale, n_img;
-  unsigned* sched;     // [0] tiles handed out beyond the first gridDim.x, [1] workgroups done (both zero between launches)
+  unsigned* sched;     // tile counters ([16 q]: queue q, tiles handed out beyond the workgroups' first ones) and [128] workgroups done; zero between launches
+  int xcdq;            // 1: one tile queue per XCD (workgroup b is on XCD b % 8 and takes the row blocks rb % 8 == b % 8, both column
+                       // tiles of a row block consecutively: they meet in that XCD's L2); 0: one queue, tile ids in launch order
   Epilogue epi;
 };
 
@@ -112,8 +114,21 @@ __global__ __launch_bounds__(P_NTHR, 1) void k_gemm32p(const GemmPArgs g) {
   // hand-over barrier; the request side needs it 2 slabs before tile j + 1 ends, the MFMA side when tile j + 1 ends.
   const int n_tiles = g.n_rb * g.n_cb;
   volatile int* tileq = reinterpret_cast<volatile int*>(smem32p + 2 * P_STAGE + P_BIAS_MAX * 4);   // ids of the tiles j, j + 1, .. (slot j & 3)
-  if (tid == 0) tileq[0] = (int)blockIdx.x;
-  int it_tile = blockIdx.x, it_j = 0, it_kc = 0;
+  // (round 4) per-XCD queues: PMC showed the N = 480 layers fetching 1.93x their input -- the two 240-column tiles of a row
+  // block went to workgroups on different XCDs, each L2 read the 256 x K pixel block from the fabric.  Queue q holds the row
+  // blocks rb = 8 i + q with their column tiles in order; local index t -> tile (8 (t / n_cb) + q) * n_cb + t % n_cb.
+  const int xq = g.xcdq ? (int)(blockIdx.x & 7) : 0;
+  const int q_wgs = g.xcdq ? (G - xq + 7) >> 3 : G;                                   // workgroups of this queue (their first tiles: local 0 .. q_wgs - 1)
+  const int q_tiles = g.xcdq ? ((g.n_rb - xq + 7) >> 3) * g.n_cb : n_tiles;           // tiles of this queue
+  auto tile_of = [&](int t) __attribute__((always_inline)) {
+    if (!g.xcdq) return t;
+    if (t >= q_tiles) return n_tiles;   // (dead: past the queue's end)
+    const int i = t / g.n_cb;
+    return (8 * i + xq) * g.n_cb + (t - i * g.n_cb);
+  };
+  const int first_tile = tile_of(g.xcdq ? (int)(blockIdx.x >> 3) : (int)blockIdx.x);
+  if (tid == 0) tileq[0] = first_tile;
+  int it_tile = first_tile, it_j = 0, it_kc = 0;
   int it_rb = it_tile / g.n_cb, it_cb = it_tile - it_rb * g.n_cb;
   unsigned it_buf = 0;
   bool it_live = it_tile < n_tiles;
@@ -222,7 +237,7 @@ __global__ __launch_bounds__(P_NTHR, 1) void k_gemm32p(const GemmPArgs g) {
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     after_epi = false;
     if (pub) {   // (the atomic was issued eight steps ago: the wait above covered it)
-      if (wid == 0 && lane_id() == 0) tileq[pub_slot] = G + (int)fetched;
+      if (wid == 0 && lane_id() == 0) tileq[pub_slot] = tile_of(q_wgs + (int)fetched);
     }
     RT_ST(2);
     __builtin_amdgcn_s_barrier();
@@ -320,7 +335,7 @@ __global__ __launch_bounds__(P_NTHR, 1) void k_gemm32p(const GemmPArgs g) {
     bool pub = false;
     if (!EPI && fetch_now) {
       if (wid == 0 && lane_id() == 0)
-        asm volatile("global_atomic_add %0, %1, %2, %3 sc0" : "=v"(fetched) : "v"(0u), "v"(1u), "s"(g.sched) : "memory");
+        asm volatile("global_atomic_add %0, %1, %2, %3 sc0" : "=v"(fetched) : "v"((unsigned)(xq * 64)), "v"(1u), "s"(g.sched) : "memory");
       fetch_now = false; pub = true;
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -419,7 +434,7 @@ __global__ __launch_bounds__(P_NTHR, 1) void k_gemm32p(const GemmPArgs g) {
     pend_rows = (int)min((long long)P_BM, g.M - m0);
   };
   {   // (every workgroup has a first tile: the grid is at most n_tiles; exit at the bottom keeps the accumulators in place)
-    int j = 0, t = (int)blockIdx.x;
+    int j = 0, t = first_tile;
     do {
       const int rb = t / g.n_cb;
       tile(j, rb, t - rb * g.n_cb);
@@ -432,10 +447,10 @@ __global__ __launch_bounds__(P_NTHR, 1) void k_gemm32p(const GemmPArgs g) {
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (the fragments read ahead for a tile that does not exist)
   // the last workgroup to finish leaves the two counters at zero for the next launch on this stream
   if (tid == 0) {
-    const unsigned done = __hip_atomic_fetch_add(g.sched + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned done = __hip_atomic_fetch_add(g.sched + 128, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (done == (unsigned)G - 1) {
-      __hip_atomic_store(g.sched, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(g.sched + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      for (int qq = 0; qq < 8; qq++) __hip_atomic_store(g.sched + 16 * qq, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(g.sched + 128, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
   if ((DBG & 16) && wid == 0 && lane == 0) {
@@ -488,8 +503,8 @@ void gemm_dma(hipStream_t st, const float* A, int lda, long long M, int K, const
     std::lock_guard<std::mutex> lk(mu);
     unsigned*& c = counters[{dev, st}];
     if (!c) {
-      RT_HIP_CHECK(hipMalloc((void**)&c, 256));
-      RT_HIP_CHECK(hipMemset(c, 0, 256));
+      RT_HIP_CHECK(hipMalloc((void**)&c, 1024));
+      RT_HIP_CHECK(hipMemset(c, 0, 1024));
     }
     sched = c;
   }
@@ -499,6 +514,12 @@ void gemm_dma(hipStream_t st, const float* A, int lda, long long M, int K, const
   g.n_rb = (int)((M + P_BM - 1) / P_BM); g.n_cb = N / P_BN; g.epi = epi;
   g.a_scale = epi.a_scale; g.a_tab = epi.a_tab; g.ld_scale = epi.ld_scale; g.n_img = epi.n_img;
   const int grid = std::min(g.n_rb * g.n_cb, cus[dev]);
+  // per-XCD tile queues (RT_G32P_XCDQ=0: one queue): needs every workgroup's first tile to exist in its queue
+  // Measured (round 4, same box, alternating runs): bit-identical results; in isolation 1.5 % SLOWER (615216 x 480 x 480: 2.311 vs
+  // 2.274 ms -- eight queues of 32 workgroups balance worse than one queue of 256), production step 27.90 / 27.91 / 28.41 / 27.90
+  // vs 27.99 / 28.53 / 28.69 / 28.15 ms (inside the noise): opt-in.
+  static const int xcdq_env = getenv("RT_G32P_XCDQ") ? atoi(getenv("RT_G32P_XCDQ")) : 0;
+  g.xcdq = (xcdq_env && g.n_rb >= 64 && grid % 8 == 0) ? 1 : 0;
   const bool half = K % KC != 0;   // (supported K are whole 16-deep groups)
 #define RT_G32P(ACTV, LABV) do { if (half) { allow_big_lds((const void*)k_gemm32p<ACTV, LABV, true>, 160 * 1024); RT_LAUNCH((k_gemm32p<ACTV, LABV, true>), dim3((unsigned)grid), dim3(P_NTHR), P_LDS, st, g); } \
                                  else { allow_big_lds((const void*)k_gemm32p<ACTV, LABV, false>, 160 * 1024); RT_LAUNCH((k_gemm32p<ACTV, LABV, false>), dim3((unsigned)grid), dim3(P_NTHR), P_LDS, st, g); } } while (0)
