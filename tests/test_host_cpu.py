@@ -352,3 +352,52 @@ def test_host_cpu_budget_follows_affinity_quota_and_local_world_size():
     eight = int(subprocess.run([sys.executable, "-c", code], env=dict(env, LOCAL_WORLD_SIZE="8"), cwd=root, capture_output=True, text=True, check=True).stdout)
     assert eight == max(1, one // 8)
     assert lib.rt_host_cpu_budget() >= 1
+
+
+def test_upsampling_aware_conv_identities():
+    """The algebra behind retto_amd/csrc/nn_fpn.hip, checked with torch on the CPU (the GPU tests check the kernels): a 3x3 "same"
+    conv over a nearest-neighbour upsampled tensor equals (a) for factor 2, four 2 x 2 phase convs of the tensor itself with
+    pre-summed taps (fpn_phase_weights), (b) for factor 4 / 8, a lookup by the row / column class (first, interior, last row of an
+    upsampling block) of a class conv computed at the coarse resolution (fpn_class_weights) -- zero padding included; and (c) a
+    bias-free 1x1 conv, a per-channel scale and a 3x3 conv compose into one 3x3 conv (fpn_compose)."""
+    import torch
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(5)
+    z = torch.randn(1, 6, 5, 7, generator=g, dtype=torch.float64)
+    w = torch.randn(4, 6, 3, 3, generator=g, dtype=torch.float64)
+
+    def taps(phase, t, s):   # taps of the 3-tap axis that land on relative coarse row t - 1 + ... for an output row at `phase` of an s-block
+        # returns {relative coarse row: [taps]} for phase in [0, s)
+        out = {}
+        for d in range(3):
+            rel = (phase + d - 1) // s          # floor division: -1, 0 or +1
+            out.setdefault(rel, []).append(d)
+        return out
+
+    for s in (2, 4, 8):
+        ref = F.conv2d(F.interpolate(z, scale_factor=s, mode="nearest"), w, padding=1)
+        H, W = z.shape[2:]
+        got = torch.zeros_like(ref)
+        zp = F.pad(z, (1, 1, 1, 1))
+        for py in range(s):
+            ty = taps(py, 0, s)
+            for px in range(s):
+                tx = taps(px, 0, s)
+                acc = torch.zeros(1, 4, H, W, dtype=torch.float64)
+                for ry, dys in ty.items():
+                    for rx, dxs in tx.items():
+                        weff = sum(w[:, :, dy, dx] for dy in dys for dx in dxs)          # pre-summed taps: [n, k]
+                        src = zp[:, :, 1 + ry:1 + ry + H, 1 + rx:1 + rx + W]
+                        acc += torch.einsum("nk,bkhw->bnhw", weff, src)
+                got[:, :, py::s, px::s] = acc
+                # the class of a phase: first (0), interior (1), last (2) -- only these three tap patterns exist per axis
+                assert sorted(ty) == ([-1, 0] if py == 0 else [0, 1] if py == s - 1 else [0])
+        assert torch.allclose(got, ref, atol=1e-12)
+    # (c) lateral 1x1 (no bias) * scale -> 3x3 conv == 3x3 conv of the narrow tensor with composed weights
+    x = torch.randn(1, 3, 6, 6, generator=g, dtype=torch.float64)
+    wl = torch.randn(8, 3, 1, 1, generator=g, dtype=torch.float64)
+    sc = torch.rand(8, generator=g, dtype=torch.float64) + 0.5
+    wc = torch.randn(4, 8, 3, 3, generator=g, dtype=torch.float64)
+    ref = F.conv2d(F.conv2d(x, wl) * sc.view(1, 8, 1, 1), wc, padding=1)
+    wcomp = torch.einsum("nmyx,m,mc->ncyx", wc, sc, wl[:, :, 0, 0])
+    assert torch.allclose(F.conv2d(x, wcomp, padding=1), ref, atol=1e-12)
