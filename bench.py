@@ -439,7 +439,7 @@ def main():
     # ---- roofline pass (rank 0 only): the same K steps strictly serial on one stream with HIP
     # events around every launch.  Concurrent lanes share the GPU and stretch each other's
     # kernels, so a kernel's own duration can only be read from a serial pass.
-    prof, serial_ms = {}, None
+    prof, prof_nets, serial_ms = {}, {}, None
     if rank == 0:
         lib.rt_set_lanes(h, 1)
         for _ in range(2):  # lane 0's arenas re-size for the whole batch
@@ -453,6 +453,13 @@ def main():
         lib.rt_synchronize(h)
         serial_ms = 1000.0 * (time.perf_counter() - ts) / psteps
         prof = sess.profile_get()
+        # whole-network device times from a pass WITHOUT the per-launch event pairs (~65 pairs per det pass are work on the
+        # stream themselves): only the enclosing net/det, net/cls, net/rec scopes are recorded
+        sess.profile_enable(2)
+        for _ in range(psteps):
+            step()
+        lib.rt_synchronize(h)
+        prof_nets = {name: v for name, v in sess.profile_get().items() if name.startswith("net/")}
         sess.profile_enable(False)
         lib.rt_set_lanes(h, 1 << 20)
     if dist_on:
@@ -521,7 +528,8 @@ def main():
             else:
                 work[k] = dict(v)
     psteps = min(a.steps, 20)
-    nets = {name[4:]: ms / psteps for name, (ms, calls) in prof.items() if calls and name.startswith("net/")}
+    nets_ev = {name[4:]: ms / psteps for name, (ms, calls) in prof.items() if calls and name.startswith("net/")}   # with the per-launch events
+    nets = {name[4:]: ms / psteps for name, (ms, calls) in prof_nets.items() if calls} or nets_ev
     fams = sorted(((ms, calls, name) for name, (ms, calls) in prof.items() if calls and not name.startswith("net/")), reverse=True)
     total_ms = sum(f[0] for f in fams)
     if a.profile_all:
@@ -608,7 +616,10 @@ def main():
                     "det_tflops": round(det_flops / (nets["det"] * 1e-3) / 1e12, 2) if nets.get("det") else None,
                     "rec_tflops": round(rec_flops / (nets["rec"] * 1e-3) / 1e12, 2) if nets.get("rec") else None,
                     "det_layer_bytes_gbs": round(det_bytes / (nets["det"] * 1e-3) / 1e9, 1) if nets.get("det") else None,
-                    "note": "per step of %d pages, one lane; %s MFMA peak %.1f TFLOP/s, HBM peak %.0f GB/s; det_layer_bytes = per-launch "
+                    "with_per_launch_events": {k: round(v, 3) for k, v in nets_ev.items()},
+                    "note": "per step of %d pages, one lane, HIP events around each network in a pass that records nothing else "
+                            "(`with_per_launch_events`: the same scopes in the per-launch profile pass, whose ~65 event pairs per det pass "
+                            "add their own stream time); %s MFMA peak %.1f TFLOP/s, HBM peak %.0f GB/s; det_layer_bytes = per-launch "
                             "algorithmic bytes of the det net as executed (retto_amd/workmodel.py)" % (n_my, a.dtype, mfma_peak, HBM_PEAK_GBS)}
         if a.models == "mobile" and a.dtype == "f32" and nets.get("det"):
             b_layer = 500e6 * sum(dh_ * dw_ for dh_, dw_ in det_dims) / (960.0 * 960.0)

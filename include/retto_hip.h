@@ -223,6 +223,9 @@ RT_API int rt_synchronize(rt_session* s);
  * rt_config.lanes).  1 = strictly serial on the session's own stream (what the per-kernel
  * profile wants: concurrent lanes share the GPU and stretch each other's kernels). */
 RT_API int rt_set_lanes(rt_session* s, int lanes);
+/* on: 0 off; 1 every launch family ("gemm_pw/...", "dwconv5", ...) and the enclosing network scopes ("net/det", "net/cls",
+ * "net/rec"); 2 the network scopes only (the per-launch event pairs are themselves work on the stream: whole-network device
+ * times are read from a pass without them). */
 RT_API int rt_profile_enable(rt_session* s, int on);
 RT_API int rt_profile_get(rt_session* s, const char* const** names, const float** ms, const int** calls, int* n);
 

@@ -392,8 +392,9 @@ int rt_set_lanes(rt_session* s, int lanes) {
 int rt_profile_enable(rt_session* s, int on) {
   RT_REQUIRE(s, s, "rt_profile_enable: null session");
   return guarded(s, [&] {
-    s->prof.clear(); s->prof.on = on != 0;
-    for (auto& h : s->helpers) { h->prof.clear(); h->prof.on = on != 0; }
+    const int mode = on == 2 ? 2 : (on != 0 ? 1 : 0);   // 2: the enclosing network scopes only
+    s->prof.clear(); s->prof.on = mode;
+    for (auto& h : s->helpers) { h->prof.clear(); h->prof.on = mode; }
   });
 }
 int rt_profile_get(rt_session* s, const char* const** names, const float** ms, const int** calls, int* n) {

@@ -80,7 +80,7 @@ class Pinned {
 class Profiler {
  public:
   ~Profiler();
-  bool on = false;
+  int on = 0;   // 0 off, 1 every launch family + network scopes, 2 network scopes only
   bool detail = getenv("RT_PROFILE_DETAIL") != nullptr;  // per-layer labels "family@shape" (tools/layer_profile.py)
   void begin(hipStream_t st, const char* name);
   void end(hipStream_t st);
@@ -106,11 +106,13 @@ class Profiler {
 
 struct ProfScope {
   Profiler* p; hipStream_t st;
-  ProfScope(Profiler* p_, hipStream_t s, const char* name) : p(p_), st(s) { if (p && p->on) p->begin(st, name); }
+  // (p->on: 1 = every launch family + the enclosing network scopes; 2 = the network scopes only -- ~65 event pairs per det pass
+  //  are themselves work on the stream, so whole-network times are read from a pass without them)
+  ProfScope(Profiler* p_, hipStream_t s, const char* name) : p(p_), st(s) { if (p && p->on == 1) p->begin(st, name); }
   ProfScope(Profiler* p_, hipStream_t s, const char* name, const std::string& shape) : p(p_), st(s) {
-    if (p && p->on) p->begin(st, p->detail ? (std::string(name) + "@" + shape).c_str() : name);
+    if (p && p->on == 1) p->begin(st, p->detail ? (std::string(name) + "@" + shape).c_str() : name);
   }
-  ~ProfScope() { if (p && p->on) p->end(st); }
+  ~ProfScope() { if (p && p->on == 1) p->end(st); }
 };
 struct ProfOuter {
   Profiler* p; hipStream_t st; const char* name; hipEvent_t a{};
