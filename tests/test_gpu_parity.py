@@ -22,7 +22,7 @@ def _rand_page(h, w, seed):
 
 # ---------------------------------------------------------------- a4 / a9 / a11 networks
 # (3 x 960^2: the squeeze-excite levels reach the sizes where the fused pooling / scaled-GEMM path is taken)
-@pytest.mark.parametrize("n,h,w", [(1, 64, 96), (2, 160, 128), (1, 320, 320), (3, 960, 960), (1, 1984, 1408)])
+@pytest.mark.parametrize("n,h,w", [(2, 32, 64), (1, 64, 96), (2, 160, 128), (1, 320, 320), (3, 960, 960), (1, 1984, 1408)])
 def test_det_net(hip_session, oracle_session, n, h, w):
     x = np.random.default_rng(h + w).uniform(-1, 1, (n, 3, h, w)).astype(np.float32)
     got = hip_session.worker.det(x)
