@@ -427,3 +427,74 @@ def test_crop_matches_independent_numpy_derivation(box):
     # f32 polynomial form (two truncations to u8) vs f64 weights form: a grey level per truncation at most
     assert diff.max() <= 2, f"max diff {diff.max()}"
     assert (diff <= 1).mean() > 0.98 and (diff == 0).mean() > 0.75, ((diff <= 1).mean(), (diff == 0).mean())
+
+
+def test_crop_exposure_to_the_homography_solver():
+    """The oracle solves get_crop_img's 8x8 DLT system by f64 Gaussian elimination; imageproc 0.25.0 goes through nalgebra's SVD
+    (INTEGRATION.md section 9).  How much can that choice move a crop?  For rotated and perspective boxes the system is solved both
+    ways -- and a third time with the SVD in f32, the worst case for the reference -- and the crops of the three inverse matrices
+    are compared through the same independent f64 bicubic evaluation.  f64 elimination vs f64 SVD: the f32 matrices agree to <= 1
+    ulp per entry and the crops byte for byte.  An f32 SVD moves matrix entries by up to ~1e-5 relative: the test records the
+    share of crop bytes that changes (about a fifth, each by one or two grey levels) -- the number a maintainer needs when the pin kit's
+    crop bytes differ in the last bit."""
+    rng = np.random.default_rng(11)
+    img = np.repeat(np.repeat(rng.integers(0, 256, (30, 48, 3), dtype=np.uint8), 4, 0), 4, 1)   # 120 x 192
+    boxes = [[[20.0, 30.0], [150.0, 18.0], [155.0, 52.0], [25.0, 66.0]],
+             [[30.5, 20.25], [160.0, 40.0], [150.0, 80.0], [22.0, 58.0]],
+             [[40.0, 35.0], [140.0, 30.0], [146.0, 70.0], [36.0, 78.0]]]
+
+    def system(box, cw, ch):
+        A, b = [], []
+        for (x, y), (u, v) in zip(np.asarray(box, np.float64), [(0, 0), (cw, 0), (cw, ch), (0, ch)]):
+            A.append([x, y, 1, 0, 0, 0, -u * x, -u * y]); b.append(u)
+            A.append([0, 0, 0, x, y, 1, -v * x, -v * y]); b.append(v)
+        return np.asarray(A), np.asarray(b)
+
+    def svd_solve(A, b, dtype):
+        U, S, Vt = np.linalg.svd(A.astype(dtype))
+        return (Vt.T @ ((U.T @ b.astype(dtype)) / S)).astype(np.float64)
+
+    def warp(Hi, out_w, out_h):
+        H, W = img.shape[:2]
+        ys, xs = np.mgrid[0:out_h, 0:out_w].astype(np.float64)
+        d = Hi[2, 0] * xs + Hi[2, 1] * ys + Hi[2, 2]
+        px = (Hi[0, 0] * xs + Hi[0, 1] * ys + Hi[0, 2]) / d
+        py = (Hi[1, 0] * xs + Hi[1, 1] * ys + Hi[1, 2]) / d
+        fx, fy = np.floor(px), np.floor(py)
+        tx, ty = px - fx, py - fy
+
+        def wts(t):
+            a = -0.5
+            x = np.stack([t + 1, t, 1 - t, 2 - t])
+            return np.where(x <= 1, (a + 2) * x ** 3 - (a + 3) * x ** 2 + 1, a * x ** 3 - 5 * a * x ** 2 + 8 * a * x - 4 * a)
+        wx, wy = wts(tx), wts(ty)
+        inside = (fx - 1 >= 0) & (fx + 3 < W) & (fy - 1 >= 0) & (fy + 3 < H)
+        out = np.full((out_h, out_w, 3), 255, np.uint8)
+        for oy, ox in zip(*np.nonzero(inside)):
+            x0, y0 = int(fx[oy, ox]) - 1, int(fy[oy, ox]) - 1
+            patch = img[y0:y0 + 4, x0:x0 + 4].astype(np.float64)
+            rows = np.floor(np.clip((patch * wx[:, oy, ox][None, :, None]).sum(1), 0, 255))
+            out[oy, ox] = np.clip((rows * wy[:, oy, ox][:, None]).sum(0), 0, 255).astype(np.uint8)
+        return out
+
+    shares = []
+    for box in boxes:
+        b32 = np.asarray(box, np.float32)
+        cw = float(np.float32(max(np.hypot(*(b32[3] - b32[2])), np.hypot(*(b32[0] - b32[1])))))
+        ch = float(np.float32(max(np.hypot(*(b32[1] - b32[2])), np.hypot(*(b32[0] - b32[3])))))
+        A, rhs = system(b32, cw, ch)
+        crops = []
+        mats = []
+        for h in (np.linalg.solve(A, rhs), svd_solve(A, rhs, np.float64), svd_solve(A, rhs, np.float32)):
+            Hm = np.append(h, 1.0).reshape(3, 3).astype(np.float32).astype(np.float64)       # the matrix as the f32 Projection holds it
+            Hi = np.linalg.inv(Hm).astype(np.float32).astype(np.float64)
+            mats.append(Hi)
+            crops.append(warp(Hi, int(cw), int(ch)))
+        # f64 elimination vs f64 SVD: the same f32 matrices up to one ulp, the same crop bytes
+        assert np.all(np.abs(mats[0] - mats[1]) <= 2 * np.spacing(np.abs(mats[0]).astype(np.float32)).astype(np.float64) + 1e-12)
+        assert np.array_equal(crops[0], crops[1])
+        d = np.abs(crops[0].astype(int) - crops[2].astype(int))
+        assert d.max() <= 2                      # an f32 SVD moves bytes by a grey level or two at most ...
+        shares.append(float((d > 0).mean()))
+    assert max(shares) < 0.35, shares           # ... and a minority of them (measured: 0.21)
+    print("crop bytes that change with an f32 SVD solve: %s" % ", ".join("%.3f" % v for v in shares))
