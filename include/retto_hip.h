@@ -290,10 +290,13 @@ RT_API int rt_broadcast_blobs(const void* id, int rank, int world, int device_id
  * LCNetV3 blocks back on k_lc_thin / the unfused pair (instead of k_lc_lds), 8 the wide fp32 GEMM
  * back on the register-staged tile (instead of k_gemm32p), 9 5x5 depthwise back on
  * k_dwconv_rows (instead of the column sweep), 10 the angle classifier's blocks as the unfused launch
- * series (instead of k_cls_block).
- * Process-wide; every setting but bit 10 computes bit-identical results (tests/test_gpu_parity.py
+ * series (instead of k_cls_block), 11 the RSEFPN output convs and the DB head conv as the round-3 launch
+ * series over materialised upsampled tensors (instead of the upsampling-aware k_fpn_phase / k_fpn_class /
+ * k_fpn_compose).
+ * Process-wide; every setting but bits 10 and 11 computes bit-identical results (tests/test_gpu_parity.py
  * checks bits 7-9 on whole networks; bit 10 changes the order of the squeeze-excite pooling sums:
- * equal within 1e-6 on the class probabilities). */
+ * equal within 1e-6 on the class probabilities; bit 11 changes the summation order of the pre-summed phase
+ * weights: equal within 2e-5 on the DB probability map). */
 RT_API void rt_debug_set_variants(int gemm_variant, int dw_variant, int flags);
 /* one launch of the fp16 implicit-GEMM conv kernel on host tensors: x [n, cin, h, w], wt [cout, cin, kh, kw], bias [cout] or
  * NULL, "same" padding k/2, stride (sh, sw), act = 0 none / 1 relu / 2 hardswish / 3 swish / 4 sigmoid -> out [n, cout, ho, wo] */

@@ -38,19 +38,24 @@ static int guarded(rt_session* s, F&& f) {
     s->last_error = "batches submitted with rt_submit_batch are in flight: call rt_wait_batch for every ticket first";
     return RT_ERR_INVALID;
   }
+  // rt_session::last_error is written and cleared on the API caller's thread only (here, RT_REQUIRE, the shape checks): lane
+  // threads keep their failure in the ticket (rt_ticket::errs) and it surfaces through rt_wait_batch's rethrow below.
+  // On the ALLOW_INFLIGHT path nothing is drained here: the lane that failed has drained its own stream in the worker, and the
+  // streams of the other lanes carry OTHER batches that a failed ticket must not stall.
+  if (s) s->last_error.clear();
   try {
     f();
     return RT_OK;
   } catch (const RtError& e) {
-    quiesce(s);
+    if (!ALLOW_INFLIGHT) quiesce(s);
     if (s) s->last_error = e.what(); else g_create_error = e.what();
     return e.code;
   } catch (const std::bad_alloc&) {
-    quiesce(s);
+    if (!ALLOW_INFLIGHT) quiesce(s);
     if (s) s->last_error = "out of host memory"; else g_create_error = "out of host memory";
     return RT_ERR_BACKEND;
   } catch (const std::exception& e) {
-    quiesce(s);
+    if (!ALLOW_INFLIGHT) quiesce(s);
     if (s) s->last_error = e.what(); else g_create_error = e.what();
     return RT_ERR_BACKEND;
   }

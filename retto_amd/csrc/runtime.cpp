@@ -20,11 +20,14 @@ void allow_big_lds(const void* kernel, int bytes) {
   // times per second; the three lanes of a session used to meet on the mutex eleven times per fp16 conv launch)
   thread_local std::set<std::pair<int, const void*>> seen;
   if (seen.count({dev, kernel})) return;
-  seen.insert({dev, kernel});
-  std::lock_guard<std::mutex> lk(mu);
-  if (done.count({dev, kernel})) return;
-  RT_HIP_CHECK(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
-  done.insert({dev, kernel});
+  {
+    std::lock_guard<std::mutex> lk(mu);
+    if (!done.count({dev, kernel})) {
+      RT_HIP_CHECK(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+      done.insert({dev, kernel});
+    }
+  }
+  seen.insert({dev, kernel});   // only once the attribute is known to be set: a throw above must be retried by the next call
 }
 
 // ---- sources / blob ---------------------------------------------------------------

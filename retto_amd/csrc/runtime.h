@@ -49,7 +49,10 @@ class Arena {
   void rewind() { if (pass_ > need_) need_ = pass_; pass_ = 0; off_ = 0; }  // stream-ordered reuse inside a call
   // A call that FAILED must not size the arena for the calls after it (a page whose size limits explode -- 1 x 4000 becomes
   // 736 x 2.76 M det pixels, as in the reference -- asked for tens of GB before hipMalloc refused): forget the pass.
-  void abandon_pass() { pass_ = 0; }
+  // need_ goes back to its value at the start of the failed call too (mark_call): rewind()s inside that call have already folded
+  // the exploding pass into it.
+  void abandon_pass() { pass_ = 0; need_ = need_mark_; }
+  void mark_call() { need_mark_ = need_; }
   size_t used() const { return off_; }
   size_t peak() const { return need_; }
   size_t capacity() const { return cap_; }
@@ -58,7 +61,7 @@ class Arena {
   void* alloc_bytes(size_t bytes);
  private:
   char* base_ = nullptr;
-  size_t cap_ = 0, off_ = 0, pass_ = 0, need_ = 0;
+  size_t cap_ = 0, off_ = 0, pass_ = 0, need_ = 0, need_mark_ = 0;
   std::vector<void*> old_;  // superseded blocks, kept until destruction (in-flight kernels may still read them)
 };
 

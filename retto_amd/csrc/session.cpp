@@ -154,7 +154,8 @@ void rt_session::begin_call() {
                              // hipMalloc, say) must not be what the first RT_LAUNCH of this call reports
   if (failed) { arena.abandon_pass(); scratch.abandon_pass(); dbws.abandon_pass(); failed = false; }
   arena.reset(); scratch.reset(); pinned.reset();
-  last_error.clear();
+  arena.mark_call(); scratch.mark_call(); dbws.mark_call();
+  // (last_error belongs to the API caller's thread -- api.cpp guarded(); lane threads run this function and never touch it)
 }
 // Waiting for the lane's stream.  hipStreamSynchronize spins on the CPU (HIP's default scheduling when there are more CPUs than
 // GPUs): three lanes = three cores at 100 % per rank for the whole step (measured: 3.9 cores busy per rank), which eight ranks
@@ -174,7 +175,9 @@ void rt_session::sync() {
       if (q != hipErrorNotReady) RT_HIP_CHECK(q);
       // (hipEventSynchronize on a hipEventBlockingSync event still kept the thread at 100 % of a core on this ROCm: measured
       //  3.0 cores busy with it, 3.9 with hipStreamSynchronize; so the sleeping is done here: poll, sleep 100 us, poll ...)
-      if (std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(50)) std::this_thread::sleep_for(std::chrono::microseconds(100));
+      //  The spin window is chosen per call: 50 us for multi-page throughput batches, the whole wait (up to 5 ms) for the
+      //  single-page / stage-level calls, whose several sync points per call would otherwise pay ~150 us of sleep each.)
+      if (std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(spin_us)) std::this_thread::sleep_for(std::chrono::microseconds(100));
     }
   }
   if (prof.on) prof.collect();
@@ -513,6 +516,10 @@ rt_results* rt_session::run_pages(const uint8_t* const* rgb, const int* hs, cons
                                   const float* const* det_map_override) {
   if (g_trace) fprintf(stderr, "[rt host] %-28s %8.3f ms\n", "between calls", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - last_exit).count());
   HostTick tick0;
+  // a one-page call is the reference's real mode (retto-cli/src/main.rs:80-86): it polls through its waits; a multi-page batch
+  // is a throughput run whose lane threads must not hold a core each (8 ranks x 3 lanes on a 16-CPU pod)
+  struct SpinScope { int& r; int old; ~SpinScope() { r = old; } } spin_scope{spin_us, spin_us};
+  spin_us = n_pages <= 1 ? 5000 : 50;
   begin_call();
   dbws.reset();
   tick0.lap("begin_call + arena reset");
@@ -924,12 +931,13 @@ rt_ticket* rt_session::submit_batch(const uint8_t* const* rgb, const int* hs, co
   }
   t->remaining = nl;
   rt_ticket* tp = t.get();
-  inflight.fetch_add(1);
   // parts go to consecutive lanes starting behind the previous batch's last one: batches that fill fewer lanes than the session
   // has (single pages: one lane each) run side by side instead of queueing on lane 0
   const int total_lanes = (int)helpers.size() + 1;
   const int base = next_lane;
   next_lane = (next_lane + nl) % total_lanes;
+  int queued = 0;
+  try {
   for (int l = 0; l < nl; l++) {
     const int li = (base + l) % total_lanes;
     rt_session* s = li == 0 ? this : helpers[(size_t)li - 1].get();
@@ -948,10 +956,24 @@ rt_ticket* rt_session::submit_batch(const uint8_t* const* rgb, const int* hs, co
         (void)hipGetLastError();
       }
       s->stage_cb = nullptr; s->stage_mu = nullptr;   // the callback never outlives the batch
-      { std::lock_guard<std::mutex> lk(tp->mu); tp->remaining--; }
-      tp->cv.notify_all();
+      // notify while holding the mutex: rt_wait_batch owns the ticket and deletes it as soon as it sees remaining == 0, so
+      // nothing of *tp may be touched once the decrement is visible outside the lock
+      { std::lock_guard<std::mutex> lk(tp->mu); tp->remaining--; tp->cv.notify_all(); }
     });
+    queued++;
   }
+  } catch (...) {
+    // a push that threw (bad_alloc): the parts already queued hold tp -- take the un-queued ones off the count, wait for the
+    // queued ones, and leave the session as it was (inflight is only counted once every part is queued)
+    {
+      std::unique_lock<std::mutex> lk(tp->mu);
+      tp->remaining -= nl - queued;
+      tp->cv.wait(lk, [&] { return tp->remaining == 0; });
+    }
+    for (auto* r : tp->parts) delete r;
+    throw;
+  }
+  inflight.fetch_add(1);
   return t.release();
 }
 

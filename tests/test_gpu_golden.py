@@ -343,6 +343,26 @@ print("cabi rccl ok")
     assert out.returncode == 0 and "cabi rccl ok" in out.stdout, (out.stdout[-500:], out.stderr[-2000:])
 
 
+def test_bench_runs_the_cabi_broadcast_every_round():
+    """bench.py's own multi-rank path with the one GPU of the box: RT_BENCH_FORCE_DIST=1 makes a world-1
+    run take the distributed branch -- process group over RCCL, rt_rccl_unique_id + rt_broadcast_blobs for the weights (the
+    C-ABI collective a Rust host would call), barrier + MAX all-reduce around the timed region -- so the collective code runs
+    on the driver's box every round even though no 8-GPU node is available."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, RT_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29547", RANK="0", LOCAL_RANK="0",
+               WORLD_SIZE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--bcast", "cabi", "--steps", "2", "--warmup", "1",
+                          "--pages", "3", "--size", "480", "--lines", "4", "--no-c5", "--no-cpu-baseline", "--repeat", "0"],
+                         capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["rccl_ranks"] == 1 and line["bcast_ms"] is not None and line["bcast_ms"] > 0
+    assert line["n_gpus"] == 1 and line["value"] > 0 and line["selfcheck"]["batch_invariance_page0"] is True
+
+
 @pytest.mark.parametrize("style", [0, 1, 2])
 def test_onnx_import_against_unfolded_torch_forward(style):
     """The importer against an INDEPENDENT evaluation of what the file says: the .onnx files are written with un-folded

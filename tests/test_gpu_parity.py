@@ -22,7 +22,8 @@ def _rand_page(h, w, seed):
 
 # ---------------------------------------------------------------- a4 / a9 / a11 networks
 # (3 x 960^2: the squeeze-excite levels reach the sizes where the fused pooling / scaled-GEMM path is taken)
-@pytest.mark.parametrize("n,h,w", [(2, 32, 64), (1, 64, 96), (2, 160, 128), (1, 320, 320), (3, 960, 960), (1, 1984, 1408)])
+# (1 x 960^2 is BASELINE.json configs[1] -- C2's literal workload: one page per call, the small-batch dispatch of every layer)
+@pytest.mark.parametrize("n,h,w", [(2, 32, 64), (1, 64, 96), (2, 160, 128), (1, 320, 320), (1, 960, 960), (3, 960, 960), (1, 1984, 1408)])
 def test_det_net(hip_session, oracle_session, n, h, w):
     x = np.random.default_rng(h + w).uniform(-1, 1, (n, 3, h, w)).astype(np.float32)
     got = hip_session.worker.det(x)
@@ -855,6 +856,45 @@ def test_submit_wait_equals_run_batch(hip_session):
             assert digest(r, len(batches[b][0])) == ref[b], "batch %d differs between rt_run_batch and submit / wait" % b
             lib.rt_results_free(r)
     assert hip_session.worker.cls(np.zeros((1, 3, 48, 192), np.float32)).shape == (1, 2)
+
+
+def test_submit_wait_against_the_oracle_teacher_forced(hip_session, oracle_session):
+    """The TIMED path itself (bench.py times rt_submit_batch / rt_wait_batch with two batches in flight) compared with the
+    oracle directly, not through rt_run_batch: two batches submitted ahead, waited in reverse order, every page against
+    oracle/pipeline.py teacher-forced by the HIP worker (session.rs:75-106 / 108-143) -- boxes, score bit patterns, labels,
+    token ids, text."""
+    lib = hip_session._hd.lib
+    batches = []
+    for b, shapes in enumerate((((640, 640, 6), (480, 704, 4), (352, 512, 3), (640, 480, 5)), ((736, 416, 4), (320, 480, 2)))):
+        pages, maps = [], []
+        for i, (h, w, L) in enumerate(shapes):
+            page, rects = workload.planted_page(h, w, L, seed=300 + 10 * b + i)
+            dh, dw = R.resize_either_dims(h, w)
+            pages.append(page); maps.append(workload.planted_map(dh, dw, h, w, rects))
+        batches.append((pages, maps))
+    tickets = [hip_session.submit_batch_raw(pages, [p.shape[0] for p in pages], [p.shape[1] for p in pages], retto_amd.RT_MEM_HOST, maps)
+               for pages, maps in batches]
+    got = {}
+    for b in (1, 0):
+        r = hip_session.wait_batch_raw(tickets[b])
+        got[b] = [hip_session._collect(r, i) for i in range(len(batches[b][0]))]
+        lib.rt_results_free(r)
+    oracle_session.det_worker = hip_session.worker.det
+    oracle_session.cls_worker = hip_session.worker.cls
+    oracle_session.rec_worker = hip_session.worker.rec
+    lines = 0
+    for b, (pages, maps) in enumerate(batches):
+        for page, m, r in zip(pages, maps, got[b]):
+            o = oracle_session.run(page, det_map_override=m)
+            assert len(r.det_result) == len(o.det_boxes) > 0
+            assert np.array_equal(np.stack([d.boxes.as_array() for d in r.det_result]), o.det_boxes)
+            assert np.array_equal(np.array([d.score for d in r.det_result], np.float32).view(np.uint32), o.det_scores.view(np.uint32))
+            assert [c.label.label for c in r.cls_result] == list(o.cls_labels)
+            for k, (g, ot) in enumerate(zip(r.rec_result, o.rec_tokens)):
+                assert np.array_equal(g.tokens, ot), f"batch {b} line {k} tokens differ"
+                assert g.text == o.rec_text[k]
+            lines += len(o.det_boxes)
+    assert lines >= 20
 
 
 def test_two_sessions_on_two_devices(hip_session):
