@@ -126,13 +126,15 @@ void rt_destroy(rt_session* s) {
     if (h->st) (void)hipStreamSynchronize(h->st);
     if (h->d_flags) (void)hipFree(h->d_flags);
     if (h->ev_block) (void)hipEventDestroy(h->ev_block);
-    if (h->st) (void)hipStreamDestroy(h->st);
+    if (h->st_part) { rt::forget_stream(h->st_part); (void)hipStreamDestroy(h->st_part); }
+    if (h->st_full) (void)hipStreamDestroy(h->st_full);
   }
   s->helpers.clear();
   s->det.reset(); s->cls.reset(); s->rec.reset();
   if (s->d_flags) (void)hipFree(s->d_flags);
   if (s->ev_block) (void)hipEventDestroy(s->ev_block);
-  if (s->st) (void)hipStreamDestroy(s->st);
+  if (s->st_part) { rt::forget_stream(s->st_part); (void)hipStreamDestroy(s->st_part); }
+  if (s->st_full) (void)hipStreamDestroy(s->st_full);
   delete s;
 }
 const char* rt_last_error(const rt_session* s) { return s ? s->last_error.c_str() : g_create_error.c_str(); }

@@ -69,6 +69,8 @@ struct RtError : std::runtime_error {
 // "set once" flag leaves a session created later on another GPU launching > 64 KB of dynamic LDS without it (the launch is
 // then rejected).  allow_big_lds(f, bytes) sets it once per (device, kernel); thread-safe (a session's lanes launch concurrently).
 void allow_big_lds(const void* kernel, int bytes);
+// CUs a kernel launched on `st` can occupy: the stream's CU partition (runtime.h) or the whole device
+int stream_cus(hipStream_t st);
 constexpr int RT_MAX_GRID_Y = 65535;  // HIP limit of gridDim.y / gridDim.z
 
 static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }

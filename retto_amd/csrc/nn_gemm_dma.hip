@@ -487,16 +487,6 @@ void gemm_dma(hipStream_t st, const float* A, int lda, long long M, int K, const
   int dev = 0;
   RT_HIP_CHECK(hipGetDevice(&dev));
   static std::mutex mu;
-  static int cus[64] = {0};
-  if (dev < 0 || dev >= 64) throw RtError(8, "gemm_dma: device index out of range");
-  {
-    std::lock_guard<std::mutex> lk(mu);   // (the lanes of a session launch concurrently)
-    if (!cus[dev]) {
-      hipDeviceProp_t p;
-      RT_HIP_CHECK(hipGetDeviceProperties(&p, dev));
-      cus[dev] = p.multiProcessorCount;
-    }
-  }
   unsigned* sched = nullptr;
   {
     static std::map<std::pair<int, hipStream_t>, unsigned*> counters;   // zero between launches (the kernel resets them)
@@ -513,7 +503,7 @@ void gemm_dma(hipStream_t st, const float* A, int lda, long long M, int K, const
   g.A = A; g.Wp = Wp; g.C = C; g.M = M; g.lda = lda; g.K = K; g.N = N; g.Npad = Npad16; g.ldc = ldc; g.coff = coff;
   g.n_rb = (int)((M + P_BM - 1) / P_BM); g.n_cb = N / P_BN; g.epi = epi;
   g.a_scale = epi.a_scale; g.a_tab = epi.a_tab; g.ld_scale = epi.ld_scale; g.n_img = epi.n_img;
-  const int grid = std::min(g.n_rb * g.n_cb, cus[dev]);
+  const int grid = std::min(g.n_rb * g.n_cb, stream_cus(st));   // (one workgroup per CU of the stream's CU partition)
   // per-XCD tile queues (RT_G32P_XCDQ=0: one queue): needs every workgroup's first tile to exist in its queue
   // Measured (round 4, same box, alternating runs): bit-identical results; in isolation 1.5 % SLOWER (615216 x 480 x 480: 2.311 vs
   // 2.274 ms -- eight queues of 32 workgroups balance worse than one queue of 256), production step 27.90 / 27.91 / 28.41 / 27.90

@@ -5,8 +5,10 @@
 
 #include <cstdio>
 #include <cstring>
+#include <map>
 #include <mutex>
 #include <set>
+#include <vector>
 #include <utility>
 
 namespace rt {
@@ -28,6 +30,83 @@ void allow_big_lds(const void* kernel, int bytes) {
     }
   }
   seen.insert({dev, kernel});   // only once the attribute is known to be set: a throw above must be retried by the next call
+}
+
+// ---- CU partitions ---------------------------------------------------------------------
+namespace {
+__global__ void k_where_am_i(unsigned* out) {
+  unsigned hw, xcc;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+  if (threadIdx.x == 0) out[blockIdx.x] = ((xcc & 15u) << 8) | ((hw >> 8) & 0xffu);   // XCD | shader engine, array, CU
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  while (__builtin_amdgcn_s_memtime() - t0 < 4000) {}   // (stay a moment so that the blocks spread over every CU the mask allows)
+}
+std::mutex g_part_mu;
+std::map<std::pair<int, hipStream_t>, int> g_stream_cus;
+std::map<int, int> g_dev_cus;
+}  // namespace
+
+int stream_cus(hipStream_t st) {
+  int dev = 0;
+  RT_HIP_CHECK(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> lk(g_part_mu);
+  auto it = g_stream_cus.find({dev, st});
+  if (it != g_stream_cus.end()) return it->second;
+  int& c = g_dev_cus[dev];
+  if (!c) {
+    hipDeviceProp_t p;
+    RT_HIP_CHECK(hipGetDeviceProperties(&p, dev));
+    c = p.multiProcessorCount;
+  }
+  return c;
+}
+void forget_stream(hipStream_t st) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return;
+  std::lock_guard<std::mutex> lk(g_part_mu);
+  g_stream_cus.erase({dev, st});
+}
+hipStream_t partition_stream(int part, int parts, int* cus_out, std::vector<unsigned>* cu_ids) {
+  int dev = 0;
+  RT_HIP_CHECK(hipGetDevice(&dev));
+  hipDeviceProp_t p;
+  RT_HIP_CHECK(hipGetDeviceProperties(&p, dev));
+  const int ncu = p.multiProcessorCount;
+  if (ncu != 256 || parts < 2 || parts > 8 || part < 0 || part >= parts) return nullptr;   // (the bit layout below is the 8-XCD x 32-CU part's)
+  // whole groups of 4 slots (slot k lies on shader engine k % 4; workgroups are dealt evenly over the shader engines whatever
+  // their CU counts, so a partition with 3 / 3 / 2 / 2 CUs per engine runs like one with 2 / 2 / 2 / 2)
+  const int k0 = 4 * (8 * part / parts), k1 = 4 * (8 * (part + 1) / parts);
+  std::vector<uint32_t> mask(8, 0u);
+  for (int k = k0; k < k1; k++)
+    for (int x = 0; x < 8; x++) { const int bit = k * 8 + x; mask[(size_t)bit / 32] |= 1u << (bit % 32); }
+  hipStream_t st = nullptr;
+  if (hipExtStreamCreateWithCUMask(&st, (uint32_t)mask.size(), mask.data()) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+  // verify: 2048 one-wave workgroups must land on exactly (k1 - k0) CUs of every XCD
+  bool ok = false;
+  unsigned* d = nullptr;
+  const int nb = 2048;
+  if (hipMalloc((void**)&d, nb * 4) == hipSuccess) {
+    hipLaunchKernelGGL(k_where_am_i, dim3(nb), dim3(64), 0, st, d);
+    std::vector<unsigned> h((size_t)nb);
+    if (hipGetLastError() == hipSuccess && hipStreamSynchronize(st) == hipSuccess &&
+        hipMemcpy(h.data(), d, nb * 4, hipMemcpyDeviceToHost) == hipSuccess) {
+      std::set<unsigned> seen(h.begin(), h.end());
+      int per_xcd[16] = {0};
+      for (unsigned v : seen) per_xcd[(v >> 8) & 15]++;
+      ok = (int)seen.size() == 8 * (k1 - k0);
+      for (int x = 0; x < 8; x++) ok = ok && per_xcd[x] == k1 - k0;
+      if (cu_ids) cu_ids->assign(seen.begin(), seen.end());
+    }
+    (void)hipFree(d);
+  }
+  if (!ok) { (void)hipGetLastError(); (void)hipStreamDestroy(st); return nullptr; }
+  {
+    std::lock_guard<std::mutex> lk(g_part_mu);
+    g_stream_cus[{dev, st}] = 8 * (k1 - k0);
+  }
+  if (cus_out) *cus_out = 8 * (k1 - k0);
+  return st;
 }
 
 // ---- sources / blob ---------------------------------------------------------------

@@ -117,7 +117,8 @@ rt_session* rt_session_create(const rt_config* cfg) {
   Blob br = Blob::from_source(cfg->rec.path, cfg->rec.data, cfg->rec.len, "rec", MODEL_REC);
   std::vector<uint8_t> dict = read_source_bytes(cfg->dict.path, cfg->dict.data, cfg->dict.len, "dict");
   s->cfg.det = s->cfg.cls = s->cfg.rec = s->cfg.dict = rt_model_source{nullptr, nullptr, 0};
-  RT_HIP_CHECK(hipStreamCreateWithFlags(&s->st, hipStreamNonBlocking));
+  RT_HIP_CHECK(hipStreamCreateWithFlags(&s->st_full, hipStreamNonBlocking));
+  s->st = s->st_full;
   // which graph a source holds is read off its tensor names; rt_config.dtype picks the arithmetic
   const bool f16 = cfg->dtype == RT_DTYPE_F16;
   const bool sdet = blob_is_server_det(bd), srec = blob_is_server_rec(br);
@@ -139,11 +140,34 @@ rt_session* rt_session_create(const rt_config* cfg) {
     std::unique_ptr<rt_session> h(new rt_session());
     h->cfg = s->cfg; h->device = s->device;
     h->det = s->det; h->cls = s->cls; h->rec = s->rec; h->dict = s->dict; h->model_info = s->model_info;
-    RT_HIP_CHECK(hipStreamCreateWithFlags(&h->st, hipStreamNonBlocking));
+    RT_HIP_CHECK(hipStreamCreateWithFlags(&h->st_full, hipStreamNonBlocking));
+    h->st = h->st_full;
     RT_HIP_CHECK(hipMalloc((void**)&h->d_flags, 64));
     RT_HIP_CHECK(hipMemset(h->d_flags, 0, 64));
     RT_HIP_CHECK(hipEventCreateWithFlags(&h->ev_block, hipEventBlockingSync | hipEventDisableTiming));
     s->helpers.push_back(std::move(h));
+  }
+  // CU partitions (RT_LANE_CUMASK=1, A/B only): every lane of a multi-lane session gets its own slice of every XCD.  Measured
+  // slower than whole-device streams on C3 (runtime.h "CU partitions"), so the default keeps the lanes time-slicing the chip.
+  static const bool part_on = getenv("RT_LANE_CUMASK") && atoi(getenv("RT_LANE_CUMASK")) != 0;
+  if (part_on && lanes > 1) {
+    std::vector<hipStream_t> ps((size_t)lanes, nullptr);
+    std::vector<int> pc((size_t)lanes, 0);
+    std::vector<std::vector<unsigned>> ids((size_t)lanes);
+    bool ok = true;
+    for (int l = 0; l < lanes && ok; l++) ok = (ps[(size_t)l] = rt::partition_stream(l, lanes, &pc[(size_t)l], &ids[(size_t)l])) != nullptr;
+    for (int a = 0; a < lanes && ok; a++)
+      for (int b = a + 1; b < lanes && ok; b++)
+        for (unsigned v : ids[(size_t)a]) if (std::find(ids[(size_t)b].begin(), ids[(size_t)b].end(), v) != ids[(size_t)b].end()) { ok = false; break; }
+    if (ok) {
+      for (int l = 0; l < lanes; l++) {
+        rt_session* ln = l == 0 ? s.get() : s->helpers[(size_t)l - 1].get();
+        ln->st_part = ps[(size_t)l]; ln->part_cus = pc[(size_t)l];
+      }
+    } else {
+      for (hipStream_t p : ps) if (p) { rt::forget_stream(p); (void)hipStreamDestroy(p); }
+      if (getenv("RT_TRACE")) fprintf(stderr, "[rt] CU partitions could not be verified on this device: lanes keep whole-device streams\n");
+    }
   }
   return s.release();
 }
@@ -934,6 +958,8 @@ rt_ticket* rt_session::submit_batch(const uint8_t* const* rgb, const int* hs, co
   // parts go to consecutive lanes starting behind the previous batch's last one: batches that fill fewer lanes than the session
   // has (single pages: one lane each) run side by side instead of queueing on lane 0
   const int total_lanes = (int)helpers.size() + 1;
+  // (with rt_set_lanes below the session's lane count the partitions would leave CUs unused: whole-device streams then)
+  const bool use_parts = active_lanes >= total_lanes;
   const int base = next_lane;
   next_lane = (next_lane + nl) % total_lanes;
   int queued = 0;
@@ -941,9 +967,12 @@ rt_ticket* rt_session::submit_batch(const uint8_t* const* rgb, const int* hs, co
   for (int l = 0; l < nl; l++) {
     const int li = (base + l) % total_lanes;
     rt_session* s = li == 0 ? this : helpers[(size_t)li - 1].get();
-    workers[(size_t)li]->push([tp, s, l] {
+    workers[(size_t)li]->push([tp, s, l, use_parts] {
       const int f0 = tp->first[l], f1 = tp->first[l + 1];
       s->stage_cb = tp->cb; s->stage_user = tp->user; s->stage_mu = &tp->cb_mu; s->page_base = f0;
+      // a lane inside a submitted batch works on its own CU partition (every call ends with its stream drained, so the lane's
+      // arenas and pinned staging can change streams between calls)
+      s->st = (s->st_part && use_parts) ? s->st_part : s->st_full;
       try {
         tp->parts[l] = s->run_pages(tp->rgb.data() + f0, tp->hs.data() + f0, tp->ws.data() + f0, f1 - f0, tp->mem,
                                     tp->maps.empty() ? nullptr : tp->maps.data() + f0);
@@ -956,6 +985,7 @@ rt_ticket* rt_session::submit_batch(const uint8_t* const* rgb, const int* hs, co
         (void)hipGetLastError();
       }
       s->stage_cb = nullptr; s->stage_mu = nullptr;   // the callback never outlives the batch
+      s->st = s->st_full;
       // notify while holding the mutex: rt_wait_batch owns the ticket and deletes it as soon as it sees remaining == 0, so
       // nothing of *tp may be touched once the decrement is visible outside the lock
       { std::lock_guard<std::mutex> lk(tp->mu); tp->remaining--; tp->cv.notify_all(); }

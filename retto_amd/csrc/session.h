@@ -70,7 +70,10 @@ struct rt_ticket {
 struct rt_session {
   rt_config cfg{};
   int device = 0;
-  hipStream_t st = nullptr;
+  hipStream_t st = nullptr;        // the stream the lane's current call runs on: st_full, or st_part inside a multi-lane batch
+  hipStream_t st_full = nullptr;   // whole device
+  hipStream_t st_part = nullptr;   // this lane's CU partition (runtime.h "CU partitions"); nullptr: not partitioned
+  int part_cus = 0;
   hipEvent_t ev_block = nullptr;   // blocking-sync event behind sync(): the lane's host thread sleeps instead of spinning
   rt::Arena arena;      // lives for one API call: pages, maps, crops, descriptors, outputs
   rt::Arena scratch;    // network activations; rewound per launch group
