@@ -83,13 +83,17 @@ constexpr int V2_HMAX = 8;   // DMA instructions per thread for one halo tile (8
 // (The cross-stage pipelining of k_gemm16p -- barrier in the middle of a stage, the next stage's first fragments read before
 // the stage ends -- was built for the row-wise 3x3 form too and measured 4 % SLOWER (43.8 vs 41.9 ms per C5 step): the row
 // and halo requests then have one stage less to land than with the barrier at the end of the stage.)
-template <int NTN, int KW, int KWR, int DOT = 0>
-__global__ __launch_bounds__(512, 1) void k_conv16v2(const ConvArgs2 c2) {
+// NW = waves per workgroup: 8 (round 2-4: ONE 512-pixel workgroup per CU, whose eight waves move in lockstep from barrier to
+// barrier) or 4 (round 5: 256-pixel tiles in <= 80 KB of LDS, so that TWO independent workgroups share a CU -- each SIMD holds one
+// wave of each -- and one workgroup's DMA waits and barriers are the other's MFMA time; the weight ring shrinks to fit: c2.wslots
+// = 1 is a single weight buffer refilled between two barriers, the partner workgroup being the latency cover)
+template <int NTN, int KW, int KWR, int DOT = 0, int NW = 8>
+__global__ __launch_bounds__(64 * NW, 2) void k_conv16v2(const ConvArgs2 c2) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem2[];
   const ConvArgs& a = c2.a;
   const bool kstamp = RT_STAMP_ON(a.stamps && blockIdx.y == 0 && blockIdx.x == gridDim.x / 2 && threadIdx.x == 0);
   if (kstamp) a.stamps[4000] = __builtin_amdgcn_s_memtime();
-  constexpr int NTHR = 512, NTP = 2, BN = 32 * NTN, ROW = KS;  // LDS row = 32 halves (64 bytes), un-padded
+  constexpr int NTHR = 64 * NW, NTP = 2, BN = 32 * NTN, ROW = KS;  // LDS row = 32 halves (64 bytes), un-padded
   const int TH = a.TH, TW = a.TW;
   // logical block coordinates (bx: tile x channel block, by: image)
   unsigned bx = blockIdx.x, by = blockIdx.y;
@@ -110,7 +114,7 @@ __global__ __launch_bounds__(512, 1) void k_conv16v2(const ConvArgs2 c2) {
   const int SPS = a.KH / RG;    // stages per 32-channel slab
   half_t* hbuf = reinterpret_cast<half_t*>(smem2);
   half_t* wring = hbuf + (size_t)c2.hbufs * c2.hbuf_halves;
-  constexpr int wbuf_halves = ((KW * BN * 4 + 511) & ~511) * 8;   // whole groups of 512 DMA slots
+  constexpr int wbuf_halves = ((KW * BN * 4 + NTHR - 1) / NTHR * NTHR) * 8;   // whole groups of NTHR DMA slots
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
 
@@ -131,8 +135,8 @@ __global__ __launch_bounds__(512, 1) void k_conv16v2(const ConvArgs2 c2) {
     }
   }
   const size_t row_halves = (size_t)KW * a.Npad * KS;
-  const int wave_slot = wid * 64 * 8;   // halves: this wave's 64 consecutive 16-byte slots inside a group of 512
-  const int wslots = c2.wslots, D = wslots - 1;   // prefetch distance in rows
+  const int wave_slot = wid * 64 * 8;   // halves: this wave's 64 consecutive 16-byte slots inside a group of NTHR
+  const int wslots = c2.wslots, D = wslots - 1;   // prefetch distance in rows (0: single buffer, refilled between two barriers)
   auto dma_wrow = [&](int rr) {         // kernel row rr -> ring slot rr % wslots
     half_t* dst = wring + (size_t)(rr % wslots) * wbuf_halves;
     const half_t* wg = a.w + (size_t)rr * row_halves;
@@ -252,7 +256,7 @@ __global__ __launch_bounds__(512, 1) void k_conv16v2(const ConvArgs2 c2) {
     // (round 4: letting the upper four waves -- each shares a SIMD with wave w - 4 and leaves the barrier with it -- make their
     //  requests two MFMA groups later, under the lower waves' MFMAs, changed nothing: 74.3 / 74.3 / 73.7 vs 74.1 / 74.6 / 73.7 ms
     //  per C5 step; removed)
-    if (rr + D < nrows) dma_wrow(rr + D);
+    if (D > 0 && rr + D < nrows) dma_wrow(rr + D);
     bool halo_now = false;
     if (c2.hbufs == 2) { if (dy == 0 && s + 1 < nslab) { dma_halo(s + 1); halo_now = true; } }
     (void)halo_now;
@@ -268,11 +272,13 @@ __global__ __launch_bounds__(512, 1) void k_conv16v2(const ConvArgs2 c2) {
     if (rr + 1 == nrows) break;
     // ---- the next row's data must have landed: everything except the requests made in THIS iteration ----
     const int ns = (rr + 1) / SPS, ndy = (rr + 1) - ns * SPS;
-    if (c2.hbufs == 1 && ndy == 0) {
-      // single halo buffer: every wave is done with the old tile only after the barrier; request and wait here (exposed)
+    if (D == 0 || (c2.hbufs == 1 && ndy == 0)) {
+      // single halo buffer / single weight buffer: every wave is done with the old contents only after the barrier; request and
+      // wait here (exposed; with NW = 4 the CU's other workgroup multiplies meanwhile)
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
-      dma_halo(ns);
+      if (D == 0) dma_wrow(rr + 1);
+      if (c2.hbufs == 1 && ndy == 0) dma_halo(ns);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       continue;
@@ -685,44 +691,99 @@ bool conv16_dma(hipStream_t st, const ConvArgs& a0, int n_img, int maxHo, int ma
     const int nb = (Npad + bn - 1) / bn, cost = nb * bn + 16 * nb;
     if (cost < best) { best = cost; bn2 = bn; }
   }
-  // 512-pixel tile: full-height tiles on short maps; the halo tile must fit V2_HMAX DMA instructions per thread
-  int th, tw;
-  if (maxHo >= 16) { const int ny = (maxHo + 15) / 16; th = maxHo >= 64 ? 16 : (maxHo + ny - 1) / ny; } else th = std::max(maxHo, 1);
-  tw = std::max(1, std::min(512 / th, maxWo));
+  // Workgroup size (round 5): two 4-wave workgroups per CU on 256-pixel tiles (<= 80 KB of LDS each) instead of one 8-wave
+  // workgroup on a 512-pixel tile.  Measured per layer on C5 (tools/layer_profile.py, ms per step, 8 -> 4 waves): the
+  // recognition maps 615216 x 1728 x 192: 6.29 -> 5.46, 1230432 x 1440 x 160: 4.92 -> 4.26, 1x3 neck convs 0.61 -> 0.35; the
+  // 480^2 det maps 1.35 -> 1.22; the 240^2 / 120^2 maps 3.43 -> 3.42 / 1.44 -> 1.34 (with the tile-shape search below; 1.53
+  // without); only the 9x9 rows lose (4.28 -> 5.17: their 37-KB weight rows leave a 4-wave workgroup one buffer) and stay on
+  // 8 waves.  RT_CONV16_NW=8 / 4 forces one form (A/B runs).
+  static const int nw_env = getenv("RT_CONV16_NW") ? atoi(getenv("RT_CONV16_NW")) : 0;
+  static const int group3 = getenv("RT_CONV3_GROUP") ? atoi(getenv("RT_CONV3_GROUP")) : 1;
+  int nw = nw_env == 4 ? 4 : (nw_env == 8 ? 8 : (k9 ? 8 : 4));
+  // (4 waves: the nine-tap form also where the 128-channel blocks of the row-wise form would be partly empty -- N = 224:
+  //  2.36 -> 2.08 ms per step for the five 307608 x 2016 x 224 layers)
+  const bool g3 = KH == 3 && KW == 3 && Npad >= 64 && (group3 == 2 || (group3 == 1 && (bn2 < 128 || (nw == 4 && Npad % 128 != 0))));
+  if (g3) bn2 = 64;
+  const int taps = g3 ? 9 : (k22 ? 4 : KW);
   auto hpix = [&](int t_h, int t_w) { return ((t_h - 1) * SH + KH) * ((t_w - 1) * SW + KW); };
-  while (hpix(th, tw) * 4 > V2_HMAX * 512 && tw > 8) tw--;
-  if (hpix(th, tw) * 4 > V2_HMAX * 512) return false;
+  auto magic = [](int d) { return d <= 1 ? 0u : (unsigned)((1ull << 32) / (unsigned)d + 1); };
+  // one plan per workgroup size: tile, halo buffers, weight ring
+  struct Plan { bool ok = false; int th = 0, tw = 0, hbuf_halves = 0, hbufs = 0, wslots = 0; size_t lds = 0; };
+  auto plan = [&](int nw) {
+    Plan p;
+    const int nthr = 64 * nw, px = 64 * nw;
+    const size_t cap = nw == 8 ? (size_t)160 * 1024 : (size_t)80 * 1024;
+    // full-height tiles on short maps; on taller ones the tile shape that wastes the fewest of the workgroup's pixel slots on
+    // the largest image (a 120 x 120 map under 15 x 17 tiles pays for 136 columns; 12 x 20 tiles fill 94 % of their slots),
+    // ties (within 3 %) going to the shape with the smaller halo; the halo tile must fit V2_HMAX DMA instructions per thread
+    static const int tile_search = getenv("RT_CONV16_TILES") ? atoi(getenv("RT_CONV16_TILES")) : 1;
+    int th, tw;
+    if (maxHo >= 16) { const int ny = (maxHo + 15) / 16; th = maxHo >= 64 ? 16 : (maxHo + ny - 1) / ny; } else th = std::max(maxHo, 1);
+    tw = std::max(1, std::min(px / th, maxWo));
+    if (tile_search && nw == 4 && maxHo >= 16) {   // (8 waves: the 16 x 32 tiles the kernel was tuned with measured better)
+      double best_eff = 0, best_halo = 1e30;
+      int bh = th, bw = tw;
+      for (int h = 8; h <= std::min(32, maxHo); h++) {
+        const int ny = (maxHo + h - 1) / h, hh = (maxHo + ny - 1) / ny;          // balanced rows
+        int w = std::max(1, std::min(px / hh, maxWo));
+        const int nx = (maxWo + w - 1) / w; w = (maxWo + nx - 1) / nx;            // balanced columns
+        if (hpix(hh, w) * 4 > V2_HMAX * nthr) continue;
+        const double eff = (double)maxHo * maxWo / ((double)ny * nx * px), halo = (double)hpix(hh, w) / (hh * w);
+        if (eff > best_eff * 1.03 || (eff > best_eff * 0.97 && halo < best_halo)) { best_eff = std::max(eff, best_eff); best_halo = halo; bh = hh; bw = w; }
+      }
+      th = bh; tw = bw;
+    }
+    while (hpix(th, tw) * 4 > V2_HMAX * nthr && tw > 8) tw--;
+    if (hpix(th, tw) * 4 > V2_HMAX * nthr) return p;
+    p.th = th; p.tw = tw;
+    p.hbuf_halves = ((hpix(th, tw) * 4 + nthr - 1) / nthr * nthr) * 8;
+    const size_t wslot_bytes = (size_t)((taps * bn2 * 4 + nthr - 1) / nthr * nthr) * 16, hbytes = (size_t)p.hbuf_halves * 2;
+    // 8 waves: the ring the kernel was tuned with (3 rows, 2 for the nine-tap stages), two halo buffers if they fit.
+    // 4 waves: the deepest buffering within 80 KB -- weights first (a stage's weights are needed at its first k-step, the halo of
+    // the NEXT slab only KH / RG stages later)
+    const int want_w = (k9 || g3) ? 2 : 3;
+    if (nw == 8) {
+      p.wslots = want_w;
+      p.hbufs = (2 * hbytes + wslot_bytes * p.wslots <= cap) ? 2 : 1;
+    } else {
+      p.wslots = 0;
+      for (int ws = want_w; ws >= 1 && !p.wslots; ws--)
+        for (int hb = 2; hb >= 1 && !p.wslots; hb--)
+          if (hb * hbytes + ws * wslot_bytes <= cap) { p.wslots = ws; p.hbufs = hb; }
+      if (!p.wslots) return p;
+    }
+    if (p.hbufs * hbytes + wslot_bytes * p.wslots > cap) return p;
+    p.lds = std::max(p.hbufs * hbytes + wslot_bytes * p.wslots, (size_t)nw * (32 * (bn2 + 8) + 128) * 2);   // main loop | epilogue scratch
+    if (p.lds > cap) return p;
+    p.ok = true;
+    return p;
+  };
+  Plan pl = plan(nw);
+  if (!pl.ok && nw == 4) { nw = 8; pl = plan(8); }
+  if (!pl.ok) return false;
+  const int th = pl.th, tw = pl.tw;
   ConvArgs2 c2;
   c2.a = a0; c2.a.TH = th; c2.a.TW = tw; c2.a.lp = KS; c2.a.nzb = (Npad + bn2 - 1) / bn2;
   c2.zeros = zero_page16();
-  auto magic = [](int d) { return d <= 1 ? 0u : (unsigned)((1ull << 32) / (unsigned)d + 1); };
   c2.hw_magic = magic((tw - 1) * SW + KW); c2.tw_magic = magic(tw);
-  c2.hbuf_halves = ((hpix(th, tw) * 4 + 511) & ~511) * 8;
-  // 3x3: all nine taps of a slab as ONE stage on 64-channel blocks (72 MFMAs per wave between barriers, like the 9x9 rows)
-  // where the row-wise form would run 96- or 64-channel blocks anyway (N = 64, 160, 192); with 128-channel blocks
-  // (N = 128, 224: 48 MFMAs per row and wave, weights re-read per 128 instead of 64 channels) the row-wise form measured
-  // 10-15 % faster.  RT_CONV3_GROUP=0 / 2 forces row-wise / grouped (A/B runs).
-  static const int group3 = getenv("RT_CONV3_GROUP") ? atoi(getenv("RT_CONV3_GROUP")) : 1;
-  const bool g3 = KH == 3 && KW == 3 && Npad >= 64 && (group3 == 2 || (group3 == 1 && bn2 < 128));
-  if (g3) { bn2 = 64; c2.a.nzb = (Npad + 63) / 64; }
-  const int taps = g3 ? 9 : (k22 ? 4 : KW);
-  c2.wslots = (k9 || g3) ? 2 : 3;
-  const size_t wbytes = (size_t)((taps * bn2 * 4 + 511) & ~511) * 16 * c2.wslots;
-  c2.hbufs = (2 * (size_t)c2.hbuf_halves * 2 + wbytes <= 160 * 1024) ? 2 : 1;
-  if ((size_t)c2.hbufs * c2.hbuf_halves * 2 + wbytes > 160 * 1024) return false;
-  const size_t lds2 = std::max((size_t)c2.hbufs * c2.hbuf_halves * 2 + wbytes, (size_t)8 * (32 * (bn2 + 8) + 128) * 2);  // main loop | epilogue scratch
+  c2.hbuf_halves = pl.hbuf_halves; c2.hbufs = pl.hbufs; c2.wslots = pl.wslots;
+  const size_t lds2 = pl.lds;
   const long long tiles2 = (long long)((maxWo + tw - 1) / tw) * ((maxHo + th - 1) / th);
   dim3 grid2((unsigned)(tiles2 * c2.a.nzb), (unsigned)n_img);
   for (const void* f : {(const void*)k_conv16v2<1, 1, 1>, (const void*)k_conv16v2<2, 1, 1>, (const void*)k_conv16v2<3, 1, 1>, (const void*)k_conv16v2<4, 1, 1>,
                         (const void*)k_conv16v2<1, 3, 3>, (const void*)k_conv16v2<2, 3, 3>, (const void*)k_conv16v2<3, 3, 3>, (const void*)k_conv16v2<4, 3, 3>,
                         (const void*)k_conv16v2<2, 9, 9>, (const void*)k_conv16v2<2, 9, 3>, (const void*)k_conv16v2<2, 4, 2, 1>})
     allow_big_lds(f, 160 * 1024);
-#define RT_V2_LAUNCH(NT) \
-  switch (KW) { case 1: RT_LAUNCH((k_conv16v2<NT, 1, 1>), grid2, dim3(512), lds2, st, c2); break; \
-                default: RT_LAUNCH((k_conv16v2<NT, 3, 3>), grid2, dim3(512), lds2, st, c2); break; }
-  if (k9) { RT_LAUNCH((k_conv16v2<2, 9, 9>), grid2, dim3(512), lds2, st, c2); return true; }
-  if (g3) { RT_LAUNCH((k_conv16v2<2, 9, 3>), grid2, dim3(512), lds2, st, c2); return true; }
-  if (k22) { RT_LAUNCH((k_conv16v2<2, 4, 2, 1>), grid2, dim3(512), lds2, st, c2); return true; }
+  for (const void* f : {(const void*)k_conv16v2<1, 1, 1, 0, 4>, (const void*)k_conv16v2<2, 1, 1, 0, 4>, (const void*)k_conv16v2<3, 1, 1, 0, 4>, (const void*)k_conv16v2<4, 1, 1, 0, 4>,
+                        (const void*)k_conv16v2<1, 3, 3, 0, 4>, (const void*)k_conv16v2<2, 3, 3, 0, 4>, (const void*)k_conv16v2<3, 3, 3, 0, 4>, (const void*)k_conv16v2<4, 3, 3, 0, 4>,
+                        (const void*)k_conv16v2<2, 9, 9, 0, 4>, (const void*)k_conv16v2<2, 9, 3, 0, 4>, (const void*)k_conv16v2<2, 4, 2, 1, 4>})
+    allow_big_lds(f, 80 * 1024);
+#define RT_V2_GO(NT, KWV, KWRV, DOTV) do { if (nw == 4) RT_LAUNCH((k_conv16v2<NT, KWV, KWRV, DOTV, 4>), grid2, dim3(256), lds2, st, c2); \
+                                          else RT_LAUNCH((k_conv16v2<NT, KWV, KWRV, DOTV, 8>), grid2, dim3(512), lds2, st, c2); } while (0)
+#define RT_V2_LAUNCH(NT) do { if (KW == 1) RT_V2_GO(NT, 1, 1, 0); else RT_V2_GO(NT, 3, 3, 0); } while (0)
+  if (k9) { RT_V2_GO(2, 9, 9, 0); return true; }
+  if (g3) { RT_V2_GO(2, 9, 3, 0); return true; }
+  if (k22) { RT_V2_GO(2, 4, 2, 1); return true; }
   switch (bn2 / 32) {
     case 1: RT_V2_LAUNCH(1); break;
     case 2: RT_V2_LAUNCH(2); break;
@@ -730,6 +791,7 @@ bool conv16_dma(hipStream_t st, const ConvArgs& a0, int n_img, int maxHo, int ma
     default: RT_V2_LAUNCH(4); break;
   }
 #undef RT_V2_LAUNCH
+#undef RT_V2_GO
   return true;
 }
 
