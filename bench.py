@@ -625,6 +625,24 @@ def main():
             b_layer = 500e6 * sum(dh_ * dw_ for dh_, dw_ in det_dims) / (960.0 * 960.0)
             networks["det_b_layer_gbs"] = round(b_layer / (nets["det"] * 1e-3) / 1e9, 1)
             networks["det_b_layer_frac_of_hbm_peak"] = round(b_layer / (nets["det"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+            # the same network by the COUNTERS: FETCH_SIZE (x2 on gfx950) + WRITE_SIZE summed over the det launches of one pass
+            # (tools/pmc_det_bytes.py, committed as profiles/pmc_det_c3.json with the digest of the sources it was taken on)
+            # over this run's det_ms -- what the HBM actually moved, next to the formula figure above
+            dpath = os.path.join(ROOT, "profiles", "pmc_det_c3.json")
+            if os.path.exists(dpath) and a.size == 960:
+                from retto_amd import _lib as _L2
+                dj = json.load(open(dpath))
+                now = _L2.source_digest()
+                stale = now != dj.get("csrc_digest")
+                per_page = dj["det_hbm_bytes_per_pass"] / float(dj["workload"]["pages"])
+                networks["det_pmc"] = {"file": "profiles/pmc_det_c3.json", "stale": stale, "collected_on_csrc_digest": dj.get("csrc_digest"),
+                                       "hbm_bytes_per_page": int(per_page),
+                                       "fetch_bytes_per_page": int(dj["det_fetch_bytes_per_pass"] / float(dj["workload"]["pages"])),
+                                       "write_bytes_per_page": int(dj["det_write_bytes_per_pass"] / float(dj["workload"]["pages"]))}
+                if not stale:
+                    gbs_pmc = per_page * n_my / (nets["det"] * 1e-3) / 1e9
+                    networks["det_pmc_gbs"] = round(gbs_pmc, 1)
+                    networks["det_pmc_frac_of_hbm_peak"] = round(gbs_pmc / HBM_PEAK_GBS, 4)
 
     # ---- C2: launch-gap accounting of the batch-1 det path ----------------------------------------------------
     c2 = None

@@ -19,6 +19,10 @@ for w in c3 c5; do
 done
 python3 tools/pmc_summary.py $out/c3_fetch/f_counter_collection.csv $out/c3_write/w_counter_collection.csv $out/pmc_traffic_c3.json $out/c3_sq/s_counter_collection.csv '{"workload": "c3", "pages": 32, "size": 960, "lines": 32, "dtype": "f32", "models": "mobile"}' > $out/pmc_c3.txt
 python3 tools/pmc_summary.py $out/c5_fetch/f_counter_collection.csv $out/c5_write/w_counter_collection.csv $out/pmc_traffic_c5.json $out/c5_sq/s_counter_collection.csv '{"workload": "c5", "pages": 32, "size": 960, "lines": 32, "dtype": "f16", "models": "server"}' > $out/pmc_c5.txt
+# det network alone: HBM bytes per pass from the counters (north_star: rocprof-reported HBM GB/s of the DBNet backbone)
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/det_fetch -o f -- python3 tools/layer_profile.py 32 1 0 > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/det_write -o w -- python3 tools/layer_profile.py 32 1 0 > /dev/null 2>&1
+python3 tools/pmc_det_bytes.py $out/det_fetch/f_counter_collection.csv $out/det_write/w_counter_collection.csv $out/pmc_det_c3.json > $out/pmc_det.txt 2>&1
 RT_PROFILE_DETAIL=1 python3 tools/layer_profile.py 32 3 > $out/c3_layers.txt 2>&1
 RT_PROFILE_DETAIL=1 python3 tools/layer_profile.py 32 3 0 > $out/c3_det_layers.txt 2>&1
 WORKLOAD=c5 RT_PROFILE_DETAIL=1 python3 tools/layer_profile.py 32 3 > $out/c5_layers.txt 2>&1
