@@ -57,27 +57,6 @@ static DbWs carve(void* base, int H, int W, int max_boxes, size_t* total) {
 size_t db_workspace_bytes(int H, int W, int max_boxes) { size_t t; carve(nullptr, H, W, max_boxes, &t); return t; }
 size_t db_page_desc_bytes() { return sizeof(DbPage); }
 
-// det_processor.rs:286-292: mask = pred > thresh; grayscale_dilate with offsets
-// {(-1,-1),(0,-1),(-1,0),(0,0)}.  Also resets the per-pixel work arrays.
-__global__ __launch_bounds__(256) void k_db_mask(const DbPage* __restrict__ pages, float thresh, int dilate) {
-  const DbPage pg = pages[blockIdx.y];
-  const int H = pg.H, W = pg.W;
-  int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= H * W) return;
-  int y = i / W, x = i % W;
-  const float* pred = pg.pred;
-  bool m = pred[i] > thresh;
-  if (dilate) {
-    if (x > 0) m = m || pred[i - 1] > thresh;
-    if (y > 0) m = m || pred[i - W] > thresh;
-    if (x > 0 && y > 0) m = m || pred[i - W - 1] > thresh;
-  }
-  const DbWs& ws = pg.ws;
-  ws.mask[i] = m ? 255 : 0;
-  ws.ymin[i] = 0x7fffffff; ws.ymax[i] = -1; ws.cidx[i] = -1; ws.outside[i] = 0;
-  if (i < 8) ws.counters[i] = 0;
-}
-
 __device__ __forceinline__ int uf_find(const int* parent, int x) {
   int p = parent[x];
   while (p != x) { x = p; p = parent[x]; }
@@ -94,25 +73,46 @@ __device__ __forceinline__ void uf_union(int* parent, int a, int b) {
   }
 }
 
-// Connected components, step 1: every pixel points at the first pixel of its horizontal
-// run (same mask value).  One block per image row; block-wide max-scan of run starts.
-__global__ __launch_bounds__(256) void k_ccl_rows(const DbPage* __restrict__ pages) {
+// det_processor.rs:286-292: mask = pred > thresh; grayscale_dilate with offsets {(-1,-1),(0,-1),(-1,0),(0,0)} -- and, in the
+// same pass, connected components step 1: every pixel points at the first pixel of its horizontal run (same mask value).
+// One block per image row; block-wide max-scan of run starts.  (Round 5: until then k_db_mask was its own pass that also reset
+// four per-pixel work arrays -- 18 bytes written per pixel, 0.18 ms per 32 pages.  ymin / ymax / cidx / outside are only ever
+// read or updated at the ROOT of a component, and a root is the smallest pixel index of its component, i.e. the first pixel
+// of a run: they are initialised at run starts only, here.)
+__global__ __launch_bounds__(256) void k_ccl_rows(const DbPage* __restrict__ pages, float thresh, int dilate) {
   const DbPage pg = pages[blockIdx.y];
   const int W = pg.W;
   int y = blockIdx.x;
   if (y >= pg.H) return;
   __shared__ int wave_max[4];
   __shared__ int carry_s;
-  const u8* mrow = pg.ws.mask + (size_t)y * W;
-  int* prow = pg.ws.parent + (size_t)y * W;
+  const DbWs& ws = pg.ws;
+  if (y == 0 && threadIdx.x < 8) ws.counters[threadIdx.x] = 0;
+  const float* prow0 = pg.pred + (size_t)y * W;
+  const float* prow1 = prow0 - W;   // (read only when y > 0)
+  u8* mrow = ws.mask + (size_t)y * W;
+  int* prow = ws.parent + (size_t)y * W;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const bool up = dilate && y > 0;
+  // t(x) = the column's own two taps; mask(x) = t(x) | t(x - 1) under dilation
+  auto t = [&](int x) { return prow0[x] > thresh || (up && prow1[x] > thresh); };
   int carry = 0;
   for (int x0 = 0; x0 < W; x0 += 256) {
     int x = x0 + threadIdx.x;
     int v = -1;
-    if (x < W && (x == 0 || mrow[x - 1] != mrow[x])) v = x;
+    if (x < W) {
+      const bool t0 = t(x), t1 = x > 0 && t(x - 1), t2 = x > 1 && t(x - 2);
+      const bool m = dilate ? (t0 || t1) : t0;
+      const bool ml = dilate ? (t1 || t2) : t1;    // mask of the left neighbour (x > 0)
+      mrow[x] = m ? 255 : 0;
+      if (x == 0 || ml != m) {
+        v = x;
+        const size_t i = (size_t)y * W + x;
+        ws.ymin[i] = 0x7fffffff; ws.ymax[i] = -1; ws.cidx[i] = -1; ws.outside[i] = 0;
+      }
+    }
     // inclusive max-scan inside the wave
-    for (int o = 1; o < 64; o <<= 1) { int t = __shfl_up(v, o); if (lane >= o) v = max(v, t); }
+    for (int o = 1; o < 64; o <<= 1) { int tt = __shfl_up(v, o); if (lane >= o) v = max(v, tt); }
     if (lane == 63) wave_max[wave] = v;
     __syncthreads();
     int pre = carry;
@@ -793,8 +793,7 @@ void db_postprocess_batch(hipStream_t st, int n, const DbPageIn* in, const DbPar
   (void)hipMemcpyAsync(d_desc, h_desc, (size_t)n * sizeof(DbPage), hipMemcpyHostToDevice, st);
   const DbPage* dp = (const DbPage*)d_desc;
   dim3 grid((maxN + 255) / 256, n), blk(256);
-  RT_LAUNCH(k_db_mask, grid, blk, 0, st, dp, p.thresh, p.dilate);
-  RT_LAUNCH(k_ccl_rows, dim3(maxH, n), blk, 0, st, dp);
+  RT_LAUNCH(k_ccl_rows, dim3(maxH, n), blk, 0, st, dp, p.thresh, p.dilate);
   RT_LAUNCH(k_ccl_link, grid, blk, 0, st, dp);
   RT_LAUNCH(k_ccl_stats, grid, blk, 0, st, dp);
   RT_LAUNCH(k_contour_alloc, grid, blk, 0, st, dp);

@@ -20,7 +20,7 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 # not part of the det network: DB post (dbpost_kernels.hip), pre / post stages (prepost_kernels.hip), the map checksum
-NOT_DET = re.compile(r"k_db_mask|k_ccl_|k_contour_|k_row_extents|k_sort_boxes|k_pack_boxes|k_thumbnail|k_det_normalize|k_warp_crops|k_resize_norm|"
+NOT_DET = re.compile(r"k_ccl_|k_contour_|k_row_extents|k_sort_boxes|k_pack_boxes|k_thumbnail|k_det_normalize|k_warp_crops|k_resize_norm|"
                      r"k_cls_post|k_ctc_|k_sum_partial|k_where_am_i|__amd_rocclr")   # (rocclr: the runtime's own fill / copy kernels)
 
 
