@@ -2374,10 +2374,95 @@ __global__ __launch_bounds__(64) void k_attention(const float* __restrict__ qkv,
     for (int d = 0; d < HD; d++) out[(g.off + t) * C + head * HD + d] = acc[d] * inv;
   }
 }
+// Round 5: one workgroup per text line.  k_attention above is one wave per (64 queries, head, line): a line of T ~ 50 tokens
+// gives 8 one-wave blocks that each gather their head's K / V with 4-byte loads at a 1440-byte stride (24 scattered load
+// instructions per thread in a dependent loop) -- 140 us per launch for 1.2 GFLOP.  Here the 256 threads of a line's workgroup
+// stage a 64-key tile of K and V for ALL heads with 16-byte loads of whole rows (the three projections of a token are 1440
+// contiguous bytes), re-laid per head into 16-float LDS rows, and a thread owns one (query, head) pair: a key costs 8
+// ds_read_b128 (lanes of a wave are consecutive queries of one head: broadcast reads) instead of 30 ds_read_b32.  Same keys in
+// the same order through the same online-softmax recurrence: bit-identical to k_attention.
+template <int HD>
+__global__ __launch_bounds__(256) void k_attention_line(const float* __restrict__ qkv, const ImgGeom* __restrict__ geom,
+                                                        int heads, float* __restrict__ out) {
+  static_assert(HD <= 16, "a head's row is padded to 16 floats");
+  extern __shared__ __attribute__((aligned(16))) float att_lds[];
+  const ImgGeom g = geom[blockIdx.x];
+  const int T = g.H * g.W, C = heads * HD;
+  if (T <= 0) return;
+  float* ks = att_lds;                       // [64 keys][heads][16]
+  float* vs = att_lds + 64 * heads * 16;
+  const int tid = threadIdx.x;
+  const float scale = 1.0f / sqrtf((float)HD);
+  const int pairs = T * heads;
+  const int C4 = C / 4;                      // 16-byte chunks of one projection of a token
+  for (int p0 = 0; p0 < pairs; p0 += 256) {
+    const int p = p0 + tid;
+    const bool valid = p < pairs;
+    const int head = valid ? p / T : 0, t = valid ? p - head * T : 0;
+    float qv[HD], acc[HD];
+#pragma unroll
+    for (int d = 0; d < HD; d++) {
+      qv[d] = valid ? qkv[(g.off + t) * 3 * C + head * HD + d] * scale : 0.f;
+      acc[d] = 0.f;
+    }
+    float m = -INFINITY, l = 0.f;
+    for (int k0 = 0; k0 < T; k0 += 64) {
+      const int kn = min(64, T - k0);
+      __syncthreads();
+      // stage: chunk j of key kk (K and V): 4 consecutive channels c .. c + 3 -> [kk][c / HD][c % HD]
+      for (int i = tid; i < kn * C4; i += 256) {
+        const int kk = i / C4, j = i - kk * C4;
+        const float* row = qkv + (g.off + k0 + kk) * 3 * C;
+        const f32x4 kq = *reinterpret_cast<const f32x4*>(row + C + 4 * j);
+        const f32x4 vq = *reinterpret_cast<const f32x4*>(row + 2 * C + 4 * j);
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          const int c = 4 * j + e, hh = c / HD, d = c - hh * HD;
+          ks[(kk * heads + hh) * 16 + d] = kq[e];
+          vs[(kk * heads + hh) * 16 + d] = vq[e];
+        }
+      }
+      __syncthreads();
+      for (int kk = 0; kk < kn; kk++) {
+        const f32x4* kr = reinterpret_cast<const f32x4*>(ks + (kk * heads + head) * 16);
+        const f32x4* vr = reinterpret_cast<const f32x4*>(vs + (kk * heads + head) * 16);
+        float kv[16], vv[16];
+#pragma unroll
+        for (int c4 = 0; c4 < 4; c4++) {
+          const f32x4 a = kr[c4], b = vr[c4];
+#pragma unroll
+          for (int e = 0; e < 4; e++) { kv[4 * c4 + e] = a[e]; vv[4 * c4 + e] = b[e]; }
+        }
+        float sdot = 0.f;
+#pragma unroll
+        for (int d = 0; d < HD; d++) sdot = fmaf(qv[d], kv[d], sdot);
+        // (v_exp_f32 forms: 2 instructions instead of ~15 each -- the loop is VALU-bound: 27 M (query, key) pairs per step)
+        const float mn = fmaxf(m, sdot);
+        const float corr = __expf(m - mn), pe = __expf(sdot - mn);
+        l = l * corr + pe;
+#pragma unroll
+        for (int d = 0; d < HD; d++) acc[d] = fmaf(acc[d], corr, pe * vv[d]);
+        m = mn;
+      }
+    }
+    if (valid) {
+      const float inv = 1.0f / l;
+#pragma unroll
+      for (int d = 0; d < HD; d++) out[(g.off + t) * C + head * HD + d] = acc[d] * inv;
+    }
+  }
+}
+int g_attention_line = getenv("RT_ATT_LINE") ? atoi(getenv("RT_ATT_LINE")) : 1;   // A/B: 0 = k_attention (one wave per 64 queries and head)
 void attention(hipStream_t st, const float* qkv, const ImgGeom* geom, int n_img, int maxT, int heads, int hd,
                float* out) {
   if (n_img <= 0) return;
   if (hd != 15) throw RtError(8, "attention: head dim must be 15");
+  if (g_attention_line && (heads * hd) % 4 == 0 && heads <= 8) {
+    const size_t lds = (size_t)2 * 64 * heads * 16 * 4;   // 64 KB at 8 heads
+    allow_big_lds((const void*)k_attention_line<15>, 64 * 1024);
+    RT_LAUNCH(k_attention_line<15>, dim3((unsigned)n_img), dim3(256), lds, st, qkv, geom, heads, out);
+    return;
+  }
   RT_LAUNCH(k_attention<15>, dim3((maxT + 63) / 64, heads, n_img), dim3(64), 0, st, qkv, geom, heads, out);
 }
 
