@@ -29,3 +29,8 @@ WORKLOAD=c5 RT_PROFILE_DETAIL=1 python3 tools/layer_profile.py 32 3 > $out/c5_la
 cp $out/c3_trace/t_kernel_stats.csv $out/c3_kernel_stats.csv 2>/dev/null
 cp $out/c5_trace/t_kernel_stats.csv $out/c5_kernel_stats.csv 2>/dev/null
 ls $out
+# one bench line per other workload of the final build (C2: det only, one page per call; C4: mixed page sizes) and the default run
+python3 bench.py --workload c2 --no-cpu-baseline --no-c5 > $out/bench_c2.json 2> $out/bench_c2.err
+python3 bench.py --workload c4 --no-cpu-baseline --no-c5 > $out/bench_c4.json 2> $out/bench_c4.err
+python3 bench.py > $out/bench_default.json 2> $out/bench_default.err
+ls $out
