@@ -137,7 +137,7 @@ static Epi16 epi16(const Conv16& w, int act, const Lab* lab = nullptr, const hal
 static void conv_sp16(RunCtx& c, const Conv16& w, H16 x, const Level& Lin, const Level& Lout, int sh, int sw, H16 y, int coff,
                       const Epi16& e, int pt = -1, int pl = -1) {
   if (x.C != w.cin) throw RtError(3, "conv16: input has " + std::to_string(x.C) + " channels, weights expect " + std::to_string(w.cin));
-  ProfScope ps(c.prof, c.st, nh::conv16_label(w.kh, w.kw, w.cout), shp(Lout.total, (long long)w.kh * w.kw * w.cin, w.cout, sh * 10 + sw));
+  ProfScope ps(c.prof, c.st, nh::conv16_label(w.kh, w.kw, w.cout, w.cin), shp(Lout.total, (long long)w.kh * w.kw * w.cin, w.cout, sh * 10 + sw));
   nh::conv16(c.st, x.p, x.ld, Lin.d, Lout.d, Lout.n(), Lout.maxH, Lout.maxW, w.cin_p, w.kh, w.kw, sh, sw, pt < 0 ? w.kh / 2 : pt,
              pl < 0 ? w.kw / 2 : pl, w.w, w.cout, w.npad, y.p, y.ld, coff, e);
 }

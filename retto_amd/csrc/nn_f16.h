@@ -47,7 +47,7 @@ void conv16(hipStream_t st, const half_t* x, int ldx, const ImgGeom* gin, const 
             const Epi16& epi);
 // same contraction as a plain GEMM over rows: y[M][ldy] = epi(x[M][ldx] (K = Cin) . W); geometry tables are built on device
 // memory the caller provides (one ImgGeom: {0, 1, M})
-const char* conv16_label(int KH, int KW, int N);
+const char* conv16_label(int KH, int KW, int N, int Cin = 32);
 bool conv_stamps_compiled();   // true in a `make STAMPS=1` build
 extern long long* g_conv_stamps;  // diagnostics: when set, one workgroup of every conv16 launch records s_memtime per stage
 

@@ -227,9 +227,11 @@ static void choose_tile(int maxHo, int maxWo, int* TH, int* TW) {
   *TH = th; *TW = tw;
 }
 
-const char* conv16_label(int KH, int KW, int N) {
+const char* conv16_label(int KH, int KW, int N, int Cin) {
   if (KH == 1 && KW == 1) return N <= 64 ? "gemm16/thin" : "gemm16";
-  if (KH == 3 && KW == 3) return "conv16_3x3";
+  // (the stems -- fewer than 32 input channels -- never take the LDS-DMA kernel: their own family, so that `conv16_3x3` is priced and
+  //  counter-measured over the same launches)
+  if (KH == 3 && KW == 3) return Cin < 32 ? "conv16_stem" : "conv16_3x3";
   if (KH == 9) return "conv16_9x9";
   return "conv16_kxk";
 }

@@ -312,19 +312,19 @@ def page_flops(det_hw: Tuple[int, int], widths: Iterable[int]) -> float:
 H2 = 2  # bytes per fp16
 
 
-def conv16_label(kh: int, kw: int, n: int) -> str:
+def conv16_label(kh: int, kw: int, n: int, cin: int = 32) -> str:
     """Mirror of nh::conv16_label (retto_amd/csrc/nn_f16.hip)."""
     if kh == 1 and kw == 1:
         return "gemm16/thin" if n <= 64 else "gemm16"
     if (kh, kw) == (3, 3):
-        return "conv16_3x3"
+        return "conv16_stem" if cin < 32 else "conv16_3x3"
     if kh == 9:
         return "conv16_9x9"
     return "conv16_kxk"
 
 
 def _conv16(add, pix_in, pix_out, cin, cout, kh, kw):
-    add(conv16_label(kh, kw, cout), (pix_in * cin + pix_out * cout) * H2 + kh * kw * cin * cout * H2, 2.0 * pix_out * kh * kw * cin * cout)
+    add(conv16_label(kh, kw, cout, cin), (pix_in * cin + pix_out * cout) * H2 + kh * kw * cin * cout * H2, 2.0 * pix_out * kh * kw * cin * cout)
 
 
 def _lc16(add, h, ww, blocks):
