@@ -97,6 +97,60 @@ __global__ __launch_bounds__(256) void k_ccl_rows(const DbPage* __restrict__ pag
   // t(x) = the column's own two taps; mask(x) = t(x) | t(x - 1) under dilation
   auto t = [&](int x) { return prow0[x] > thresh || (up && prow1[x] > thresh); };
   int carry = 0;
+  if ((W & 3) == 0 && ((size_t)pg.pred & 15) == 0) {
+    // four pixels per thread (16-byte loads of the map, one 16-byte store of the run pointers, one 4-byte store of the mask): a
+    // 960-pixel row is one pass of the block instead of four
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    typedef int i4 __attribute__((ext_vector_type(4)));
+    for (int x0 = 0; x0 < W; x0 += 1024) {
+      const int x = x0 + 4 * threadIdx.x;
+      int v[4] = {-1, -1, -1, -1};
+      bool m[4] = {false, false, false, false};
+      if (x < W) {
+        const f4 a0 = *reinterpret_cast<const f4*>(prow0 + x);
+        f4 a1 = {0.f, 0.f, 0.f, 0.f}, l0 = {0.f, 0.f, 0.f, 0.f}, l1 = {0.f, 0.f, 0.f, 0.f};
+        if (up) a1 = *reinterpret_cast<const f4*>(prow1 + x);
+        if (x > 0) { l0 = *reinterpret_cast<const f4*>(prow0 + x - 4); if (up) l1 = *reinterpret_cast<const f4*>(prow1 + x - 4); }
+        bool t[6];   // t(x - 2) .. t(x + 3)
+        t[0] = x > 0 && (l0[2] > thresh || (up && l1[2] > thresh));
+        t[1] = x > 0 && (l0[3] > thresh || (up && l1[3] > thresh));
+#pragma unroll
+        for (int k = 0; k < 4; k++) t[2 + k] = a0[k] > thresh || (up && a1[k] > thresh);
+        bool ml = dilate ? (t[1] || t[0]) : t[1];   // mask of pixel x - 1
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          m[k] = dilate ? (t[2 + k] || t[1 + k]) : t[2 + k];
+          if (x + k == 0 || ml != m[k]) {
+            v[k] = x + k;
+            const size_t i = (size_t)y * W + x + k;
+            ws.ymin[i] = 0x7fffffff; ws.ymax[i] = -1; ws.cidx[i] = -1; ws.outside[i] = 0;
+          }
+          ml = m[k];
+        }
+        *reinterpret_cast<unsigned*>(mrow + x) = (m[0] ? 0xffu : 0u) | (m[1] ? 0xff00u : 0u) | (m[2] ? 0xff0000u : 0u) | (m[3] ? 0xff000000u : 0u);
+      }
+      // inclusive max-scan: inside the thread, then of the threads' maxima inside the wave, then over the waves
+      v[1] = max(v[1], v[0]); v[2] = max(v[2], v[1]); v[3] = max(v[3], v[2]);
+      int tv = v[3];
+      for (int o = 1; o < 64; o <<= 1) { int tt = __shfl_up(tv, o); if (lane >= o) tv = max(tv, tt); }
+      if (lane == 63) wave_max[wave] = tv;
+      __syncthreads();
+      int pre = carry;
+      for (int k = 0; k < wave; k++) pre = max(pre, wave_max[k]);
+      const int before = __shfl_up(tv, 1);             // maximum of the earlier threads of this wave
+      if (lane > 0) pre = max(pre, before);
+      if (x < W) {
+        i4 o4;
+#pragma unroll
+        for (int k = 0; k < 4; k++) o4[k] = y * W + max(v[k], pre);
+        *reinterpret_cast<i4*>(prow + x) = o4;
+      }
+      if (threadIdx.x == 255) carry_s = max(tv, pre);
+      __syncthreads();
+      carry = carry_s;
+    }
+    return;
+  }
   for (int x0 = 0; x0 < W; x0 += 256) {
     int x = x0 + threadIdx.x;
     int v = -1;
@@ -126,119 +180,182 @@ __global__ __launch_bounds__(256) void k_ccl_rows(const DbPage* __restrict__ pag
 }
 // step 2: link vertically / diagonally adjacent runs, once per pair (at the first column
 // of their overlap).  Foreground is 8-connected, background 4-connected.
+// (round 5: a thread takes FOUR pixels when the row length allows -- two 4-byte loads tell it whether any of them or their
+//  upper neighbours starts a run; inside uniform stretches, i.e. nearly everywhere, nothing is linked and the thread is done)
 __global__ __launch_bounds__(256) void k_ccl_link(const DbPage* __restrict__ pages) {
   const DbPage pg = pages[blockIdx.y];
   const int H = pg.H, W = pg.W;
+  const u8* mask = pg.ws.mask;
+  int* parent = pg.ws.parent;
+  auto link1 = [&](int i, int x) {   // the per-pixel rule; y > 0
+    const u8 m = mask[i];
+    const bool my_start = (x == 0) || mask[i - 1] != m;
+    if (mask[i - W] == m) {
+      const bool up_start = (x == 0) || mask[i - W - 1] != m;
+      if (my_start || up_start) uf_union(parent, i, i - W);
+    } else if (m) {
+      // N is background: diagonal neighbours are only reachable from a run end
+      if (x + 1 < W && mask[i - W + 1] && !mask[i + 1]) uf_union(parent, i, i - W + 1);
+      if (x > 0 && mask[i - W - 1] && my_start) uf_union(parent, i, i - W - 1);
+    }
+  };
+  if ((W & 3) == 0) {
+    const int q = blockIdx.x * 256 + threadIdx.x;   // group of four pixels
+    if (q >= H * (W >> 2)) return;
+    const int y = q / (W >> 2), x = (q - y * (W >> 2)) * 4;
+    if (y == 0) return;
+    const int i = y * W + x;
+    const unsigned cur = *reinterpret_cast<const unsigned*>(mask + i), up = *reinterpret_cast<const unsigned*>(mask + i - W);
+    const unsigned rep = (cur & 0xffu) * 0x01010101u;
+    // uniform stretch: the four pixels, the four above them and both left neighbours hold one value -> no run starts here, and
+    // with N equal to the pixel the diagonal rules do not apply
+    if (cur == rep && up == rep && (x == 0 ? false : (mask[i - 1] == (u8)(cur & 0xff) && mask[i - W - 1] == (u8)(cur & 0xff)))) return;
+#pragma unroll
+    for (int k = 0; k < 4; k++) link1(i + k, x + k);
+    return;
+  }
   int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= H * W) return;
   int y = i / W, x = i % W;
   if (y == 0) return;
-  const u8* mask = pg.ws.mask;
-  int* parent = pg.ws.parent;
-  u8 m = mask[i];
-  bool my_start = (x == 0) || mask[i - 1] != m;
-  if (mask[i - W] == m) {
-    bool up_start = (x == 0) || mask[i - W - 1] != m;
-    if (my_start || up_start) uf_union(parent, i, i - W);
-  } else if (m) {
-    // N is background: diagonal neighbours are only reachable from a run end
-    if (x + 1 < W && mask[i - W + 1] && !mask[i + 1]) uf_union(parent, i, i - W + 1);
-    if (x > 0 && mask[i - W - 1] && my_start) uf_union(parent, i, i - W - 1);
-  }
-  if (m && mask[i - W] == m) {
-    // both N and a diagonal may hold distinct upper runs when N's run ends/starts here
-  }
+  link1(i, x);
 }
+// step 3, per RUN (round 5; until then per pixel: every pixel found its root through a segmented scan over the wave, ~270 VALU
+// instructions per pixel of a 29.5 M-pixel step, 0.25 ms).  Everything this pass produces is a property of runs:
+//   * after k_ccl_link only run heads carry links (uf_union works on roots, and a root is a run head), every other pixel still points
+//     at its head: the head is flattened here, and a pixel's root is parent[parent[i]] from now on (k_row_extents);
+//   * the row range of a foreground component is the range of its runs' rows (its top row has background or the frame above); of a
+//     hole: one row above its first and one below its last run (the foreground pixels bordering it);
+//   * a background component is "outside" when one of its runs touches the frame: a run that starts at x = 0 or lies on the first /
+//     last row is seen at its head, a run that ENDS at x = W - 1 by the thread of that pixel.
+// Only run heads (and the last column's background pixels) do any work.
+// Only run heads (and the last column's background pixels) do any work; a thread takes four pixels when the row length allows and
+// leaves at once when none of them starts a run (one 4-byte load of the mask).
 __global__ __launch_bounds__(256) void k_ccl_stats(const DbPage* __restrict__ pages) {
   const DbPage pg = pages[blockIdx.y];
   const int H = pg.H, W = pg.W;
+  const DbWs& ws = pg.ws;
+  auto px = [&](int i, int y, int x) {
+    const u8 m = ws.mask[i];
+    const bool head = x == 0 || ws.mask[i - 1] != m;
+    if (!head) {
+      if (x == W - 1 && !m) ws.outside[uf_find(ws.parent, ws.parent[i])] = 1;
+      return;
+    }
+    const int r = uf_find(ws.parent, i);
+    ws.parent[i] = r;   // flatten the head (only this thread writes the slot; concurrent finds through it tolerate either value)
+    if (m) {
+      atomicMin(&ws.ymin[r], y);
+      atomicMax(&ws.ymax[r], y);
+    } else {
+      atomicMin(&ws.ymin[r], y - 1);
+      atomicMax(&ws.ymax[r], y + 1);
+      if (x == 0 || y == 0 || y == H - 1 || (x == W - 1)) ws.outside[r] = 1;
+    }
+  };
+  if ((W & 3) == 0) {
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= H * (W >> 2)) return;
+    const int y = q / (W >> 2), x = (q - y * (W >> 2)) * 4, i = y * W + x;
+    const unsigned cur = *reinterpret_cast<const unsigned*>(ws.mask + i);
+    const unsigned rep = (cur & 0xffu) * 0x01010101u;
+    if (cur == rep && x > 0 && ws.mask[i - 1] == (u8)(cur & 0xff) && !(x + 4 == W && !(cur & 0xff))) return;   // no head, not a background run end at the frame
+#pragma unroll
+    for (int k = 0; k < 4; k++) px(i + k, y, x + k);
+    return;
+  }
   int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= H * W) return;
-  int y = i / W, x = i % W;
-  const DbWs& ws = pg.ws;
-  // Root of this pixel's component.  A pixel still points at the first pixel of its horizontal run
-  // (k_ccl_rows); the run heads were linked by atomicMin without compression, so a find from a head can be a
-  // long walk (the page background: one hop per image row).  Lanes of a wave are consecutive pixels, i.e.
-  // whole stretches of them share a run head: only the first lane of each stretch walks, the others take its
-  // result through a segmented shuffle scan.
-  const int lane = threadIdx.x & 63;
-  const int rs = ws.parent[i];
-  const int prev = __shfl_up(rs, 1);
-  const bool head = lane == 0 || prev != rs;
-  int r = head ? uf_find(ws.parent, rs) : -1;
-  int src = head ? lane : -1;  // lane of the stretch's head: inclusive max-scan
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) { int t = __shfl_up(src, o); if (lane >= o) src = max(src, t); }
-  r = __shfl(r, src);
-  ws.parent[i] = r;  // flatten (each thread writes only its own slot; readers tolerate either value)
-  // Row range of every component (for a hole: of the fg pixels bordering it).  All lanes of a stretch sit on
-  // one image row and share r, so they would send the same (address, value) atomic -- thousands of them to
-  // the page background's root under every text line.  One atomic per stretch: the head lane sends it if any
-  // lane of its stretch asks.
-  const unsigned long long heads = __ballot(head);
-  const unsigned long long above = src >= 63 ? 0ull : (heads >> (src + 1)) << (src + 1);  // heads after mine
-  const int end = above ? __builtin_ctzll(above) : 64;                                        // my stretch = [src, end)
-  const unsigned long long smask = (end >= 64 ? ~0ull : ((1ull << end) - 1)) & ~((1ull << src) - 1);
-  const bool fg = ws.mask[i] != 0;
-  const bool up_fg = y > 0 && ws.mask[i - W], dn_fg = y < H - 1 && ws.mask[i + W];
-  const unsigned long long b_top = __ballot(fg && !up_fg), b_bot = __ballot(fg && !dn_fg);
-  const unsigned long long b_hole_top = __ballot(!fg && up_fg), b_hole_bot = __ballot(!fg && dn_fg);
-  const unsigned long long b_edge = __ballot(!fg && (x == 0 || y == 0 || x == W - 1 || y == H - 1));
-  if (head) {
-    if (b_top & smask) atomicMin(&ws.ymin[r], y);
-    if (b_bot & smask) atomicMax(&ws.ymax[r], y);
-    // border rows of a hole: the fg pixels above its top / below its bottom
-    if (b_hole_top & smask) atomicMin(&ws.ymin[r], y - 1);
-    if (b_hole_bot & smask) atomicMax(&ws.ymax[r], y + 1);
-    if (b_edge & smask) ws.outside[r] = 1;
-  }
+  const int y = i / W;
+  px(i, y, i - y * W);
 }
 // one contour per fg component (outer border) and per hole (bg component not touching
 // the frame); discovery key = raster index of the border-following start pixel
+// (a root is the first pixel of a run: four pixels per thread, groups without a run start leave after one load of the mask)
 __global__ __launch_bounds__(256) void k_contour_alloc(const DbPage* __restrict__ pages) {
   const DbPage pg = pages[blockIdx.y];
   const int H = pg.H, W = pg.W;
+  const DbWs& ws = pg.ws;
+  auto px = [&](int i) {
+    if (ws.parent[i] != i) return;
+    int type;
+    if (ws.mask[i]) type = 0;
+    else { if (ws.outside[i]) return; type = 1; }
+    int y0 = ws.ymin[i], y1 = ws.ymax[i];
+    if (y1 < y0) return;
+    int rows = y1 - y0 + 1;
+    int idx = atomicAdd(&ws.counters[0], 1);
+    if (idx >= ws.contour_cap) { ws.counters[4] = 1; return; }
+    int base = atomicAdd(&ws.counters[1], rows);
+    int hbase = atomicAdd(&ws.counters[2], 2 * rows + 4);
+    if (base + rows > ws.row_cap || hbase + 2 * rows + 4 > ws.hull_cap) { ws.counters[4] = 1; return; }
+    for (int r = 0; r < rows; r++) { ws.rowmin[base + r] = 0x7fffffff; ws.rowmax[base + r] = -1; }
+    Contour c; c.root = i; c.type = type; c.ymin = y0; c.rows = rows; c.base = base; c.hbase = hbase;
+    ws.contours[idx] = c;
+    ws.cidx[i] = idx;
+  };
+  if ((W & 3) == 0) {
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= H * (W >> 2)) return;
+    const int y = q / (W >> 2), x = (q - y * (W >> 2)) * 4, i = y * W + x;
+    const unsigned cur = *reinterpret_cast<const unsigned*>(ws.mask + i);
+    const unsigned rep = (cur & 0xffu) * 0x01010101u;
+    if (cur == rep && x > 0 && ws.mask[i - 1] == (u8)(cur & 0xff)) return;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const u8 m = (u8)(cur >> (8 * k));
+      const bool head = x + k == 0 || (k == 0 ? ws.mask[i - 1] : (u8)(cur >> (8 * (k - 1)))) != m;
+      if (head) px(i + k);
+    }
+    return;
+  }
   int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= H * W) return;
-  const DbWs& ws = pg.ws;
-  if (ws.parent[i] != i) return;
-  int type;
-  if (ws.mask[i]) type = 0;
-  else { if (ws.outside[i]) return; type = 1; }
-  int y0 = ws.ymin[i], y1 = ws.ymax[i];
-  if (y1 < y0) return;
-  int rows = y1 - y0 + 1;
-  int idx = atomicAdd(&ws.counters[0], 1);
-  if (idx >= ws.contour_cap) { ws.counters[4] = 1; return; }
-  int base = atomicAdd(&ws.counters[1], rows);
-  int hbase = atomicAdd(&ws.counters[2], 2 * rows + 4);
-  if (base + rows > ws.row_cap || hbase + 2 * rows + 4 > ws.hull_cap) { ws.counters[4] = 1; return; }
-  for (int r = 0; r < rows; r++) { ws.rowmin[base + r] = 0x7fffffff; ws.rowmax[base + r] = -1; }
-  Contour c; c.root = i; c.type = type; c.ymin = y0; c.rows = rows; c.base = base; c.hbase = hbase;
-  ws.contours[idx] = c;
-  ws.cidx[i] = idx;
+  px(i);
 }
+// (only pixels at the edge of a run, or background pixels next to foreground, contribute: four pixels per thread, groups
+//  whose pixels and all their 4-neighbours hold one value leave after three 4-byte loads)
 __global__ __launch_bounds__(256) void k_row_extents(const DbPage* __restrict__ pages) {
   const DbPage pg = pages[blockIdx.y];
   const int H = pg.H, W = pg.W;
+  const DbWs& ws = pg.ws;
+  auto px = [&](int i, int y, int x) {
+    int r = ws.parent[ws.parent[i]];   // pixel -> head of its run -> root (k_ccl_stats flattened the heads only)
+    int ci = ws.cidx[r];
+    if (ci < 0) return;  // outside background (or an overflowed list)
+    const Contour c = ws.contours[ci];
+    if (ws.mask[i]) {
+      int row = c.base + (y - c.ymin);
+      if (x == 0 || !ws.mask[i - 1]) atomicMin(&ws.rowmin[row], x);
+      if (x == W - 1 || !ws.mask[i + 1]) atomicMax(&ws.rowmax[row], x);
+    } else {
+      if (x > 0 && ws.mask[i - 1]) { int row = c.base + (y - c.ymin); atomicMin(&ws.rowmin[row], x - 1); atomicMax(&ws.rowmax[row], x - 1); }
+      if (x + 1 < W && ws.mask[i + 1]) { int row = c.base + (y - c.ymin); atomicMin(&ws.rowmin[row], x + 1); atomicMax(&ws.rowmax[row], x + 1); }
+      if (y > 0 && ws.mask[i - W]) { int row = c.base + (y - 1 - c.ymin); atomicMin(&ws.rowmin[row], x); atomicMax(&ws.rowmax[row], x); }
+      if (y + 1 < H && ws.mask[i + W]) { int row = c.base + (y + 1 - c.ymin); atomicMin(&ws.rowmin[row], x); atomicMax(&ws.rowmax[row], x); }
+    }
+  };
+  if ((W & 3) == 0) {
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= H * (W >> 2)) return;
+    const int y = q / (W >> 2), x = (q - y * (W >> 2)) * 4, i = y * W + x;
+    const unsigned cur = *reinterpret_cast<const unsigned*>(ws.mask + i);
+    const unsigned rep = (cur & 0xffu) * 0x01010101u;
+    const u8 m = (u8)(cur & 0xff);
+    // interior of a uniform region: foreground pixels that are no run ends, or background pixels without a foreground neighbour.
+    // (At the frame: a foreground pixel in the first / last column IS a run end; missing rows above / below count as "same".)
+    if (cur == rep && (x > 0 ? ws.mask[i - 1] == m : !m) && (x + 4 < W ? ws.mask[i + 4] == m : !m) &&
+        (y == 0 || *reinterpret_cast<const unsigned*>(ws.mask + i - W) == rep || m) &&
+        (y + 1 >= H || *reinterpret_cast<const unsigned*>(ws.mask + i + W) == rep || m))
+      return;
+#pragma unroll
+    for (int k = 0; k < 4; k++) px(i + k, y, x + k);
+    return;
+  }
   int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= H * W) return;
-  int y = i / W, x = i % W;
-  const DbWs& ws = pg.ws;
-  int r = ws.parent[i];
-  int ci = ws.cidx[r];
-  if (ci < 0) return;  // outside background (or an overflowed list)
-  const Contour c = ws.contours[ci];
-  if (ws.mask[i]) {
-    int row = c.base + (y - c.ymin);
-    if (x == 0 || !ws.mask[i - 1]) atomicMin(&ws.rowmin[row], x);
-    if (x == W - 1 || !ws.mask[i + 1]) atomicMax(&ws.rowmax[row], x);
-  } else {
-    if (x > 0 && ws.mask[i - 1]) { int row = c.base + (y - c.ymin); atomicMin(&ws.rowmin[row], x - 1); atomicMax(&ws.rowmax[row], x - 1); }
-    if (x + 1 < W && ws.mask[i + 1]) { int row = c.base + (y - c.ymin); atomicMin(&ws.rowmin[row], x + 1); atomicMax(&ws.rowmax[row], x + 1); }
-    if (y > 0 && ws.mask[i - W]) { int row = c.base + (y - 1 - c.ymin); atomicMin(&ws.rowmin[row], x); atomicMax(&ws.rowmax[row], x); }
-    if (y + 1 < H && ws.mask[i + W]) { int row = c.base + (y + 1 - c.ymin); atomicMin(&ws.rowmin[row], x); atomicMax(&ws.rowmax[row], x); }
-  }
+  const int y = i / W;
+  px(i, y, i - y * W);
 }
 
 // ---- per-contour geometry ----------------------------------------------------------
@@ -792,7 +909,10 @@ void db_postprocess_batch(hipStream_t st, int n, const DbPageIn* in, const DbPar
   }
   (void)hipMemcpyAsync(d_desc, h_desc, (size_t)n * sizeof(DbPage), hipMemcpyHostToDevice, st);
   const DbPage* dp = (const DbPage*)d_desc;
-  dim3 grid((maxN + 255) / 256, n), blk(256);
+  // the per-pixel passes take four pixels per thread on pages whose width is a multiple of 4 (every det map is: multiples of 32)
+  bool all4 = true;
+  for (int i = 0; i < n; i++) all4 = all4 && (in[i].W & 3) == 0;
+  dim3 grid(((all4 ? maxN / 4 : maxN) + 255) / 256, n), blk(256);
   RT_LAUNCH(k_ccl_rows, dim3(maxH, n), blk, 0, st, dp, p.thresh, p.dilate);
   RT_LAUNCH(k_ccl_link, grid, blk, 0, st, dp);
   RT_LAUNCH(k_ccl_stats, grid, blk, 0, st, dp);
