@@ -407,6 +407,24 @@ def test_det_postprocess_sparse_noise(hip_session):
     assert np.array_equal(gb, rb) and np.array_equal(gs.view(np.uint32), rs.view(np.uint32))
 
 
+@pytest.mark.parametrize("w", [332, 333, 334, 335])
+def test_det_postprocess_widths_mod_4(hip_session, w):
+    """The labelling passes take four pixels per thread when the row length is a multiple of 4 (round 5) and one otherwise: the same
+    content at widths = 0 .. 3 (mod 4) -- noise blobs, runs that start / end on every frame edge, holes, a diagonal chain that is
+    only 8-connected -- against the oracle, boxes and score bit patterns."""
+    rng = np.random.default_rng(7)
+    h = 201
+    pred = (rng.uniform(0, 1, (h, w)) > 0.975).astype(np.float32) * 0.85 + 0.02   # sparse blobs (dilation merges denser noise into one component)
+    pred[0:9, 0:60] = 0.9; pred[h - 8:h, w - 70:w] = 0.9                  # blobs on the top-left / bottom-right corners
+    pred[40:70, 0:5] = 0.8; pred[90:130, w - 4:w] = 0.8                    # left / right frame
+    pred[100:140, 100:220] = 0.9; pred[112:128, 130:190] = 0.02           # a hole
+    for k in range(30): pred[150 + k, 40 + k] = 0.95                      # diagonal chain
+    gb, gs = hip_session.det_postprocess(pred, h, w)
+    rb, rs = R.det_postprocess(pred, h, w)
+    assert len(gb) == len(rb) >= 3
+    assert np.array_equal(gb, rb) and np.array_equal(gs.view(np.uint32), rs.view(np.uint32))
+
+
 def test_pipeline_raw_det_map(hip_session, oracle_session):
     """No planted map: boxes come from the det network's own (noise-like) output; the oracle is
     teacher-forced with the HIP map, so every discrete result must still agree."""
