@@ -574,7 +574,19 @@ float* RecNet::run(RunCtx& c, const float* x, Level& L0, Level& Lt, int* idx_out
   { ProfScope ps(c.prof, c.st, "avgpool");
     nn::avgpool_3x2(c.st, t, lv.back().d, Lt.d, Lt.n(), Lt.maxPix, C, cat, 2 * C); }
   float* z1 = c.arena->alloc<float>((size_t)rows * 60);
+  // line-boundary flags of the flat token list (the two 1x3 convs run over it as one sequence: nn::conv13_flat)
+  unsigned char* tok_flags = nullptr;
+  if (nn::conv13_flat_supported(60, conv1_.Npad) && Lt.maxH == 1 && rows > 0) {
+    unsigned char* hf = c.pinned->alloc<unsigned char>((size_t)rows);
+    memset(hf, 0, (size_t)rows);
+    for (const ImgGeom& g : Lt.h)
+      if (g.H == 1 && g.W > 0) { hf[g.off] |= 1; hf[g.off + g.W - 1] |= 2; }
+    tok_flags = c.arena->alloc<unsigned char>((size_t)rows);
+    RT_HIP_CHECK(hipMemcpyAsync(tok_flags, hf, (size_t)rows, hipMemcpyHostToDevice, c.st));
+  }
   { ProfScope ps(c.prof, c.st, "conv1x3");
+    if (tok_flags) nn::conv13_flat(c.st, cat, 2 * C, rows, tok_flags, C, conv1_.w, 60, conv1_.Npad, z1, 60, make_epi(conv1_, ACT_SWISH));
+    else
     nn::conv_sp(c.st, 1, 3, cat, 2 * C, Lt.d, Lt.n(), Lt.maxH, Lt.maxW, C, conv1_.w, 60, conv1_.Npad, z1, 60,
                 make_epi(conv1_, ACT_SWISH)); }
   float* z = c.arena->alloc<float>((size_t)rows * D);
@@ -585,6 +597,8 @@ float* RecNet::run(RunCtx& c, const float* x, Level& L0, Level& Lt, int* idx_out
     nn::gemm(c.st, zf, D, rows, conv3_.K, conv3_.w, C, conv3_.Npad, cat, 2 * C, C, make_epi(conv3_, ACT_SWISH)); }
   float* z4 = c.arena->alloc<float>((size_t)rows * 60);
   { ProfScope ps(c.prof, c.st, "conv1x3");
+    if (tok_flags) nn::conv13_flat(c.st, cat, 2 * C, rows, tok_flags, 2 * C, conv4_.w, 60, conv4_.Npad, z4, 60, make_epi(conv4_, ACT_SWISH));
+    else
     nn::conv_sp(c.st, 1, 3, cat, 2 * C, Lt.d, Lt.n(), Lt.maxH, Lt.maxW, 2 * C, conv4_.w, 60, conv4_.Npad, z4, 60,
                 make_epi(conv4_, ACT_SWISH)); }
   float* z5 = c.arena->alloc<float>((size_t)rows * D);

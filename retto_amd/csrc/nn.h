@@ -27,6 +27,11 @@ extern int g_dw_sweep;      // A/B: column-sweep 5x5 depthwise kernel: pixels pe
 
 // Dense stride-1 "same" convolution, kernel (KH,KW) in {(3,3),(1,3)}; W packed as
 // [ceil(Cin/KC)][KH*KW][Npad16][KC].
+// 1x3 conv over the flat token list of a level of text lines (H = 1 images, contiguous rows): flags[t] bit 0 = token t is the first
+// of its line, bit 1 = the last (nn_kernels.hip k_conv13_flat).  N <= 64.
+bool conv13_flat_supported(int N, int Npad16);
+void conv13_flat(hipStream_t st, const float* x, int ldx, long long rows, const unsigned char* flags, int Cin, const float* Wp, int N,
+                 int Npad16, float* y, int ldy, const Epilogue& epi);
 void conv_sp(hipStream_t st, int KH, int KW, const float* x, int ldx, const ImgGeom* geom, int n_img, int maxH,
              int maxW, int Cin, const float* Wp, int N, int Npad16, float* y, int ldy, const Epilogue& epi);
 

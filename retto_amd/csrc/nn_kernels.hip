@@ -1112,6 +1112,123 @@ void conv3_fpn_fused(hipStream_t st, const float* p5, const float* p4, const flo
   RT_LAUNCH((k_conv3_few<6, 1>), gridf, dim3(256), 0, st, nullptr, 4 * Cq, g2, 4 * Cq, Wp, N, Npad16, y, ldy, epi, fs);
 }
 
+// ---------------------------------------------------------------------------
+// k_conv13_flat (round 5): the SVTR neck's 1x3 convs (480 / 960 -> 60 channels) over the FLAT token list.
+// The token sequences of a launch's text lines are contiguous in memory ([line 0 | line 1 | ...], one row per token), so a 1x3
+// conv over all of them is one conv over the flat list in which a tap must not cross a line boundary.  k_conv_sp gives every
+// line its own 128-token tile: lines of ~50 tokens leave 61 % of every tile's MFMAs on pixels that do not exist (PMC: matrix pipe
+// 0.76 busy at 0.20 / 0.41 ms per launch for 8.8 / 17.7 GFLOP), and five ways of shrinking the tiles did not help (DESIGN.md
+// 5.4).  Here a tile is 128 CONSECUTIVE tokens whatever lines they belong to; `flags` (one byte per token: 1 = first of its
+// line, 2 = last) zero the left / right tap's operand where the neighbour belongs to another line.  Halo rows are contiguous
+// (130 rows of the activation matrix), every tile but the last is full.  Same slab / tap / (q, s) -> k order per accumulator as
+// k_conv_sp and exact zeros for the masked taps: bit-identical.
+// ---------------------------------------------------------------------------
+template <int NT>
+__global__ __launch_bounds__(256) void k_conv13_flat(const float* __restrict__ x, int ldx, long long rows, const unsigned char* __restrict__ flags,
+                                                     int Cin, const float* __restrict__ Wp, int N, int Npad, float* __restrict__ y, int ldy,
+                                                     Epilogue epi) {
+  constexpr int TW = 128, HW = TW + 2;
+  __shared__ __attribute__((aligned(16))) float lds[(HW + 3 * 16 * NT) * LROW];
+  float* xs = lds;
+  float* ws = lds + HW * LROW;
+  const long long P0 = (long long)blockIdx.x * TW;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, q = lane >> 4;
+  const int n0 = blockIdx.y * 16 * NT;
+  const int nt_valid = min(NT, (Npad - n0) / 16);
+  f32x4 acc[2][NT];
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int j = 0; j < NT; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int p0 = wave * 32 + r, p1 = p0 + 16;
+  const long long t0 = P0 + p0, t1 = P0 + p1;
+  const unsigned f0 = t0 < rows ? flags[t0] : 3u, f1 = t1 < rows ? flags[t1] : 3u;
+  const int nkc = (Cin + KC - 1) / KC;
+  constexpr int XLD = (HW * 8 + 255) / 256, WLD = (3 * 16 * NT * 8 + 255) / 256;
+  f32x4 px_[XLD], pw_[WLD];
+  auto fetch = [&](int kc) {
+    const int k0 = kc * KC;
+#pragma unroll
+    for (int i = 0; i < XLD; i++) {
+      const int idx = tid + 256 * i;
+      px_[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (idx < HW * 8) {
+        const int hx = idx >> 3, c4 = idx & 7;
+        const long long tok = P0 - 1 + hx;
+        if (tok >= 0 && tok < rows && k0 + c4 * 4 < Cin) px_[i] = *reinterpret_cast<const f32x4*>(x + tok * ldx + k0 + c4 * 4);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < WLD; i++) {
+      const int idx = tid + 256 * i;
+      pw_[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (idx < 3 * 16 * NT * 8) {
+        const int row = idx >> 3, c4 = idx & 7;
+        const int tap = row / (16 * NT), n = row - tap * (16 * NT);
+        if (n0 + n < Npad) pw_[i] = *reinterpret_cast<const f32x4*>(Wp + (((long long)kc * 3 + tap) * Npad + n0 + n) * KC + c4 * 4);
+      }
+    }
+  };
+  fetch(0);
+  for (int kc = 0; kc < nkc; kc++) {
+#pragma unroll
+    for (int i = 0; i < XLD; i++) {
+      const int idx = tid + 256 * i;
+      if (idx < HW * 8) *reinterpret_cast<f32x4*>(xs + (idx >> 3) * LROW + (idx & 7) * 4) = px_[i];
+    }
+#pragma unroll
+    for (int i = 0; i < WLD; i++) {
+      const int idx = tid + 256 * i;
+      if (idx < 3 * 16 * NT * 8) *reinterpret_cast<f32x4*>(ws + (idx >> 3) * LROW + (idx & 7) * 4) = pw_[i];
+    }
+    __syncthreads();
+    if (kc + 1 < nkc) fetch(kc + 1);
+#pragma unroll
+    for (int dx = 0; dx < 3; dx++) {
+      // tap dx reads halo row p + dx (= token p + dx - 1); the left tap of a line's first token and the right tap of its last are zero
+      const bool z0 = (dx == 0 && (f0 & 1u)) || (dx == 2 && (f0 & 2u)), z1 = (dx == 0 && (f1 & 1u)) || (dx == 2 && (f1 & 2u));
+      const float* xr0 = xs + (p0 + dx) * LROW;
+      const float* xr1 = xs + (p1 + dx) * LROW;
+      const float* wt = ws + dx * 16 * NT * LROW;
+#pragma unroll
+      for (int g = 0; g < KC / 16; g++) {
+        f32x4 a0 = *reinterpret_cast<const f32x4*>(xr0 + g * 16 + 4 * q);
+        f32x4 a1 = *reinterpret_cast<const f32x4*>(xr1 + g * 16 + 4 * q);
+        if (dx != 1) { if (z0) a0 = f32x4{0.f, 0.f, 0.f, 0.f}; if (z1) a1 = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+        for (int nt = 0; nt < NT; nt++) {
+          if (nt < nt_valid) {
+            const f32x4 b = *reinterpret_cast<const f32x4*>(wt + (nt * 16 + r) * LROW + g * 16 + 4 * q);
+#pragma unroll
+            for (int s4 = 0; s4 < 4; s4++) {
+              acc[0][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[s4], a0[s4], acc[0][nt], 0, 0, 0);
+              acc[1][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[s4], a1[s4], acc[1][nt], 0, 0, 0);
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+  const int nstore = (N + 3) & ~3;
+  epilogue_store<NT>(acc, nt_valid, epi, n0, N, nstore, y + t0 * ldy, y + t1 * ldy, t0 < rows, t1 < rows,
+                     epi.residual ? epi.residual + t0 * epi.ld_res : nullptr, epi.residual ? epi.residual + t1 * epi.ld_res : nullptr, q);
+}
+int g_conv13_flat = getenv("RT_CONV13_FLAT") ? atoi(getenv("RT_CONV13_FLAT")) : 1;   // A/B: 0 = k_conv_sp<1,3,1,128,NT> (a tile per line)
+bool conv13_flat_supported(int N, int Npad16) { return g_conv13_flat && Npad16 <= 64 && N > 0; }
+void conv13_flat(hipStream_t st, const float* x, int ldx, long long rows, const unsigned char* flags, int Cin, const float* Wp, int N,
+                 int Npad16, float* y, int ldy, const Epilogue& epi) {
+  if (rows <= 0) return;
+  const int ntiles = Npad16 / 16, NT = ntiles >= 4 ? 4 : ntiles;
+  dim3 grid((unsigned)((rows + 127) / 128), (unsigned)((ntiles + NT - 1) / NT));
+  switch (NT) {
+    case 1: RT_LAUNCH((k_conv13_flat<1>), grid, dim3(256), 0, st, x, ldx, rows, flags, Cin, Wp, N, Npad16, y, ldy, epi); break;
+    case 2: RT_LAUNCH((k_conv13_flat<2>), grid, dim3(256), 0, st, x, ldx, rows, flags, Cin, Wp, N, Npad16, y, ldy, epi); break;
+    case 3: RT_LAUNCH((k_conv13_flat<3>), grid, dim3(256), 0, st, x, ldx, rows, flags, Cin, Wp, N, Npad16, y, ldy, epi); break;
+    default: RT_LAUNCH((k_conv13_flat<4>), grid, dim3(256), 0, st, x, ldx, rows, flags, Cin, Wp, N, Npad16, y, ldy, epi); break;
+  }
+}
+
 void conv_sp(hipStream_t st, int KH, int KW, const float* x, int ldx, const ImgGeom* geom, int n_img, int maxH,
              int maxW, int Cin, const float* Wp, int N, int Npad16, float* y, int ldy, const Epilogue& epi) {
   if (n_img <= 0) return;
