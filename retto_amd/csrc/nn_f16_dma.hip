@@ -62,6 +62,15 @@ __device__ __forceinline__ void glds16_s(unsigned long long gaddr, unsigned lds_
   asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gaddr), "s"(lds_sgpr) : "memory", "m0");
 }
 #pragma clang diagnostic pop
+// LDS-DMA request through a buffer resource (round 5): lane i writes 16 bytes at M0 + 16 i; source = resource base + per-lane
+// byte offset + scalar offset; a lane whose offset is out of range (0x80000000) writes ZEROS -- the padding pixels / rows cost no
+// select, and the per-slab / per-row advance is one scalar operand instead of a 64-bit add per lane and request.
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+__device__ __forceinline__ void blds16(unsigned voff, __amdgpu_buffer_rsrc_t rs, unsigned lds_sgpr, unsigned soff) {
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %3 offen lds" ::"v"(voff), "s"(rs), "s"(lds_sgpr), "s"(soff) : "memory", "m0");
+}
+#pragma clang diagnostic pop
 template <int N>
 __device__ __forceinline__ void lds_wait() {
   static_assert(N >= 0 && N <= 15, "lgkmcnt is a 4-bit counter");
@@ -76,6 +85,7 @@ struct ConvArgs2 {
   int hbufs;             // 2: next slab's halo prefetched; 1: single buffer (large halos)
   unsigned hw_magic, tw_magic;   // ceil(2^32 / d) for d = halo width, tile width (0: d == 1): q = umulhi(p, magic), exact for p * d < 2^32
   int wslots;            // weight ring: 3 (row r + 2 requested while row r is multiplied) or 2 (row r + 1; the 9-tap rows)
+  int bdma;              // 1: the layer's byte offsets fit the buffer-resource form of the requests
 };
 constexpr int V2_HMAX = 8;   // DMA instructions per thread for one halo tile (8 * 512 * 16 B = 64 KB)
 
@@ -87,7 +97,9 @@ constexpr int V2_HMAX = 8;   // DMA instructions per thread for one halo tile (8
 // barrier) or 4 (round 5: 256-pixel tiles in <= 80 KB of LDS, so that TWO independent workgroups share a CU -- each SIMD holds one
 // wave of each -- and one workgroup's DMA waits and barriers are the other's MFMA time; the weight ring shrinks to fit: c2.wslots
 // = 1 is a single weight buffer refilled between two barriers, the partner workgroup being the latency cover)
-template <int NTN, int KW, int KWR, int DOT = 0, int NW = 8>
+// BD: requests through buffer resources (whole 32-channel slabs only; compile time, so that the pointer form's state is not live
+// beside it: as a run-time choice the 128-channel row-wise instance spilled 12 VGPRs)
+template <int NTN, int KW, int KWR, int DOT = 0, int NW = 8, bool BD = false>
 __global__ __launch_bounds__(64 * NW, 2) void k_conv16v2(const ConvArgs2 c2) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem2[];
   const ConvArgs& a = c2.a;
@@ -137,7 +149,35 @@ __global__ __launch_bounds__(64 * NW, 2) void k_conv16v2(const ConvArgs2 c2) {
   const size_t row_halves = (size_t)KW * a.Npad * KS;
   const int wave_slot = wid * 64 * 8;   // halves: this wave's 64 consecutive 16-byte slots inside a group of NTHR
   const int wslots = c2.wslots, D = wslots - 1;   // prefetch distance in rows (0: single buffer, refilled between two barriers)
+  // Buffer-resource form of the requests (whole 32-channel slabs only: a partial last slab needs per-slab channel tests):
+  // PMC + ISA showed ~120 of the ~235 non-MFMA VALU instructions of a stage building 64-bit request addresses and selecting the
+  // zero page; here the per-lane byte offsets are fixed for the whole tile and the row / slab advance is a scalar operand.
+  constexpr bool bdma = BD;
+  // (the descriptors must live in SGPRs: everything they are built from is made scalar explicitly -- the image geometry comes
+  //  from a load indexed by the remapped block id, which hipcc does not prove uniform)
+  auto uni_ptr = [](const half_t* p_) {
+    const unsigned long long v = (unsigned long long)p_;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return (half_t*)(((unsigned long long)hi << 32) | lo);
+  };
+  const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(uni_ptr(a.w), 0, __builtin_amdgcn_readfirstlane((unsigned)(nrows * row_halves * 2)), 0x00020000);
+  // (halo: the descriptor starts at the TILE's origin -- possibly a row above the image -- with an open range; pixels outside the
+  //  image carry the out-of-range mark themselves, every valid pixel's offset from the origin is >= 0)
+  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(uni_ptr(xtile), 0, 0x7fffffffu, 0x00020000);
+  const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_addr(smem2));
+  const unsigned wring_b = lds0 + (unsigned)c2.hbufs * (unsigned)c2.hbuf_halves * 2u + (unsigned)__builtin_amdgcn_readfirstlane(wid) * 1024u;   // this wave's slots of ring slot 0
+  const unsigned hbuf_b = lds0 + (unsigned)__builtin_amdgcn_readfirstlane(wid) * 1024u;
   auto dma_wrow = [&](int rr) {         // kernel row rr -> ring slot rr % wslots
+    if (bdma) {
+      const unsigned dstb = __builtin_amdgcn_readfirstlane(wring_b + (unsigned)(rr % wslots) * (unsigned)(wbuf_halves * 2));
+      const unsigned soff = __builtin_amdgcn_readfirstlane((unsigned)rr * (unsigned)(row_halves * 2));
+#pragma unroll
+      for (int i = 0; i < WI; i++) {
+        if (i * NTHR >= wchunks) break;   // (uniform)
+        blds16(wsrc[i] >= 0 ? (unsigned)wsrc[i] * 2u : 0x80000000u, wrs, dstb + (unsigned)i * (NTHR * 16), soff);
+      }
+      return;
+    }
     half_t* dst = wring + (size_t)(rr % wslots) * wbuf_halves;
     const half_t* wg = a.w + (size_t)rr * row_halves;
 #pragma unroll
@@ -166,6 +206,16 @@ __global__ __launch_bounds__(64 * NW, 2) void k_conv16v2(const ConvArgs2 c2) {
     }
   }
   auto dma_halo = [&](int s) {          // slab s -> halo buffer s % hbufs
+    if (bdma) {
+      const unsigned dstb = __builtin_amdgcn_readfirstlane(hbuf_b + (unsigned)(s % c2.hbufs) * (unsigned)(c2.hbuf_halves * 2));
+      const unsigned soff = __builtin_amdgcn_readfirstlane((unsigned)s * (KS * 2));
+#pragma unroll
+      for (int i = 0; i < V2_HMAX; i++) {
+        if (i * NTHR >= hchunks) break;   // (uniform)
+        blds16(hsrc[i] >= 0 ? (unsigned)(hsrc[i] & 0x0fffffff) * 2u : 0x80000000u, xrs, dstb + (unsigned)i * (NTHR * 16), soff);
+      }
+      return;
+    }
     half_t* dst = hbuf + (size_t)(s % c2.hbufs) * c2.hbuf_halves;
     const int cvalid = min(KS, a.Cin - s * KS);
 #pragma unroll
@@ -767,23 +817,22 @@ bool conv16_dma(hipStream_t st, const ConvArgs& a0, int n_img, int maxHo, int ma
   c2.zeros = zero_page16();
   c2.hw_magic = magic((tw - 1) * SW + KW); c2.tw_magic = magic(tw);
   c2.hbuf_halves = pl.hbuf_halves; c2.hbufs = pl.hbufs; c2.wslots = pl.wslots;
+  // (byte offsets inside one image / the packed weights must stay below 2^31: the out-of-range marker is bit 31)
+  c2.bdma = (long long)maxHo * SH * maxWo * SW * a0.ldx * 2 < (1ll << 31) ? 1 : 0;
   const size_t lds2 = pl.lds;
   const long long tiles2 = (long long)((maxWo + tw - 1) / tw) * ((maxHo + th - 1) / th);
   dim3 grid2((unsigned)(tiles2 * c2.a.nzb), (unsigned)n_img);
-  for (const void* f : {(const void*)k_conv16v2<1, 1, 1>, (const void*)k_conv16v2<2, 1, 1>, (const void*)k_conv16v2<3, 1, 1>, (const void*)k_conv16v2<4, 1, 1>,
-                        (const void*)k_conv16v2<1, 3, 3>, (const void*)k_conv16v2<2, 3, 3>, (const void*)k_conv16v2<3, 3, 3>, (const void*)k_conv16v2<4, 3, 3>,
-                        (const void*)k_conv16v2<2, 9, 9>, (const void*)k_conv16v2<2, 9, 3>, (const void*)k_conv16v2<2, 4, 2, 1>})
-    allow_big_lds(f, 160 * 1024);
-  for (const void* f : {(const void*)k_conv16v2<1, 1, 1, 0, 4>, (const void*)k_conv16v2<2, 1, 1, 0, 4>, (const void*)k_conv16v2<3, 1, 1, 0, 4>, (const void*)k_conv16v2<4, 1, 1, 0, 4>,
-                        (const void*)k_conv16v2<1, 3, 3, 0, 4>, (const void*)k_conv16v2<2, 3, 3, 0, 4>, (const void*)k_conv16v2<3, 3, 3, 0, 4>, (const void*)k_conv16v2<4, 3, 3, 0, 4>,
-                        (const void*)k_conv16v2<2, 9, 9, 0, 4>, (const void*)k_conv16v2<2, 9, 3, 0, 4>, (const void*)k_conv16v2<2, 4, 2, 1, 4>})
-    allow_big_lds(f, 80 * 1024);
-#define RT_V2_GO(NT, KWV, KWRV, DOTV) do { if (nw == 4) RT_LAUNCH((k_conv16v2<NT, KWV, KWRV, DOTV, 4>), grid2, dim3(256), lds2, st, c2); \
-                                          else RT_LAUNCH((k_conv16v2<NT, KWV, KWRV, DOTV, 8>), grid2, dim3(512), lds2, st, c2); } while (0)
-#define RT_V2_LAUNCH(NT) do { if (KW == 1) RT_V2_GO(NT, 1, 1, 0); else RT_V2_GO(NT, 3, 3, 0); } while (0)
-  if (k9) { RT_V2_GO(2, 9, 9, 0); return true; }
-  if (g3) { RT_V2_GO(2, 9, 3, 0); return true; }
-  if (k22) { RT_V2_GO(2, 4, 2, 1); return true; }
+  // Buffer-resource requests are the only form of the dense instances (the pointer form survives in the PFHeadLocal phase convs,
+  // whose 80 input channels are not whole slabs); a layer with a partial last slab or an image beyond the 2-GB offset range takes
+  // the register-staged kernel.  (A/B of the two forms on C5, same box: 444 / 444 vs 452-460 images/s.)
+  if (!k22 && ((Cin % KS) != 0 || !c2.bdma)) return false;
+#define RT_V2_ONE(NT, KWV, KWRV, DOTV, NWV, BDV) do { allow_big_lds((const void*)k_conv16v2<NT, KWV, KWRV, DOTV, NWV, BDV>, (NWV) == 8 ? 160 * 1024 : 80 * 1024); \
+                                                      RT_LAUNCH((k_conv16v2<NT, KWV, KWRV, DOTV, NWV, BDV>), grid2, dim3(64 * (NWV)), lds2, st, c2); } while (0)
+#define RT_V2_GO(NT, KWV, KWRV) do { if (nw == 4) RT_V2_ONE(NT, KWV, KWRV, 0, 4, true); else RT_V2_ONE(NT, KWV, KWRV, 0, 8, true); } while (0)
+#define RT_V2_LAUNCH(NT) do { if (KW == 1) RT_V2_GO(NT, 1, 1); else RT_V2_GO(NT, 3, 3); } while (0)
+  if (k9) { RT_V2_GO(2, 9, 9); return true; }
+  if (g3) { RT_V2_GO(2, 9, 3); return true; }
+  if (k22) { if (nw == 4) RT_V2_ONE(2, 4, 2, 1, 4, false); else RT_V2_ONE(2, 4, 2, 1, 8, false); return true; }
   switch (bn2 / 32) {
     case 1: RT_V2_LAUNCH(1); break;
     case 2: RT_V2_LAUNCH(2); break;
@@ -792,6 +841,7 @@ bool conv16_dma(hipStream_t st, const ConvArgs& a0, int n_img, int maxHo, int ma
   }
 #undef RT_V2_LAUNCH
 #undef RT_V2_GO
+#undef RT_V2_ONE
   return true;
 }
 
