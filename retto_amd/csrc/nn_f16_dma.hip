@@ -78,6 +78,13 @@ __device__ __forceinline__ void lds_wait() {
   __builtin_amdgcn_sched_barrier(0);
 }
 
+// Halo rows un-swizzled since round 5 (make EXTRA=-DRT_V2_HSWZ=1 restores the XOR swizzle of the chunk index with bits 2-3 of the
+// pixel): the swizzle made the pixel-fragment reads conflict-free at ~4 address instructions per read, and the main loop is bound
+// by instruction issue, not by the LDS (24 % busy): without it the reads are 2-way conflicting and the server det network runs
+// 30.4 -> 29.8 ms per 32 pages.  (The weight rows keep their swizzle: its term is a per-lane constant.)
+#ifndef RT_V2_HSWZ
+#define RT_V2_HSWZ 0
+#endif
 struct ConvArgs2 {
   ConvArgs a;
   const half_t* zeros;   // >= 16 zero bytes in device memory: DMA source of padding pixels / channels
@@ -199,7 +206,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_conv16v2(const ConvArgs2 c2) {
     const int e = tid + i * NTHR;
     hsrc[i] = -1;
     if (e < hchunks) {
-      const int p = e >> 2, cl = (e & 3) ^ ((p >> 2) & 3);
+      const int p = e >> 2, cl = RT_V2_HSWZ ? ((e & 3) ^ ((p >> 2) & 3)) : (e & 3);
       const int hy = c2.hw_magic ? (int)__umulhi((unsigned)p, c2.hw_magic) : p, hx = p - hy * HW;
       const int iy = iy0 + hy, ix = ix0 + hx;
       if (iy >= 0 && iy < gi.H && ix >= 0 && ix < gi.W) hsrc[i] = ((hy * gi.W + hx) * a.ldx + cl * 8) | (cl << 28);
@@ -280,7 +287,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_conv16v2(const ConvArgs2 c2) {
 #pragma unroll
       for (int j = 0; j < NTP; j++) {
         const int p = pix[j] + tap0 + (RG == 1 ? dx : (dx / KWR) * HW + dx % KWR);
-        B[j] = *reinterpret_cast<const h8*>(halo + p * ROW + ((cl ^ ((p >> 2) & 3)) << 3));
+        B[j] = *reinterpret_cast<const h8*>(halo + p * ROW + ((RT_V2_HSWZ ? (cl ^ ((p >> 2) & 3)) : cl) << 3));
       }
     };
     auto mfmas = [&](const h8 (&A)[NTN], const h8 (&B)[NTP]) {
