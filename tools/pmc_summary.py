@@ -55,7 +55,7 @@ LABELS = {"gemm_pw/k_gemm32p": "family:gemm32p", "gemm_pw/k_gemm32p+se": "family
 # member kernels (traffic per launch) and the cycle-weighted MFMA utilisation.  (The 3x3 family's few register-staged
 # launches -- the 3-channel stems -- run k_conv16 instances shared with other families and are left out.)
 FAMILIES = {"gemm32p": r"k_gemm32p<-?\d+, -?\d+, (true|false), 0, false>", "gemm32p_se": r"k_gemm32p<-?\d+, -?\d+, (true|false), 0, true>",   # (fp32: the persistent LDS-DMA wide GEMM, K = 32 j and K = 32 j + 16 instances)
-            "conv16_3x3": r"k_conv16v2<\d, (3, 3|9, 3)(, 0)?(, \d)?>", "gemm16": r"k_gemm16p?<", "conv16_9x9": r"k_conv16v2<2, 9, 9(, 0)?(, \d)?>"}
+            "conv16_3x3": r"k_conv16v2<\d, (3, 3|9, 3)(, 0)?(, \d)?(, (true|false))?>", "gemm16": r"k_gemm16p?<", "conv16_9x9": r"k_conv16v2<2, 9, 9(, 0)?(, \d)?(, (true|false))?>"}
 
 
 def main():
