@@ -86,7 +86,10 @@ __device__ __forceinline__ void epilogue_store(f32x4 (&acc)[2][NT], int nt_valid
 // Flat GEMM: rows = pixels (any ragged batch is just a longer M).
 // Block 256 threads (4 waves), tile 128 rows x 16*NT cols, K in 32-chunks.
 // ---------------------------------------------------------------------------
-template <int NT, int EPIM = 0>
+// BF (round 5): the slab fetch through buffer resources -- fixed per-thread byte offsets, the slab advance as the scalar offset, rows
+// beyond M / Npad and the K tail out of range (zeros) -- instead of a predicated 64-bit-address load per vector: every VALU
+// instruction of an fp32 MFMA loop is paid in MFMA time, and the address / predicate arithmetic was ~100 of them per slab.
+template <int NT, int EPIM = 0, bool BF = false>
 __global__ __launch_bounds__(256) void k_gemm(const float* __restrict__ A, int lda, long long M, int K,
                                               const float* __restrict__ Wp, int N, int Npad, float* __restrict__ C,
                                               int ldc, int coff, Epilogue epi) {
@@ -107,8 +110,34 @@ __global__ __launch_bounds__(256) void k_gemm(const float* __restrict__ A, int l
   // next K-slab (128 activation rows + 16*NT weight rows) in registers while the current one is multiplied
   constexpr int W_LD = (16 * NT * 8 + 255) / 256;
   f32x4 pa[4], pw[W_LD];
+  // buffer form: descriptors over this tile's rows / this block's weight rows, per-thread offsets fixed for the whole K loop
+  unsigned aoff[4], woff[W_LD];
+  __amdgpu_buffer_rsrc_t ars, wrs;
+  if (BF) {
+    const long long rows_here = min((long long)128, M - m0);
+    ars = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(A + m0 * lda), 0, (unsigned)(rows_here * lda * 4), 0x00020000);
+    wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Wp + (long long)n0 * KC), 0, 0x7fffffffu, 0x00020000);
+#pragma unroll
+    for (int i = 0; i < 4; i++) { const int idx = tid + 256 * i; aoff[i] = (unsigned)((idx >> 3) * lda * 4 + (idx & 7) * 16); }
+#pragma unroll
+    for (int i = 0; i < W_LD; i++) {
+      const int idx = tid + 256 * i, row = idx >> 3;
+      woff[i] = (idx < 16 * NT * 8 && n0 + row < Npad) ? (unsigned)(row * KC * 4 + (idx & 7) * 16) : 0x80000000u;
+    }
+  }
   auto fetch = [&](int kc) {
     const int k0 = kc * KC;
+    if (BF) {
+      const bool tail = k0 + KC > K;   // (uniform) the last slab of a K that is not a multiple of 32: vectors beyond K are zeros
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        const unsigned o = (tail && k0 + (int)((tid + 256 * i) & 7) * 4 >= K) ? 0x80000000u : aoff[i];
+        pa[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ars, o, k0 * 4, 0));
+      }
+#pragma unroll
+      for (int i = 0; i < W_LD; i++) pw[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, woff[i], kc * Npad * KC * 4, 0));
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < 4; i++) {
       int idx = tid + 256 * i;
@@ -781,6 +810,10 @@ void gemm(hipStream_t st, const float* A, int lda, long long M, int K, const flo
       RT_LAUNCH((k_gemm_wide<2, 4, 4, 2, 0, 0, 0, 1>), grid, dim3(512), 0, st, A, lda, M, K, Wp, N, Npad16, C, ldc, coff, epi);
     } else {  // narrow kernel, 128-column blocks
       dim3 grid((unsigned)((M + 127) / 128), (unsigned)((Npad16 + 127) / 128));
+      static const int bf_env1 = getenv("RT_GEMM_BF") ? atoi(getenv("RT_GEMM_BF")) : 1;
+      if (bf_env1 && (long long)128 * lda * 4 < (1ll << 31) && (long long)((K + KC - 1) / KC) * Npad16 * KC * 4 < (1ll << 31))
+        RT_LAUNCH((k_gemm<8, 1, true>), grid, dim3(256), 0, st, A, lda, M, K, Wp, N, Npad16, C, ldc, coff, epi);
+      else
       RT_LAUNCH((k_gemm<8, 1>), grid, dim3(256), 0, st, A, lda, M, K, Wp, N, Npad16, C, ldc, coff, epi);
     }
     return;
@@ -845,8 +878,12 @@ void gemm(hipStream_t st, const float* A, int lda, long long M, int K, const flo
     NT = best;
   }
   dim3 grid((unsigned)((M + 127) / 128), (unsigned)((ntiles + NT - 1) / NT));
+  // buffer-resource fetch (k_gemm<NT, 0, true>): a tile's 128 rows and the packed weights within the 2-GB offset range
+  static const int bf_env = getenv("RT_GEMM_BF") ? atoi(getenv("RT_GEMM_BF")) : 1;
+  const bool bf = bf_env && (long long)128 * lda * 4 < (1ll << 31) && (long long)((K + KC - 1) / KC) * Npad16 * KC * 4 < (1ll << 31);
 #define RT_GEMM_CASE(n) \
-  case n: RT_LAUNCH(k_gemm<n>, grid, dim3(256), 0, st, A, lda, M, K, Wp, N, Npad16, C, ldc, coff, epi); break;
+  case n: if (bf) RT_LAUNCH((k_gemm<n, 0, true>), grid, dim3(256), 0, st, A, lda, M, K, Wp, N, Npad16, C, ldc, coff, epi); \
+          else RT_LAUNCH(k_gemm<n>, grid, dim3(256), 0, st, A, lda, M, K, Wp, N, Npad16, C, ldc, coff, epi); break;
   switch (NT) {
     RT_GEMM_CASE(1) RT_GEMM_CASE(2) RT_GEMM_CASE(3) RT_GEMM_CASE(4) RT_GEMM_CASE(5) RT_GEMM_CASE(6) RT_GEMM_CASE(7)
     RT_GEMM_CASE(8)
