@@ -37,7 +37,15 @@ namespace {
 __device__ __forceinline__ void glds16_so(unsigned voff, const void* sbase, unsigned lds_sgpr) {
   asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_sgpr) : "memory", "m0");
 }
+// The same through a buffer resource (round 5): source = resource base + per-lane byte offset + scalar offset; a lane whose offset
+// is beyond the resource's range writes zeros.
+__device__ __forceinline__ void blds16(unsigned voff, __amdgpu_buffer_rsrc_t rs, unsigned lds_sgpr, unsigned soff) {
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %3 offen lds" ::"v"(voff), "s"(rs), "s"(lds_sgpr), "s"(soff) : "memory", "m0");
+}
 #pragma clang diagnostic pop
+#ifndef RT_G32P_BUF
+#define RT_G32P_BUF 1   // 0 (make EXTRA=-DRT_G32P_BUF=0): the round-4 request form, per-lane offsets re-derived at every request
+#endif
 __device__ __forceinline__ unsigned lds_addr32(const void* p) { return (unsigned)(size_t)(__attribute__((address_space(3))) const char*)p; }
 template <int OFF>
 __device__ __forceinline__ f32x4 lds_read16f(unsigned byte_addr) {   // address + compile-time offset in the instruction
@@ -137,14 +145,59 @@ __global__ __launch_bounds__(P_NTHR, 1) void k_gemm32p(const GemmPArgs g) {
   const bool p2_is_a = wid + 2 * P_NW < P_AJ;
   const unsigned pitch = (unsigned)(g.lda * 4);
   int dbg_issued = 0;
+#if RT_G32P_BUF
+  // per-lane request offsets: lane i of a wave's piece addresses row 8 wid + i / 8 of the piece group, physical chunk i % 8
+  constexpr bool REQ_HELD = ASC;
+  unsigned held_a = 0, held_w = 0;
+  if (REQ_HELD) {
+    const int rsub = lane >> 3, c0 = lane & 7, row = 8 * wid + rsub;
+    const unsigned ch = (unsigned)((c0 ^ ((row >> 1) & 7)) * 16);
+    held_a = (unsigned)row * pitch + ch;
+    held_w = (unsigned)(row * 128) + ch;
+  }
+#endif
   auto dma_issue = [&]() __attribute__((always_inline)) {
     if (it_live && !((DBG & 2) && dbg_issued >= 2)) {
       dbg_issued++;
       const long long m0 = (long long)it_rb * P_BM;
+      const unsigned dst = lds_b + it_buf * P_STAGE + (unsigned)wid * 1024;
+#if RT_G32P_BUF
+      // Buffer form: every piece a wave requests lies 96 rows (12 KB of slab image) behind its previous one, and 96 rows do not
+      // change the swizzle term -- so ONE per-lane offset per operand (req_a / req_w, fixed for the kernel) serves all six
+      // requests; the piece, slab and column-block advances are scalar.  The pixel descriptor ends with the row block's last
+      // valid row: rows beyond M arrive as zeros (never stored) without the per-lane clamp.  ~8 VALU instructions per slab and
+      // wave instead of ~30 -- an fp32 MFMA loop pays each of them in MFMA time.
+      {
+        const unsigned rows_here = (unsigned)min((long long)P_BM, g.M - m0);
+        const __amdgpu_buffer_rsrc_t ars = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.A + m0 * g.lda), 0, rows_here * pitch, 0x00020000);
+        // (weights: the descriptor starts 8 pieces BEFORE the column block's rows -- piece 2 of the waves 8..11 is weight piece
+        //  wid - 8 -- so that every scalar offset is >= 0; nothing below the first weight row is ever addressed)
+        const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.Wp + (long long)it_cb * P_BN * KC - 8 * 256), 0, 0x7fffffffu, 0x00020000);
+        // (the two per-lane offsets: held in registers by the squeeze-excite instantiations, re-derived from the lane id -- ~10
+        //  VALU instructions -- by the plain ones: each form spills accumulators in the other family, allocation is at 168 of 168)
+        unsigned req_a = held_a, req_w = held_w;
+        unsigned sa = (unsigned)it_kc * (KC * 4), swk = (unsigned)it_kc * (unsigned)g.Npad * (KC * 4);
+        if (!REQ_HELD) {
+          int ln_ = lane_id();
+          asm volatile("" : "+v"(ln_));
+          const unsigned ch_ = (unsigned)(((ln_ & 7) ^ (((ln_ >> 4) & 3) | ((wid & 1) << 2))) << 4);
+          req_a = (unsigned)(ln_ >> 3) * pitch + ch_; req_w = (unsigned)((ln_ >> 3) * 128) + ch_;
+          sa += (unsigned)(8 * wid) * pitch; swk += (unsigned)wid * 1024u;
+        }
+        blds16(req_a, ars, dst, sa);
+        blds16(req_a + 96u * pitch, ars, dst + 1 * (P_NW * 1024), sa);
+        if (p2_is_a) blds16(req_a + 192u * pitch, ars, dst + 2 * (P_NW * 1024), sa);
+        else blds16(req_w, wrs, dst + 2 * (P_NW * 1024), swk);
+        blds16(req_w, wrs, dst + 3 * (P_NW * 1024), swk + 12 * 1024);
+        blds16(req_w, wrs, dst + 4 * (P_NW * 1024), swk + 24 * 1024);
+        if (wid + 5 * P_NW < P_AJ + P_WJ) blds16(req_w, wrs, dst + 5 * (P_NW * 1024), swk + 36 * 1024);
+      }
+      int ln = 0;
+      if (ASC) { ln = lane_id(); asm volatile("" : "+v"(ln)); }
+#else
       const int last = (int)min((long long)P_BM - 1, g.M - 1 - m0);   // rows beyond M re-read the last valid row (never stored)
       const float* abase = g.A + m0 * g.lda + it_kc * KC;
       const float* wbase = g.Wp + ((long long)it_kc * g.Npad + it_cb * P_BN) * KC;
-      const unsigned dst = lds_b + it_buf * P_STAGE + (unsigned)wid * 1024;
       int ln = lane_id();
       asm volatile("" : "+v"(ln));
       const int rsub = ln >> 3, c0 = ln & 7;
@@ -163,6 +216,7 @@ __global__ __launch_bounds__(P_NTHR, 1) void k_gemm32p(const GemmPArgs g) {
       glds16_so(off_w(3), wbase, dst + 3 * (P_NW * 1024));
       glds16_so(off_w(4), wbase, dst + 4 * (P_NW * 1024));
       if (wid + 5 * P_NW < P_AJ + P_WJ) glds16_so(off_w(5), wbase, dst + 5 * (P_NW * 1024));
+#endif
       if (ASC && it_kc == 0 && wid >= 2 && wid < 8) {
         // the tile's scale vectors (3 images x K floats) ride with its first slab: waves 2..7 request one 1-KB piece each
         // (image slot (wid - 2) / 2, half (wid - 2) % 2) into the table of this tile's parity

@@ -877,6 +877,13 @@ void gemm(hipStream_t st, const float* A, int lda, long long M, int K, const flo
     }
     NT = best;
   }
+  // small M (one page, the coarse pyramid levels): fewer columns per workgroup until there is a workgroup per CU -- 3600 x 480 x
+  // 480 on 128 x 128 tiles is 116 workgroups walking 15 slabs each, 35 us; the column tiles are independent: same bits
+  {
+    const long long rbs = (M + 127) / 128;
+    const int cus = stream_cus(st);
+    while (NT > 1 && rbs * ((ntiles + NT - 1) / NT) < cus) NT = (NT + 1) / 2;
+  }
   dim3 grid((unsigned)((M + 127) / 128), (unsigned)((ntiles + NT - 1) / NT));
   // buffer-resource fetch (k_gemm<NT, 0, true>): a tile's 128 rows and the packed weights within the 2-GB offset range
   static const int bf_env = getenv("RT_GEMM_BF") ? atoi(getenv("RT_GEMM_BF")) : 1;
@@ -1908,7 +1915,9 @@ void nchw3_to_nhwc4(hipStream_t st, const float* in, int n, int H, int W, float*
 // ---------------------------------------------------------------------------
 // Squeeze-excite / global mean: deterministic two-stage reduction.
 // ---------------------------------------------------------------------------
-constexpr int POOL_PIX = 1024;  // pixels per partial block
+// (round 5: 128 pixels per block, was 1024 -- with 480 channels a thread summed 512 pixels one dependent load after the other, 27 us
+//  per launch whatever the batch: 8 launches = 18 % of the one-page C2 call; k_se_fc adds the chunks 16 bytes wide on up to 1024 threads)
+constexpr int POOL_PIX = 128;  // pixels per partial block
 int pool_chunks(long long max_pix) { return (int)((max_pix + POOL_PIX - 1) / POOL_PIX); }
 
 __global__ __launch_bounds__(256) void k_pool_partial(const float* __restrict__ x, const ImgGeom* __restrict__ geom,
@@ -1928,6 +1937,7 @@ __global__ __launch_bounds__(256) void k_pool_partial(const float* __restrict__ 
     f32x4 s = {0.f, 0.f, 0.f, 0.f};
     if (pl < PL && p0 < npix) {
       long long pend = min(npix, p0 + POOL_PIX);
+#pragma unroll 4
       for (long long p = p0 + pl; p < pend; p += PL) {
         f32x4 v = *reinterpret_cast<const f32x4*>(x + (g.off + p) * Cp + c4 * 4);
         s += v;
@@ -1944,20 +1954,24 @@ __global__ __launch_bounds__(256) void k_pool_partial(const float* __restrict__ 
   }
 }
 
-// block per image: mean -> fc1 -> relu -> fc2 -> hardsigmoid.  Round 4: every phase on all 256 threads (the first form summed the
-// chunks with one thread per channel and ran each hidden unit's C-long dot product on one thread: 14 us per launch, 23 launches
-// per C3 step) -- the chunk sums by 256 / C threads per channel, fc1 by 8 lanes per hidden unit (shuffle tree); every order of
-// summation is fixed by the thread layout: repeatable, and independent of the batch the image is in.
-__global__ __launch_bounds__(256) void k_se_fc(const float* __restrict__ partial, const ImgGeom* __restrict__ geom,
-                                               int chunks_alloc, int C, int Cp, const float* __restrict__ w1,
-                                               const float* __restrict__ b1, const float* __restrict__ w2,
-                                               const float* __restrict__ b2, int Cr, float slope, int residual,
-                                               float* __restrict__ scale, int strip_R, int strips_per_block,
-                                               const float* __restrict__ Wlin, int Cin, int Cin_p) {
-  extern __shared__ float sm[];  // mean[Cp] + hid[Cr + 4] + mean_in[Cin_p + 4] (when projecting) + red[256]
+// block per image: mean -> fc1 -> relu -> fc2 -> hardsigmoid.  Round 4: every phase on all threads of the block (the first form
+// summed the chunks with one thread per channel and ran each hidden unit's C-long dot product on one thread: 14 us per launch).
+// Round 5: the launch was still 31 us whatever the batch -- 10 of them are a quarter of the C2 call -- because every phase was a
+// chain of dependent-latency iterations (chunks, then C / 8 per hidden unit, then Cr per channel: ~490 load -> fma steps).  Now up
+// to 1024 threads, 16-byte loads everywhere, 16 lanes per hidden unit and 4 per channel: ~35 steps.  Every order of summation is
+// fixed by the thread layout and the block size, which depends on nothing but the layer: repeatable, and independent of the batch
+// the image is in.
+__global__ __launch_bounds__(1024) void k_se_fc(const float* __restrict__ partial, const ImgGeom* __restrict__ geom,
+                                                int chunks_alloc, int C, int Cp, const float* __restrict__ w1,
+                                                const float* __restrict__ b1, const float* __restrict__ w2,
+                                                const float* __restrict__ b2, int Cr, float slope, int residual,
+                                                float* __restrict__ scale, int strip_R, int strips_per_block,
+                                                const float* __restrict__ Wlin, int Cin, int Cin_p) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];  // mean[Cp] | hid[Cr4 + 4] | mean_in[Cin_p + 4] (when projecting) | red[4 NT]
+  const int NT = (int)blockDim.x, Cr4 = (Cr + 3) & ~3;
   float* mean = sm;
   float* hid = sm + Cp;
-  float* mean_in = sm + Cp + Cr + 4;
+  float* mean_in = hid + Cr4 + 4;
   float* red = mean_in + (Wlin ? Cin_p + 4 : 0);
   const ImgGeom g = geom[blockIdx.x];
   const long long npix = (long long)g.H * g.W;
@@ -1970,49 +1984,80 @@ __global__ __launch_bounds__(256) void k_se_fc(const float* __restrict__ partial
                                  : (int)((npix + POOL_PIX - 1) / POOL_PIX);
   const float inv = 1.0f / (float)npix;
   {
-    // channel sums: Cs channels (of the narrow tensor when projecting), `parts` threads per channel each adding every parts-th
-    // chunk, then the parts in order
-    const int Cs = Wlin ? Cin_p : Cp;
+    // channel sums: Cs channels (of the narrow tensor when projecting) as Cs / 4 columns of 16 bytes, NT / (Cs / 4) threads per
+    // column each adding every PL-th chunk, then the parts in order
+    const int Cs = Wlin ? Cin_p : Cp, C4 = Cs >> 2;
     float* dst = Wlin ? mean_in : mean;
     const float* part = partial + (long long)blockIdx.x * chunks_alloc * Cs;
-    if (Cs <= 128) {
-      const int parts = 256 / Cs, c = tid % Cs, pp = tid / Cs;
-      float s0 = 0.f;
-      if (pp < parts)
-        for (int k = pp; k < chunks; k += parts) s0 += part[(long long)k * Cs + c];
-      red[tid] = s0;
+    f32x4* red4 = reinterpret_cast<f32x4*>(red);
+    for (int cb = 0; cb < C4; cb += NT) {
+      const int cg = min(NT, C4 - cb), PL = NT / cg, col = cb + tid % cg, pl = tid / cg;
+      f32x4 s0 = {0.f, 0.f, 0.f, 0.f};
+      if (pl < PL) {
+#pragma unroll 4
+        for (int k = pl; k < chunks; k += PL) s0 += *reinterpret_cast<const f32x4*>(part + (long long)k * Cs + col * 4);
+      }
+      red4[tid] = s0;
       __syncthreads();
-      if (tid < Cs) {
-        float t = 0.f;
-        for (int i = 0; i < parts; i++) t += red[i * Cs + tid];
-        dst[tid] = t * inv;
+      if (tid < cg) {
+        f32x4 t = {0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < PL; i++) t += red4[i * cg + tid];
+        *reinterpret_cast<f32x4*>(dst + (cb + tid) * 4) = t * inv;
       }
-    } else {
-      for (int c = tid; c < Cs; c += 256) {
-        float s0 = 0.f;
-        for (int k = 0; k < chunks; k++) s0 += part[(long long)k * Cs + c];
-        dst[c] = s0 * inv;
-      }
+      __syncthreads();
     }
-    __syncthreads();
   }
   if (Wlin) {
     // The pooled tensor is a bias-free 1x1 conv of a narrower one (FPN lateral: y = x . Wlin): mean(y) = mean(x) . Wlin,
     // so the partial sums are those of x (pitch Cin_p) and y itself never has to exist for the squeeze.
-    for (int c = tid; c < Cp; c += 256) {
+    if (Cp <= NT) {   // NT / Cp threads per output channel, each every G-th input channel; the parts in order
+      const int G = NT / Cp, gk = tid / Cp, c = tid - gk * Cp;
       float s0 = 0.f;
-      if (c < C) for (int k = 0; k < Cin; k++) s0 = fmaf(mean_in[k], Wlin[k * C + c], s0);
-      mean[c] = s0;
+      if (gk < G && c < C) {
+#pragma unroll 4
+        for (int k = gk; k < Cin; k += G) s0 = fmaf(mean_in[k], Wlin[k * C + c], s0);
+      }
+      red[tid] = s0;
+      __syncthreads();
+      if (tid < Cp) {
+        float t = 0.f;
+        for (int i = 0; i < G; i++) t += red[i * Cp + tid];
+        mean[tid] = tid < C ? t : 0.f;
+      }
+    } else {
+      for (int c = tid; c < Cp; c += NT) {
+        float s0 = 0.f;
+        if (c < C) for (int k = 0; k < Cin; k++) s0 = fmaf(mean_in[k], Wlin[k * C + c], s0);
+        mean[c] = s0;
+      }
     }
     __syncthreads();
   }
   if (w1 == nullptr) {  // plain global mean
-    for (int c = tid; c < Cp; c += 256) scale[(long long)blockIdx.x * Cp + c] = mean[c];
+    for (int c = tid; c < Cp; c += NT) scale[(long long)blockIdx.x * Cp + c] = mean[c];
     return;
   }
-  {  // fc1, w1 [Cr][C]: 8 adjacent lanes per hidden unit, 32 units per pass
-    const int l = tid & 7;
-    for (int j0 = 0; j0 < Cr; j0 += 32) {
+  if (tid < Cr4 + 4 - Cr) hid[Cr + tid] = 0.f;
+  if (((C & 3) | (int)((size_t)w1 & 15)) == 0) {  // fc1, w1 [Cr][C]: 16 adjacent lanes per hidden unit, 16-byte loads, NT / 16 units per pass
+    const int l = tid & 15, UP = NT >> 4, n4 = C >> 2;
+    const f32x4* m4 = reinterpret_cast<const f32x4*>(mean);
+    for (int j0 = 0; j0 < Cr; j0 += UP) {
+      const int j = j0 + (tid >> 4);
+      float s0 = 0.f;
+      if (j < Cr) {
+        const f32x4* wr = reinterpret_cast<const f32x4*>(w1 + (long long)j * C);
+#pragma unroll 4
+        for (int c4 = l; c4 < n4; c4 += 16) {
+          const f32x4 w = wr[c4], m = m4[c4];
+          s0 = fmaf(m[0], w[0], s0); s0 = fmaf(m[1], w[1], s0); s0 = fmaf(m[2], w[2], s0); s0 = fmaf(m[3], w[3], s0);
+        }
+      }
+      s0 += __shfl_xor(s0, 8); s0 += __shfl_xor(s0, 4); s0 += __shfl_xor(s0, 2); s0 += __shfl_xor(s0, 1);
+      if (j < Cr && l == 0) hid[j] = fmaxf(s0 + b1[j], 0.f);
+    }
+  } else {  // (C not a multiple of 4: 8 lanes per unit, scalar loads)
+    const int l = tid & 7, UP = NT >> 3;
+    for (int j0 = 0; j0 < Cr; j0 += UP) {
       const int j = j0 + (tid >> 3);
       float s0 = 0.f;
       if (j < Cr) {
@@ -2024,18 +2069,50 @@ __global__ __launch_bounds__(256) void k_se_fc(const float* __restrict__ partial
     }
   }
   __syncthreads();
-  for (int c = tid; c < Cp; c += 256) {  // w2 [C][Cr]
-    float o = 0.f;
-    if (c < C) {
-      float s0 = b2[c];
-      const float* wr = w2 + (long long)c * Cr;
+  if (((Cr & 3) | (int)((size_t)w2 & 15)) == 0) {  // fc2, w2 [C][Cr]: 4 adjacent lanes per channel, 16-byte loads
+    const int l = tid & 3, CPP = NT >> 2, n4 = Cr >> 2;
+    const f32x4* h4 = reinterpret_cast<const f32x4*>(hid);
+    for (int c0 = 0; c0 < Cp; c0 += CPP) {
+      const int c = c0 + (tid >> 2);
+      float s0 = 0.f;
+      if (c < C) {
+        const f32x4* wr = reinterpret_cast<const f32x4*>(w2 + (long long)c * Cr);
 #pragma unroll 4
-      for (int j = 0; j < Cr; j++) s0 = fmaf(hid[j], wr[j], s0);
-      o = fminf(fmaxf(fmaf(s0, slope, 0.5f), 0.f), 1.f);
-      if (residual) o += 1.0f;
+        for (int j4 = l; j4 < n4; j4 += 4) {
+          const f32x4 w = wr[j4], h = h4[j4];
+          s0 = fmaf(h[0], w[0], s0); s0 = fmaf(h[1], w[1], s0); s0 = fmaf(h[2], w[2], s0); s0 = fmaf(h[3], w[3], s0);
+        }
+      }
+      s0 += __shfl_xor(s0, 2); s0 += __shfl_xor(s0, 1);
+      if (l == 0 && c < Cp) {
+        float o = 0.f;
+        if (c < C) {
+          o = fminf(fmaxf(fmaf(s0 + b2[c], slope, 0.5f), 0.f), 1.f);
+          if (residual) o += 1.0f;
+        }
+        scale[(long long)blockIdx.x * Cp + c] = o;
+      }
     }
-    scale[(long long)blockIdx.x * Cp + c] = o;
+  } else {
+    for (int c = tid; c < Cp; c += NT) {
+      float o = 0.f;
+      if (c < C) {
+        float s0 = b2[c];
+        const float* wr = w2 + (long long)c * Cr;
+#pragma unroll 4
+        for (int j = 0; j < Cr; j++) s0 = fmaf(hid[j], wr[j], s0);
+        o = fminf(fmaxf(fmaf(s0, slope, 0.5f), 0.f), 1.f);
+        if (residual) o += 1.0f;
+      }
+      scale[(long long)blockIdx.x * Cp + c] = o;
+    }
   }
+}
+// block size of k_se_fc: decided by the layer alone (the summation orders depend on it): 1024 threads for the wide layers, whose
+// fc matrices are 30-230 KB; 256 where a block has nothing to spread (C <= 64)
+static int se_fc_threads(int Cp, int Cin_p) { return std::max(Cp, Cin_p) > 64 ? 1024 : 256; }
+static size_t se_fc_lds(int Cp, int Cr, int Cin_p, bool proj, int nt) {
+  return (size_t)(Cp + ((Cr + 3) & ~3) + 4 + (proj ? Cin_p + 4 : 0) + 4 * nt) * sizeof(float);
 }
 
 void se_scale(hipStream_t st, const float* x, const ImgGeom* geom, int n_img, long long max_pix, int C, int Cp,
@@ -2044,7 +2121,8 @@ void se_scale(hipStream_t st, const float* x, const ImgGeom* geom, int n_img, lo
   if (n_img <= 0) return;
   int chunks = pool_chunks(max_pix);
   RT_LAUNCH(k_pool_partial, dim3(chunks, n_img), dim3(256), 0, st, x, geom, Cp, chunks, partial);
-  RT_LAUNCH(k_se_fc, dim3(n_img), dim3(256), (Cp + Cr + 4 + 256) * sizeof(float), st, partial, geom, chunks, C, Cp,
+  const int nt = se_fc_threads(Cp, 0);
+  RT_LAUNCH(k_se_fc, dim3(n_img), dim3(nt), se_fc_lds(Cp, Cr, 0, false, nt), st, partial, geom, chunks, C, Cp,
                      w1, b1, w2, b2, Cr, slope, residual, scale, 0, 32, (const float*)nullptr, 0, 0);
 }
 void se_scale_projected(hipStream_t st, const float* x_in, const ImgGeom* geom, int n_img, long long max_pix, int Cin,
@@ -2053,7 +2131,8 @@ void se_scale_projected(hipStream_t st, const float* x_in, const ImgGeom* geom, 
   if (n_img <= 0) return;
   int chunks = pool_chunks(max_pix);
   RT_LAUNCH(k_pool_partial, dim3(chunks, n_img), dim3(256), 0, st, x_in, geom, Cin_p, chunks, partial);
-  RT_LAUNCH(k_se_fc, dim3(n_img), dim3(256), (Cp + Cr + 4 + Cin_p + 4 + 256) * sizeof(float), st, partial, geom, chunks, C, Cp,
+  const int nt = se_fc_threads(Cp, Cin_p);
+  RT_LAUNCH(k_se_fc, dim3(n_img), dim3(nt), se_fc_lds(Cp, Cr, Cin_p, true, nt), st, partial, geom, chunks, C, Cp,
                      w1, b1, w2, b2, Cr, slope, residual, scale, 0, 32, Wlin, Cin, Cin_p);
 }
 // Lanes side by side on a pixel in k_dwconv_rows for this layer: 16 / 32 (64- / 128-channel slabs) where the tensor is
@@ -2079,14 +2158,16 @@ void se_fc_from_dw(hipStream_t st, const float* partial, const ImgGeom* geom, in
                    int strips_per_block, int C, int Cp, const float* w1, const float* b1, const float* w2, const float* b2,
                    int Cr, float slope, int residual, float* scale) {
   if (n_img <= 0) return;
-  RT_LAUNCH(k_se_fc, dim3(n_img), dim3(256), (Cp + Cr + 4 + 256) * sizeof(float), st, partial, geom, chunks, C, Cp,
+  const int nt = se_fc_threads(Cp, 0);
+  RT_LAUNCH(k_se_fc, dim3(n_img), dim3(nt), se_fc_lds(Cp, Cr, 0, false, nt), st, partial, geom, chunks, C, Cp,
                      w1, b1, w2, b2, Cr, slope, residual, scale, strip_R, strips_per_block, (const float*)nullptr, 0, 0);
 }
 void se_fc_from_tiles(hipStream_t st, const float* partial, const ImgGeom* geom, int n_img, int tiles_alloc, int C, int Cp,
                       const float* w1, const float* b1, const float* w2, const float* b2, int Cr, float slope, int residual,
                       float* scale) {
   if (n_img <= 0) return;
-  RT_LAUNCH(k_se_fc, dim3(n_img), dim3(256), (Cp + Cr + 4 + 256) * sizeof(float), st, partial, geom, tiles_alloc, C, Cp,
+  const int nt = se_fc_threads(Cp, 0);
+  RT_LAUNCH(k_se_fc, dim3(n_img), dim3(nt), se_fc_lds(Cp, Cr, 0, false, nt), st, partial, geom, tiles_alloc, C, Cp,
                      w1, b1, w2, b2, Cr, slope, residual, scale, -16, 32, (const float*)nullptr, 0, 0);
 }
 void global_mean(hipStream_t st, const float* x, const ImgGeom* geom, int n_img, long long max_pix, int Cp,
@@ -2094,7 +2175,8 @@ void global_mean(hipStream_t st, const float* x, const ImgGeom* geom, int n_img,
   if (n_img <= 0) return;
   int chunks = pool_chunks(max_pix);
   RT_LAUNCH(k_pool_partial, dim3(chunks, n_img), dim3(256), 0, st, x, geom, Cp, chunks, partial);
-  RT_LAUNCH(k_se_fc, dim3(n_img), dim3(256), (Cp + 4 + 256) * sizeof(float), st, partial, geom, chunks, Cp, Cp,
+  const int nt = se_fc_threads(Cp, 0);
+  RT_LAUNCH(k_se_fc, dim3(n_img), dim3(nt), se_fc_lds(Cp, 0, 0, false, nt), st, partial, geom, chunks, Cp, Cp,
                      (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, 0,
                      0.f, 0, out, 0, 32, (const float*)nullptr, 0, 0);
 }

@@ -669,6 +669,12 @@ rt_results* rt_session::run_pages(const uint8_t* const* rgb, const int* hs, cons
   // metadata round trip #1: box lists (a few KB per page); pixels and tensors stay on the device
   int* h_counts = pinned.alloc<int>((size_t)2 * std::max(n_pages, 1));
   if (n_pages > 0) RT_HIP_CHECK(hipMemcpyAsync(h_counts, d_counts_all, (size_t)2 * n_pages * sizeof(int), hipMemcpyDeviceToHost, st));
+  // (the map checksum partials ride to pinned memory with the box counts)
+  std::vector<double*> h_sum(sum_parts.size());
+  for (size_t g = 0; g < sum_parts.size(); g++) {
+    h_sum[g] = pinned.alloc<double>((size_t)sum_counts[g]);
+    RT_HIP_CHECK(hipMemcpyAsync(h_sum[g], sum_parts[g], (size_t)sum_counts[g] * 8, hipMemcpyDeviceToHost, st));
+  }
   sync(); check_flags();
   int total_lines = 0;
   for (int i = 0; i < n_pages; i++) {
@@ -677,17 +683,16 @@ rt_results* rt_session::run_pages(const uint8_t* const* rgb, const int* hs, cons
     pg[i].first_line = total_lines;
     total_lines += pg[i].n_boxes;
   }
+  pp::DbBox* h_boxes = nullptr;
   if (total_lines > 0) {
-    pp::DbBox* h_boxes = pinned.alloc<pp::DbBox>((size_t)total_lines);
+    h_boxes = pinned.alloc<pp::DbBox>((size_t)total_lines);
     RT_HIP_CHECK(hipMemcpyAsync(h_boxes, d_boxes_packed, (size_t)total_lines * sizeof(pp::DbBox), hipMemcpyDeviceToHost, st));
-    sync();
+  }
+  if (total_lines > 0) sync();
+  if (total_lines > 0)
     for (int i = 0; i < n_pages; i++) pg[i].boxes.assign(h_boxes + pg[i].first_line, h_boxes + pg[i].first_line + pg[i].n_boxes);
-  }
-  for (size_t g = 0; g < sum_parts.size(); g++) {
-    std::vector<double> hp((size_t)sum_counts[g]);
-    RT_HIP_CHECK(hipMemcpy(hp.data(), sum_parts[g], hp.size() * 8, hipMemcpyDeviceToHost));
-    for (double v : hp) res->det_checksum += v;
-  }
+  for (size_t g = 0; g < sum_parts.size(); g++)
+    for (int i = 0; i < sum_counts[g]; i++) res->det_checksum += h_sum[g][i];
 
   if (stage_cb) {  // run_stream: the Det stage is complete here (session.rs:98)
     for (int i = 0; i < n_pages; i++) {
