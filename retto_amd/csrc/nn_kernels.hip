@@ -90,7 +90,7 @@ __device__ __forceinline__ void epilogue_store(f32x4 (&acc)[2][NT], int nt_valid
 // beyond M / Npad and the K tail out of range (zeros) -- instead of a predicated 64-bit-address load per vector: every VALU
 // instruction of an fp32 MFMA loop is paid in MFMA time, and the address / predicate arithmetic was ~100 of them per slab.
 template <int NT, int EPIM = 0, bool BF = false>
-__global__ __launch_bounds__(256) void k_gemm(const float* __restrict__ A, int lda, long long M, int K,
+__global__ __launch_bounds__(256, 4) void k_gemm(const float* __restrict__ A, int lda, long long M, int K,
                                               const float* __restrict__ Wp, int N, int Npad, float* __restrict__ C,
                                               int ldc, int coff, Epilogue epi) {
   __shared__ __attribute__((aligned(16))) float lds[(128 + 16 * NT) * LROW];
@@ -881,8 +881,9 @@ void gemm(hipStream_t st, const float* A, int lda, long long M, int K, const flo
   // 480 on 128 x 128 tiles is 116 workgroups walking 15 slabs each, 35 us; the column tiles are independent: same bits
   {
     const long long rbs = (M + 127) / 128;
-    const int cus = stream_cus(st);
-    while (NT > 1 && rbs * ((ntiles + NT - 1) / NT) < cus) NT = (NT + 1) / 2;
+    static const int occ_env = getenv("RT_GEMM_OCC") ? atoi(getenv("RT_GEMM_OCC")) : 2;   // workgroups per CU to aim for
+    const long long want = (long long)stream_cus(st) * occ_env;
+    while (NT > 1 && rbs * ((ntiles + NT - 1) / NT) < want) NT = (NT + 1) / 2;
   }
   dim3 grid((unsigned)((M + 127) / 128), (unsigned)((ntiles + NT - 1) / NT));
   // buffer-resource fetch (k_gemm<NT, 0, true>): a tile's 128 rows and the packed weights within the 2-GB offset range
