@@ -77,8 +77,8 @@ def parse():
     ap.add_argument("--no-c5", action="store_true", help="skip the C5 leg (server graphs, fp16) that the default C3 run appends as `c5`")
     ap.add_argument("--c5-pages", type=int, default=32)
     ap.add_argument("--c5-steps", type=int, default=5)
-    ap.add_argument("--inflight", type=int, default=2,
-                    help="batches submitted ahead in the timed region (rt_submit_batch / rt_wait_batch); 1 = one synchronous rt_run_batch per step")
+    ap.add_argument("--inflight", type=int, default=None,
+                    help="batches submitted ahead in the timed region (rt_submit_batch / rt_wait_batch; default 2, C2: 4); 1 = one synchronous rt_run_batch per step")
     ap.add_argument("--repeat", type=int, default=2, help="extra repetitions of the K timed steps after the timed region (spread, reported in `repeat`)")
     a = ap.parse_args()
     if a.workload == "c5":
@@ -87,6 +87,10 @@ def parse():
     if a.workload == "c2":
         a.pages = a.pages or 1; a.lines = 0 if a.lines is None else a.lines
         a.steps = a.steps or 200; a.warmup = a.warmup if a.warmup is not None else 20
+        # (one-page calls are 78 short kernels: with 4 calls in flight their lanes fill the CUs a single call leaves idle --
+        #  2240 pages/s at 2 in flight, 2960 at 3, 2980 at 4; C3's 32-page batches gain nothing beyond 2)
+        a.inflight = 4 if a.inflight is None else a.inflight
+    a.inflight = 2 if a.inflight is None else a.inflight
     a.dtype = a.dtype or "f32"; a.models = a.models or "mobile"
     a.pages = a.pages or 32; a.lines = 32 if a.lines is None else a.lines
     a.steps = a.steps or 40; a.warmup = 10 if a.warmup is None else a.warmup   # (round 4: a 1.1 s timed region instead of 0.6 s)
