@@ -50,3 +50,23 @@ def test_pmc_det_bytes_sums_the_det_launches_only(tmp_path):
     assert j["passes"] == passes
     assert j["det_fetch_bytes_per_pass"] == len(det) * 100 * 1024 * 2 and j["det_write_bytes_per_pass"] == len(det) * 40 * 1024
     assert set(j["left_out"]) >= {"k_ccl_rows", "k_contour_boxes", "k_sum_partial"}
+
+
+def test_bench_workload_defaults(monkeypatch):
+    """bench.py's per-workload defaults: the driver runs it with --gpus / --steps / --warmup only, so what a workload needs beyond
+    those must come from parse() -- C3 two batches in flight, C2 (one page per call) four, an explicit --inflight wins."""
+    sys.path.insert(0, ROOT) if ROOT not in sys.path else None
+    import importlib
+    bench = importlib.import_module("bench")
+
+    def args(*argv):
+        monkeypatch.setattr(sys, "argv", ["bench.py", *argv])
+        return bench.parse()
+
+    a = args("--gpus", "1", "--steps", "20", "--warmup", "5")
+    assert (a.workload, a.pages, a.lines, a.inflight, a.dtype, a.models) == ("c3", 32, 32, 2, "f32", "mobile")
+    a = args("--workload", "c2")
+    assert (a.pages, a.lines, a.inflight, a.steps) == (1, 0, 4, 200)
+    assert args("--workload", "c2", "--inflight", "1").inflight == 1
+    a = args("--workload", "c5")
+    assert (a.dtype, a.models, a.inflight) == ("f16", "server", 2)
