@@ -1264,7 +1264,11 @@ bool conv13_flat_supported(int N, int Npad16) { return g_conv13_flat && Npad16 <
 void conv13_flat(hipStream_t st, const float* x, int ldx, long long rows, const unsigned char* flags, int Cin, const float* Wp, int N,
                  int Npad16, float* y, int ldy, const Epilogue& epi) {
   if (rows <= 0) return;
-  const int ntiles = Npad16 / 16, NT = ntiles >= 4 ? 4 : ntiles;
+  const int ntiles = Npad16 / 16;
+  int NT = ntiles >= 4 ? 4 : ntiles;
+  // few tokens (one page: 13 tiles of 128 tokens walking 45 slabs each, 96 us): a column tile per workgroup until there is a
+  // workgroup per CU -- the column tiles are independent: same bits (as the narrow GEMM's launch rule)
+  while (NT > 1 && (rows + 127) / 128 * ((ntiles + NT - 1) / NT) < stream_cus(st)) NT = (NT + 1) / 2;
   dim3 grid((unsigned)((rows + 127) / 128), (unsigned)((ntiles + NT - 1) / NT));
   switch (NT) {
     case 1: RT_LAUNCH((k_conv13_flat<1>), grid, dim3(256), 0, st, x, ldx, rows, flags, Cin, Wp, N, Npad16, y, ldy, epi); break;
