@@ -15,6 +15,10 @@ void gemm(hipStream_t st, const float* A, int lda, long long M, int K, const flo
 const char* gemm_pw_label(long long M, int Npad16, bool a_scale = false, int se_tile_rows = 0);   // se_tile_rows: gemm_se_tile_rows() of the layer
 // Persistent LDS-DMA form of the 256 x 240 tile (nn_gemm_dma.hip): N a multiple of 240, K whole 16-deep groups, plain
 // bias / activation / LAB epilogue.  gemm() takes it for the large 240- / 480-channel layers.
+// k_gemm32w: K = N = 128 with the weights resident in LDS (nn_gemm_dma.hip)
+bool gemm_w_supported(int lda, long long M, int K, int N, int Npad16, const Epilogue& epi);
+void gemm_w(hipStream_t st, const float* A, int lda, long long M, int K, const float* Wp, int N, int Npad16, float* C, int ldc, int coff,
+            const Epilogue& epi);
 bool gemm_dma_supported(int lda, long long M, int K, int N, int Npad16, const Epilogue& epi);
 void gemm_dma(hipStream_t st, const float* A, int lda, long long M, int K, const float* Wp, int N, int Npad16, float* C,
               int ldc, int coff, const Epilogue& epi);

@@ -523,6 +523,133 @@ __global__ __launch_bounds__(P_NTHR, 1) void k_gemm32p(const GemmPArgs g) {
 #undef RT_MF0
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// k_gemm32w (round 5): the 128 -> 128-channel 1x1 convolution of the recognition net's first stage (2.4 M pixels per C3 step:
+// `gemm_pw/thin`, 0.93 ms at 0.55 of the MFMA peak on the register-staged 128 x 128 tile, whose four 32-deep slabs per tile cannot
+// amortise a prologue, two barriers per slab and an epilogue).  Here the WHOLE weight matrix (128 x 128 fp32 = 64 KB) is resident
+// in LDS for the life of a persistent workgroup and the pixel operand arrives as complete 64-row x 128-deep tiles by LDS-DMA
+// (buffer form: one per-lane offset, scalar slab / tile advances, rows beyond M as zeros) into a ring of two: there is no K
+// loop to pipeline at all -- tile t + 1 lands while tile t is multiplied, ONE barrier per tile.  8 waves = 4 (16 pixel rows each)
+// x 2 (64 channels each).  Same fragment maps and per-accumulator K order as k_gemm<8>: bit-identical results.
+// ---------------------------------------------------------------------------------------------------------------------
+struct GemmWArgs {
+  const float* A; const float* Wp; float* C;
+  long long M;
+  int lda, ldc, coff, n_tiles;
+  Epilogue epi;
+};
+constexpr int W_BM = 64, W_NTHR = 512;
+constexpr unsigned W_WBYTES = 128 * 128 * 4, W_ABYTES = W_BM * 128 * 4;
+constexpr size_t W_LDS = W_WBYTES + 2 * (size_t)W_ABYTES + 128 * 4;   // weights | two pixel tiles | bias
+
+__global__ __launch_bounds__(W_NTHR, 1) void k_gemm32w(const GemmWArgs g) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem32w[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 15, q = lane >> 4;
+  const int wm = wid >> 1, wn = wid & 1;
+  const unsigned lds_b = __builtin_amdgcn_readfirstlane(lds_addr32(smem32w));
+  float* bias_l = reinterpret_cast<float*>(smem32w + W_WBYTES + 2 * W_ABYTES);
+  if (tid < 128) bias_l[tid] = g.epi.bias ? g.epi.bias[tid] : 0.f;
+  const int G = gridDim.x;
+  const unsigned pitch = (unsigned)(g.lda * 4);
+  // per-lane request offsets: lane i of a 1-KB piece = row i / 8 of the piece, physical chunk i % 8 <- logical chunk ^ ((row >> 1) & 7);
+  // every piece a wave requests starts at a row that is a multiple of 8 with the parity of the wave id: one offset per operand
+  const int rsub = lane >> 3, c0 = lane & 7;
+  const unsigned ch = (unsigned)((c0 ^ (((rsub >> 1) | ((wid & 1) << 2)) & 7)) << 4);
+  const unsigned req_w = (unsigned)(rsub * 128) + ch;
+  const unsigned req_a = (unsigned)(8 * wid + rsub) * pitch + ch;
+  {   // the weights, once: 64 pieces (slab p / 16, rows 8 (p % 16) ..), wave w takes p = w + 8 i; packed [slab][n][32] in global
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.Wp), 0, 0x7fffffffu, 0x00020000);
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      const unsigned p = (unsigned)(wid + 8 * i);
+      blds16(req_w, wrs, lds_b + p * 1024u, p * 1024u);
+    }
+  }
+  auto issue_a = [&](int t, unsigned buf) __attribute__((always_inline)) {   // pixel tile t -> ring buffer buf: 4 slabs x rows 8 wid .. + 7
+    const long long m0 = (long long)t * W_BM;
+    const unsigned rows_here = (unsigned)min((long long)W_BM, g.M - m0);
+    const __amdgpu_buffer_rsrc_t ars = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.A + m0 * g.lda), 0, rows_here * pitch, 0x00020000);
+    const unsigned dst = lds_b + W_WBYTES + buf * W_ABYTES + (unsigned)wid * 1024u;
+#pragma unroll
+    for (int s = 0; s < 4; s++) blds16(req_a, ars, dst + s * 8192u, s * 128u);
+  };
+  int t = blockIdx.x;
+  issue_a(t, 0u);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  // fragment addresses: lane (r, q) reads row (16-row tile base + r), logical chunk 4 grp + q; group 1 = byte address ^ 64
+  const unsigned sw = (unsigned)((r >> 1) & 7);
+  const unsigned fo = (unsigned)(r * 128) + (((unsigned)q ^ sw) << 4);
+  const unsigned char* wfrag = smem32w + (wn * 64) * 128;
+  const float* bl = bias_l + wn * 64 + q * 4;
+  act_dispatch(g.epi.act, g.epi.has_lab, false, [&](auto at, auto lt, auto) {
+    constexpr int ACT = decltype(at)::value, LAB = decltype(lt)::value;
+    unsigned buf = 0;
+    for (; t < g.n_tiles; t += G, buf ^= 1u) {
+      const int tn = t + G;
+      const bool more = tn < g.n_tiles;
+      if (more) issue_a(tn, buf ^ 1u);
+      __builtin_amdgcn_sched_barrier(0);
+      const unsigned char* afrag = smem32w + W_WBYTES + buf * W_ABYTES + (wm * 16) * 128;
+      f32x4 acc[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+      for (int s = 0; s < 4; s++)
+#pragma unroll
+        for (int grp = 0; grp < 2; grp++) {
+          const unsigned fg = grp ? fo ^ 64u : fo;   // (the chunk field of the address: bits 4..6)
+          const f32x4 a = *reinterpret_cast<const f32x4*>(afrag + s * 8192 + fg);
+#pragma unroll
+          for (int nt = 0; nt < 4; nt++) {
+            const f32x4 b = *reinterpret_cast<const f32x4*>(wfrag + s * 16384 + nt * 2048 + fg);
+#pragma unroll
+            for (int k = 0; k < 4; k++) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[k], a[k], acc[nt], 0, 0, 0);
+          }
+        }
+      // epilogue: bias / activation / LAB, 16-byte stores (a lane holds 4 consecutive channels of a pixel)
+      const long long m0 = (long long)t * W_BM;
+      const long long row = m0 + wm * 16 + r;
+      const bool full = m0 + W_BM <= g.M;
+      float* crow = g.C + row * g.ldc + g.coff + wn * 64 + q * 4;
+#pragma unroll
+      for (int nt = 0; nt < 4; nt++) {
+        const f32x4 bias = *reinterpret_cast<const f32x4*>(bl + nt * 16);
+        f32x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; j++) o[j] = epi_val<ACT, LAB>(acc[nt][j] + bias[j], g.epi.act, g.epi.has_lab, g.epi.lab_a, g.epi.lab_c);
+        if (full || row < g.M) *reinterpret_cast<f32x4*>(crow + nt * 16) = o;
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      // the next tile has landed (this wave's requests; the 4 stores behind them may stay in flight -- a partial tile's
+      // stores may be skipped by whole waves: then nothing is assumed)
+      if (more) {
+        if (full) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      __syncthreads();   // ... and everybody's; every wave is done with this tile's buffer
+    }
+  });
+}
+
+bool gemm_w_supported(int lda, long long M, int K, int N, int Npad16, const Epilogue& epi) {
+  static const int on = getenv("RT_GEMM_W") ? atoi(getenv("RT_GEMM_W")) : 1;   // A/B: 0 = k_gemm<8>
+  if (!on || epi.am_max || epi.residual || epi.a_scale) return false;
+  if (K != 128 || N != 128 || Npad16 != 128) return false;
+  if (lda < 128 || (lda & 3) || (long long)lda * 4 * W_BM >= (1ll << 31)) return false;
+  return M >= 65536;
+}
+
+void gemm_w(hipStream_t st, const float* A, int lda, long long M, int K, const float* Wp, int N, int Npad16, float* C, int ldc, int coff,
+            const Epilogue& epi) {
+  GemmWArgs g;
+  g.A = A; g.Wp = Wp; g.C = C; g.M = M; g.lda = lda; g.ldc = ldc; g.coff = coff; g.epi = epi;
+  g.n_tiles = (int)((M + W_BM - 1) / W_BM);
+  const int grid = std::min(g.n_tiles, stream_cus(st));
+  allow_big_lds((const void*)k_gemm32w, 160 * 1024);
+  RT_LAUNCH(k_gemm32w, dim3((unsigned)grid), dim3(W_NTHR), W_LDS, st, g);
+}
+
 bool gemm_dma_supported(int lda, long long M, int K, int N, int Npad16, const Epilogue& epi) {
   if (epi.am_max || epi.residual) return false;
   // squeeze-excite scale: 3-int row-block table (gemm_se_tile_rows() == 256), hardswish epilogue, K within the LDS scale table

@@ -818,6 +818,7 @@ void gemm(hipStream_t st, const float* A, int lda, long long M, int K, const flo
     }
     return;
   }
+  if (!g_gemm_variant && gemm_w_supported(lda, M, K, N, Npad16, epi)) { gemm_w(st, A, lda, M, K, Wp, N, Npad16, C, ldc, coff, epi); return; }
   // persistent LDS-DMA form of the 256 x 240 tile (variant 30; production for the large N = 240 / 480 layers)
   if ((v == 30 || (v == 15 && !g_gemm_variant && g_gemm_dma)) && gemm_dma_supported(lda, M, K, N, Npad16, epi)) {
     gemm_dma(st, A, lda, M, K, Wp, N, Npad16, C, ldc, coff, epi);
