@@ -531,6 +531,9 @@ __global__ __launch_bounds__(P_NTHR, 1) void k_gemm32p(const GemmPArgs g) {
 // (buffer form: one per-lane offset, scalar slab / tile advances, rows beyond M as zeros) into a ring of two: there is no K
 // loop to pipeline at all -- tile t + 1 lands while tile t is multiplied, ONE barrier per tile.  8 waves = 4 (16 pixel rows each)
 // x 2 (64 channels each).  Same fragment maps and per-accumulator K order as k_gemm<8>: bit-identical results.
+// Measured against it and removed: every wave streaming its OWN 16-row tiles through a private two-buffer ring (4 waves, no
+// workgroup barrier after the weights have landed, counted vmcnt): 0.97-0.99 ms against 0.80-0.82 -- one wave per SIMD does not
+// keep the matrix pipe fed through its own epilogue and waits; two per SIMD need 192 KB of LDS in that form.
 // ---------------------------------------------------------------------------------------------------------------------
 struct GemmWArgs {
   const float* A; const float* Wp; float* C;
