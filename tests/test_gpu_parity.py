@@ -50,7 +50,8 @@ def test_cls_net(hip_session, oracle_session, n):
 #  squeeze-excite form k_gemm32p+se and k_gemm_wide<4,...>, so the production-size kernels are compared with the oracle directly;
 #  1000 x 96: 144 rows per line at the 480-channel squeeze-excite level -- 256-row blocks that span three lines, the +se kernel's
 #  third scale slot)
-@pytest.mark.parametrize("n,w", [(1, 320), (3, 321), (2, 487), (1, 960), (12, 640), (24, 640), (1, 3648), (120, 400), (1000, 96)])
+@pytest.mark.parametrize("n,w", [(1, 320), (3, 321), (2, 487), (1, 960), (12, 640), (24, 640), (1, 3648), (120, 400), (1000, 96),
+                                 (130, 412)])  # (130, 412): 160 680 rows at the 128-channel stage = k_gemm32w with a partial last 64-row tile
 def test_rec_net(hip_session, oracle_session, n, w):
     x = np.random.default_rng(w).uniform(-1, 1, (n, 3, 48, w)).astype(np.float32)
     x[:, :, :, w // 2:] = 0.0  # zero padding like resize_norm_image
