@@ -734,7 +734,10 @@ int g_gemm_dma = getenv("RT_GEMM_DMA") ? atoi(getenv("RT_GEMM_DMA")) : 1;   // A
 // production dispatch (tools/bench_gemm.py): wide tiles once N and M are large; 0 = narrow k_gemm<NT>
 static int gemm_dispatch(long long M, int Npad16) {
   if (Npad16 % 240 == 0 && M >= 131072) return 15;  // 256 x 240 tile: halves the weight re-fetch per row
-  if (Npad16 % 240 == 0 && M >= 16384) return 10;
+  // (round 5: the 128 x 240 tile only where it fills the chip twice -- 38 k rows x 240 channels, a one-page batch, are 300
+  //  workgroups of 768 threads on 256 CUs: two rounds for 1.17 rounds of work; the narrow kernel's 600 workgroups sit four to a CU)
+  static const int mid_env = getenv("RT_GEMM_MID") ? atoi(getenv("RT_GEMM_MID")) : 1;   // A/B: 0 = the 128 x 240 tile from 16384 rows
+  if (Npad16 % 240 == 0 && M >= 16384 && (!mid_env || (M + 127) / 128 * (Npad16 / 240) >= 512)) return 10;
   // (the 128 x 128 tile, variant 8, lost to the narrow kernel once that prefetched its next K-slab: 192 x 192 at
   // 115200 rows 85 vs 65 TFLOP/s, 128 x 128 at 2.4 M rows 76 vs 72; it remains the squeeze-excite (a_scale) and CTC tile)
   return 0;  // gemm() picks the streaming kernel when K, N <= 64, else the narrow LDS kernel
