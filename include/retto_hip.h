@@ -163,11 +163,14 @@ RT_API int rt_ctc_decode(rt_session* s, const float* probs, int n, int t, int c,
 /* ---- L2: RettoSession::run over a batch of pages --------------------------------- */
 #define RT_MEM_HOST 0
 #define RT_MEM_DEVICE 1
+#define RT_MEM_HOST_MAPS_DEVICE 2   /* pages in host memory (what RettoSession::run is handed, session.rs:108-131), override maps in HBM */
 /* rgb[i]: RGB8 HWC page i (hs[i] x ws[i]); mem says where the pixels live.
  * det_map_override (may be NULL, entries may be NULL): f32 [H,W] probability map at the
- * det input size of page i, same memory space as the pages, used INSTEAD of the det
- * network's output when building boxes (the network still runs).  This is the hook the
- * synthetic-weights benchmark and the teacher-forced parity tests use. */
+ * det input size of page i, in the memory space of the pages (RT_MEM_HOST_MAPS_DEVICE: in
+ * device memory beside host pages), used INSTEAD of the det network's output when building
+ * boxes (the network still runs).  This is the hook the synthetic-weights benchmark and the
+ * teacher-forced parity tests use; a deployment has no such maps, so a host-fed measurement
+ * keeps them in HBM and sends only the pages over PCIe. */
 RT_API int rt_run_batch(rt_session* s, const uint8_t* const* rgb, const int* hs, const int* ws, int n_pages,
                         int mem, const float* const* det_map_override, rt_results** out);
 /* RettoSession::run_stream (session.rs:133-143): as rt_run_batch, and cb(user, page, stage, json) is called for
@@ -305,6 +308,10 @@ RT_API int rt_debug_conv16(rt_session* s, const float* x, int n, int cin, int h,
 /* times nn::gemm (M x K x N, random data) over `iters` launches on the session's stream and
  * returns the average ms and the max |diff| against variant 0 */
 RT_API int rt_bench_gemm(rt_session* s, long long M, int K, int N, int variant, int iters, float* ms_out, float* maxdiff_out);
+/* Error of one nn::gemm variant against an fp64 product on operands with full 24-bit significands (bias 0): out4 = {max |err|,
+ * rms err, max |ref|, rms ref} over `rows` rows from the start, the middle and the end of the M rows.  variant 1 = narrow fp32-MFMA
+ * kernel, 30 = k_gemm32p (fp32 MFMA), 40 = split-bf16 (three bf16 planes per operand, six bf16 MFMAs per product, fp32 accumulate). */
+RT_API int rt_bench_gemm_err(rt_session* s, long long M, int K, int N, int variant, int rows, int act, unsigned seed, double* out4);
 /* times the fused thin LCNetV3 block (3x3 depthwise -> 1x1 conv; n images of h x w, random data).  form: 0 = k_lc_thin
  * (workgroup-staged; the unfused depthwise + GEMM pair where it has no instance), 1 = k_lc_wave (direct loads, stride 1 only),
  * 3 = k_lc_lds (production), 5 = k_lc_lds incl. the opt-in 128 -> 128 split.  stride: 1, 2, or 21 = (2, 1).  Returns the average

@@ -18,7 +18,7 @@ from typing import Callable, List, Optional, Sequence, Union
 import numpy as np
 
 from . import _lib
-from ._lib import Config, ModelSource, RT_MEM_DEVICE, RT_MEM_HOST
+from ._lib import Config, ModelSource, RT_MEM_DEVICE, RT_MEM_HOST, RT_MEM_HOST_MAPS_DEVICE
 
 
 # ---- errors (error.rs:2-21) ------------------------------------------------------------

@@ -77,6 +77,7 @@ struct DevBufs {
   template <typename T> T* alloc(size_t n) { void* q = nullptr; RT_HIP_CHECK(hipMalloc(&q, std::max<size_t>(n, 1) * sizeof(T))); p.push_back(q); return (T*)q; }
   ~DevBufs() { for (void* q : p) (void)hipFree(q); }
 };
+struct ForgetSplit { const float* w; ~ForgetSplit() { nn::gemm_split_forget(w); } };
 struct Events { hipEvent_t a = nullptr, b = nullptr; ~Events() { if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); } };
 }  // namespace
 
@@ -221,21 +222,21 @@ int rt_ctc_decode(rt_session* s, const float* probs, int n, int t, int c, int32_
 int rt_run_batch(rt_session* s, const uint8_t* const* rgb, const int* hs, const int* ws, int n_pages, int mem,
                  const float* const* det_map_override, rt_results** out) {
   RT_REQUIRE(s && out && n_pages >= 0 && (n_pages == 0 || (rgb && hs && ws)), s, "rt_run_batch: bad argument");
-  RT_REQUIRE(mem == RT_MEM_HOST || mem == RT_MEM_DEVICE, s, "rt_run_batch: bad mem kind");
+  RT_REQUIRE(mem == RT_MEM_HOST || mem == RT_MEM_DEVICE || mem == RT_MEM_HOST_MAPS_DEVICE, s, "rt_run_batch: bad mem kind");
   *out = nullptr;
   return guarded(s, [&] { *out = s->run_batch(rgb, hs, ws, n_pages, mem, det_map_override); });
 }
 int rt_run_batch_stream(rt_session* s, const uint8_t* const* rgb, const int* hs, const int* ws, int n_pages, int mem,
                         const float* const* det_map_override, rt_stage_callback cb, void* user, rt_results** out) {
   RT_REQUIRE(s && out && cb && n_pages >= 0 && (n_pages == 0 || (rgb && hs && ws)), s, "rt_run_batch_stream: bad argument");
-  RT_REQUIRE(mem == RT_MEM_HOST || mem == RT_MEM_DEVICE, s, "rt_run_batch_stream: bad mem kind");
+  RT_REQUIRE(mem == RT_MEM_HOST || mem == RT_MEM_DEVICE || mem == RT_MEM_HOST_MAPS_DEVICE, s, "rt_run_batch_stream: bad mem kind");
   *out = nullptr;
   return guarded(s, [&] { *out = s->run_batch(rgb, hs, ws, n_pages, mem, det_map_override, cb, user); });
 }
 int rt_submit_batch(rt_session* s, const uint8_t* const* rgb, const int* hs, const int* ws, int n_pages, int mem,
                     const float* const* det_map_override, rt_ticket** out) {
   RT_REQUIRE(s && out && n_pages >= 0 && (n_pages == 0 || (rgb && hs && ws)), s, "rt_submit_batch: bad argument");
-  RT_REQUIRE(mem == RT_MEM_HOST || mem == RT_MEM_DEVICE, s, "rt_submit_batch: bad mem kind");
+  RT_REQUIRE(mem == RT_MEM_HOST || mem == RT_MEM_DEVICE || mem == RT_MEM_HOST_MAPS_DEVICE, s, "rt_submit_batch: bad mem kind");
   RT_REQUIRE(s->inflight.load() < RT_MAX_INFLIGHT, s, "rt_submit_batch: too many batches in flight (RT_MAX_INFLIGHT)");
   *out = nullptr;
   return guarded<true>(s, [&] { *out = s->submit_batch(rgb, hs, ws, n_pages, mem, det_map_override); });
@@ -551,14 +552,15 @@ RT_API int rt_bench_gemm(rt_session* s, long long M, int K, int N, int variant, 
     // operand pitches as the networks have them (chan_pitch: 240 -> 256), padding channels zero
     const int Kp = round_up(K, 4), lda = chan_pitch(K), Np = round_up(N, 16), ldc = chan_pitch(N), nkc = (Kp + nn::KC - 1) / nn::KC;
     std::vector<float> ha((size_t)M * lda, 0.f), hw((size_t)nkc * Np * nn::KC, 0.f), hb(Np, 0.1f);
-    uint32_t st = 12345;
-    auto rnd = [&]() { st = st * 1664525u + 1013904223u; return ((st >> 8) & 0xffff) / 32768.0f - 1.0f; };
+    uint64_t st = 0x2545F4914F6CDD1Dull;   // (xorshift64: 24 live significand bits per value -- the matrix pipe's clock depends on the data)
+    auto rnd = [&]() { st ^= st << 13; st ^= st >> 7; st ^= st << 17; return (float)((double)(int64_t)(st >> 11) * (1.0 / 4503599627370496.0)) - 1.0f; };
     for (long long m = 0; m < M; m++) for (int k = 0; k < K; k++) ha[(size_t)m * lda + k] = rnd();
     for (int k = 0; k < K; k++) for (int n = 0; n < N; n++) hw[((size_t)(k / nn::KC) * Np + n) * nn::KC + k % nn::KC] = rnd() * 0.1f;
     DevBufs bufs;
     RestoreInt keep_variant(nn::g_gemm_variant);
     float *dA = bufs.alloc<float>(ha.size()), *dW = bufs.alloc<float>(hw.size()), *dB = bufs.alloc<float>(hb.size()),
           *dC = bufs.alloc<float>((size_t)M * ldc), *dC0 = bufs.alloc<float>((size_t)M * ldc);
+    ForgetSplit forget{dW};
     RT_HIP_CHECK(hipMemset(dC, 0, (size_t)M * ldc * 4)); RT_HIP_CHECK(hipMemset(dC0, 0, (size_t)M * ldc * 4));
     RT_HIP_CHECK(hipMemcpy(dA, ha.data(), ha.size() * 4, hipMemcpyHostToDevice));
     RT_HIP_CHECK(hipMemcpy(dW, hw.data(), hw.size() * 4, hipMemcpyHostToDevice));
@@ -585,6 +587,64 @@ RT_API int rt_bench_gemm(rt_session* s, long long M, int K, int N, int variant, 
       }
       *maxdiff_out = md;
     }
+  });
+}
+
+// Error of one nn::gemm variant against an fp64 product (round 6: the evidence behind the split-bf16 form): random operands with
+// FULL 24-bit significands (a few binades each), bias 0, no activation, so the output is the bare product; the first `rows` rows are
+// compared with sum_k (double)a * (double)w on the host.  out4 = {max |err|, rms err, max |ref|, rms ref}; variant as rt_bench_gemm
+// (1 = narrow fp32-MFMA kernel, 30 = k_gemm32p, 40 = split-bf16).  seed != 0 reseeds the operands; act = an Act value.
+RT_API int rt_bench_gemm_err(rt_session* s, long long M, int K, int N, int variant, int rows, int act, unsigned seed, double* out4) {
+  RT_REQUIRE(s && out4 && M > 0 && K > 0 && N > 0 && rows > 0, s, "rt_bench_gemm_err: bad argument");
+  return guarded(s, [&] {
+    RT_HIP_CHECK(hipSetDevice(s->device));
+    const int Kp = round_up(K, 4), lda = chan_pitch(K), Np = round_up(N, 16), ldc = chan_pitch(N), nkc = (Kp + nn::KC - 1) / nn::KC;
+    std::vector<float> ha((size_t)M * lda, 0.f), hw((size_t)nkc * Np * nn::KC, 0.f), hwd((size_t)K * N), hb(Np, 0.f);
+    uint64_t st = 0x9E3779B97F4A7C15ull ^ ((uint64_t)(seed ? seed : 1u) * 0xD1B54A32D192ED03ull);
+    auto next = [&]() { st ^= st << 13; st ^= st >> 7; st ^= st << 17; return st; };
+    // sign * (1 + 23 random bits) * 2^e, e in [-4, 0] (pixels) / [-6, -2] (weights): every significand bit is live
+    auto rnd = [&](int e_hi) {
+      const uint64_t v = next();
+      const uint32_t bits = (uint32_t)((v >> 63) << 31) | (uint32_t)((127 + e_hi - (int)((v >> 40) % 5)) << 23) | (uint32_t)(v & 0x7fffff);
+      float f; memcpy(&f, &bits, 4); return f;
+    };
+    for (long long m = 0; m < M; m++) for (int k = 0; k < K; k++) ha[(size_t)m * lda + k] = rnd(0);
+    for (int k = 0; k < K; k++) for (int n = 0; n < N; n++) { const float w = rnd(-2); hwd[(size_t)k * N + n] = w; hw[((size_t)(k / nn::KC) * Np + n) * nn::KC + k % nn::KC] = w; }
+    DevBufs bufs;
+    RestoreInt keep_variant(nn::g_gemm_variant);
+    float *dA = bufs.alloc<float>(ha.size()), *dW = bufs.alloc<float>(hw.size()), *dB = bufs.alloc<float>(hb.size()), *dC = bufs.alloc<float>((size_t)M * ldc);
+    ForgetSplit forget{dW};
+    RT_HIP_CHECK(hipMemset(dC, 0, (size_t)M * ldc * 4));
+    RT_HIP_CHECK(hipMemcpy(dA, ha.data(), ha.size() * 4, hipMemcpyHostToDevice));
+    RT_HIP_CHECK(hipMemcpy(dW, hw.data(), hw.size() * 4, hipMemcpyHostToDevice));
+    RT_HIP_CHECK(hipMemcpy(dB, hb.data(), hb.size() * 4, hipMemcpyHostToDevice));
+    Epilogue e; e.bias = dB; e.act = act;
+    nn::g_gemm_variant = variant;
+    nn::gemm(s->st, dA, lda, M, Kp, dW, N, Np, dC, ldc, 0, e);
+    RT_HIP_CHECK(hipStreamSynchronize(s->st));
+    // rows from the start, the middle and the end (the last row block is the partial one)
+    const long long R = std::min<long long>(rows, M);
+    std::vector<float> hc((size_t)R * ldc);
+    double max_err = 0, sq_err = 0, max_ref = 0, sq_ref = 0; long long cnt = 0;
+    for (int part = 0; part < 3; part++) {
+      const long long r0 = part == 0 ? 0 : part == 1 ? std::max<long long>(0, M / 2 - R / 2) : M - R;
+      RT_HIP_CHECK(hipMemcpy(hc.data(), dC + r0 * ldc, hc.size() * 4, hipMemcpyDeviceToHost));
+      std::vector<double> ref(N);
+      for (long long m = 0; m < R; m++) {
+        std::fill(ref.begin(), ref.end(), 0.0);
+        const float* a = &ha[(size_t)(r0 + m) * lda];
+        for (int k = 0; k < K; k++) { const double av = a[k]; const float* w = &hwd[(size_t)k * N]; for (int n = 0; n < N; n++) ref[n] += av * (double)w[n]; }
+        for (int n = 0; n < N; n++) {
+          double rv = ref[n];
+          if (act == ACT_HSWISH) rv = rv * std::min(std::max(rv + 3.0, 0.0), 6.0) / 6.0;
+          else if (act == ACT_RELU) rv = std::max(rv, 0.0);
+          const double d = std::fabs((double)hc[(size_t)m * ldc + n] - rv);
+          if (!(d == d)) max_err = INFINITY;
+          max_err = std::max(max_err, d); sq_err += d * d; max_ref = std::max(max_ref, std::fabs(rv)); sq_ref += rv * rv; cnt++;
+        }
+      }
+    }
+    out4[0] = max_err; out4[1] = std::sqrt(sq_err / cnt); out4[2] = max_ref; out4[3] = std::sqrt(sq_ref / cnt);
   });
 }
 

@@ -16,12 +16,19 @@ const char* gemm_pw_label(long long M, int Npad16, bool a_scale = false, int se_
 // Persistent LDS-DMA form of the 256 x 240 tile (nn_gemm_dma.hip): N a multiple of 240, K whole 16-deep groups, plain
 // bias / activation / LAB epilogue.  gemm() takes it for the large 240- / 480-channel layers.
 // k_gemm32w: K = N = 128 with the weights resident in LDS (nn_gemm_dma.hip)
-bool gemm_w_supported(int lda, long long M, int K, int N, int Npad16, const Epilogue& epi);
+bool gemm_w_supported(int lda, long long M, int K, int N, int Npad16, const Epilogue& epi, int ldc = 0, int coff = 0);
 void gemm_w(hipStream_t st, const float* A, int lda, long long M, int K, const float* Wp, int N, int Npad16, float* C, int ldc, int coff,
             const Epilogue& epi);
 bool gemm_dma_supported(int lda, long long M, int K, int N, int Npad16, const Epilogue& epi);
 void gemm_dma(hipStream_t st, const float* A, int lda, long long M, int K, const float* Wp, int N, int Npad16, float* C,
               int ldc, int coff, const Epilogue& epi);
+// Split-bf16 form of the same layers (nn_gemm_split.hip): three bf16 planes per operand, six v_mfma_f32_16x16x32_bf16 products
+// per fp32 product, fp32 accumulation.  Opt-in: g_gemm_split (RT_GEMM_SPLIT=1, rt_debug_set_variants flag bit 12).
+extern int g_gemm_split;
+bool gemm_split_supported(int lda, long long M, int K, int N, int Npad16, const Epilogue& epi);
+void gemm_split(hipStream_t st, const float* A, int lda, long long M, int K, const float* Wp, int N, int Npad16, float* C,
+                int ldc, int coff, const Epilogue& epi);
+void gemm_split_forget(const float* Wp);   // drops the cached split planes of a weight pack (before its memory is freed / reused)
 void set_dw_xcd(int v);  // A/B: XCD-aware block order of the depthwise kernel (default on)
 extern int g_dw_wide_slab_min, g_dw_wide3_min, g_dw_wide_lp;
 extern int g_dw_variant;    // same for dwconv

@@ -168,8 +168,12 @@ __global__ __launch_bounds__(P_NTHR, 1) void k_gemm32p(const GemmPArgs g) {
       // valid row: rows beyond M arrive as zeros (never stored) without the per-lane clamp.  ~8 VALU instructions per slab and
       // wave instead of ~30 -- an fp32 MFMA loop pays each of them in MFMA time.
       {
-        const unsigned rows_here = (unsigned)min((long long)P_BM, g.M - m0);
-        const __amdgpu_buffer_rsrc_t ars = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.A + m0 * g.lda), 0, rows_here * pitch, 0x00020000);
+        // (the plain instantiations re-derive the per-lane offset WITHOUT the wave's row base 8 wid: that base goes into the
+        //  descriptor -- start and length -- not into the scalar offset, which the range check of a raw buffer does not see:
+        //  rows beyond M must come back as zeros for every wave)
+        const int wrow = REQ_HELD ? 0 : 8 * wid;
+        const unsigned rows_here = (unsigned)max(0ll, min((long long)P_BM, g.M - m0) - wrow);
+        const __amdgpu_buffer_rsrc_t ars = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.A + (m0 + (rows_here ? wrow : 0)) * g.lda), 0, rows_here * pitch, 0x00020000);
         // (weights: the descriptor starts 8 pieces BEFORE the column block's rows -- piece 2 of the waves 8..11 is weight piece
         //  wid - 8 -- so that every scalar offset is >= 0; nothing below the first weight row is ever addressed)
         const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.Wp + (long long)it_cb * P_BN * KC - 8 * 256), 0, 0x7fffffffu, 0x00020000);
@@ -182,7 +186,7 @@ __global__ __launch_bounds__(P_NTHR, 1) void k_gemm32p(const GemmPArgs g) {
           asm volatile("" : "+v"(ln_));
           const unsigned ch_ = (unsigned)(((ln_ & 7) ^ (((ln_ >> 4) & 3) | ((wid & 1) << 2))) << 4);
           req_a = (unsigned)(ln_ >> 3) * pitch + ch_; req_w = (unsigned)((ln_ >> 3) * 128) + ch_;
-          sa += (unsigned)(8 * wid) * pitch; swk += (unsigned)wid * 1024u;
+          swk += (unsigned)wid * 1024u;
         }
         blds16(req_a, ars, dst, sa);
         blds16(req_a + 96u * pitch, ars, dst + 1 * (P_NW * 1024), sa);
@@ -635,11 +639,12 @@ __global__ __launch_bounds__(W_NTHR, 1) void k_gemm32w(const GemmWArgs g) {
   });
 }
 
-bool gemm_w_supported(int lda, long long M, int K, int N, int Npad16, const Epilogue& epi) {
+bool gemm_w_supported(int lda, long long M, int K, int N, int Npad16, const Epilogue& epi, int ldc, int coff) {
   static const int on = getenv("RT_GEMM_W") ? atoi(getenv("RT_GEMM_W")) : 1;   // A/B: 0 = k_gemm<8>
   if (!on || epi.am_max || epi.residual || epi.a_scale) return false;
   if (K != 128 || N != 128 || Npad16 != 128) return false;
   if (lda < 128 || (lda & 3) || (long long)lda * 4 * W_BM >= (1ll << 31)) return false;
+  if ((ldc & 3) || (coff & 3)) return false;   // 16-byte stores of four consecutive channels
   return M >= 65536;
 }
 

@@ -821,7 +821,12 @@ void gemm(hipStream_t st, const float* A, int lda, long long M, int K, const flo
     }
     return;
   }
-  if (!g_gemm_variant && gemm_w_supported(lda, M, K, N, Npad16, epi)) { gemm_w(st, A, lda, M, K, Wp, N, Npad16, C, ldc, coff, epi); return; }
+  if ((v == 40 || (!g_gemm_variant && g_gemm_split)) && gemm_split_supported(lda, M, K, N, Npad16, epi)) {
+    gemm_split(st, A, lda, M, K, Wp, N, Npad16, C, ldc, coff, epi);
+    return;
+  }
+  if (v == 40) v = 30;
+  if (!g_gemm_variant && gemm_w_supported(lda, M, K, N, Npad16, epi, ldc, coff)) { gemm_w(st, A, lda, M, K, Wp, N, Npad16, C, ldc, coff, epi); return; }
   // persistent LDS-DMA form of the 256 x 240 tile (variant 30; production for the large N = 240 / 480 layers)
   if ((v == 30 || (v == 15 && !g_gemm_variant && g_gemm_dma)) && gemm_dma_supported(lda, M, K, N, Npad16, epi)) {
     gemm_dma(st, A, lda, M, K, Wp, N, Npad16, C, ldc, coff, epi);
@@ -1272,7 +1277,8 @@ void conv13_flat(hipStream_t st, const float* x, int ldx, long long rows, const 
   int NT = ntiles >= 4 ? 4 : ntiles;
   // few tokens (one page: 13 tiles of 128 tokens walking 45 slabs each, 96 us): a column tile per workgroup until there is a
   // workgroup per CU -- the column tiles are independent: same bits (as the narrow GEMM's launch rule)
-  while (NT > 1 && (rows + 127) / 128 * ((ntiles + NT - 1) / NT) < stream_cus(st)) NT = (NT + 1) / 2;
+  const int cus13 = stream_cus(st);
+  while (NT > 1 && (rows + 127) / 128 * ((ntiles + NT - 1) / NT) < cus13) NT = (NT + 1) / 2;
   dim3 grid((unsigned)((rows + 127) / 128), (unsigned)((ntiles + NT - 1) / NT));
   switch (NT) {
     case 1: RT_LAUNCH((k_conv13_flat<1>), grid, dim3(256), 0, st, x, ldx, rows, flags, Cin, Wp, N, Npad16, y, ldy, epi); break;
@@ -2625,7 +2631,8 @@ __global__ __launch_bounds__(64) void k_attention(const float* __restrict__ qkv,
 // stage a 64-key tile of K and V for ALL heads with 16-byte loads of whole rows (the three projections of a token are 1440
 // contiguous bytes), re-laid per head into 16-float LDS rows, and a thread owns one (query, head) pair: a key costs 8
 // ds_read_b128 (lanes of a wave are consecutive queries of one head: broadcast reads) instead of 30 ds_read_b32.  Same keys in
-// the same order through the same online-softmax recurrence: bit-identical to k_attention.
+// the same order through the same online-softmax recurrence; exp by v_exp_f32 (__expf) where k_attention calls expf: equal to
+// ~2 ulp of the exponentials, NOT bit-identical (RT_ATT_LINE=0/1 is an fp32-tolerance A/B).
 template <int HD>
 __global__ __launch_bounds__(256) void k_attention_line(const float* __restrict__ qkv, const ImgGeom* __restrict__ geom,
                                                         int heads, float* __restrict__ out) {

@@ -5,6 +5,7 @@
 
 #include <cstdio>
 #include <cstring>
+#include <atomic>
 #include <map>
 #include <mutex>
 #include <set>
@@ -46,10 +47,24 @@ std::mutex g_part_mu;
 std::map<std::pair<int, hipStream_t>, int> g_stream_cus;
 std::map<int, int> g_dev_cus;
 }  // namespace
+static int stream_cus_locked(int dev, hipStream_t st);
 
+// (on the launch path of every narrow gemm(), gemm_w, gemm_dma: the last answer is kept per thread -- a lane thread launches on
+//  one stream of one device -- so the process-wide mutex is met once per (thread, stream), not per launch; forget_stream bumps
+//  the epoch that invalidates every thread's copy)
+static std::atomic<unsigned> g_part_epoch{1};
 int stream_cus(hipStream_t st) {
   int dev = 0;
   RT_HIP_CHECK(hipGetDevice(&dev));
+  struct Seen { unsigned epoch = 0; int dev = -1; hipStream_t st = nullptr; int cus = 0; };
+  static thread_local Seen seen;
+  const unsigned ep = g_part_epoch.load(std::memory_order_acquire);
+  if (seen.epoch == ep && seen.dev == dev && seen.st == st) return seen.cus;
+  const int c = stream_cus_locked(dev, st);
+  seen = Seen{ep, dev, st, c};
+  return c;
+}
+int stream_cus_locked(int dev, hipStream_t st) {
   std::lock_guard<std::mutex> lk(g_part_mu);
   auto it = g_stream_cus.find({dev, st});
   if (it != g_stream_cus.end()) return it->second;
@@ -66,6 +81,7 @@ void forget_stream(hipStream_t st) {
   if (hipGetDevice(&dev) != hipSuccess) return;
   std::lock_guard<std::mutex> lk(g_part_mu);
   g_stream_cus.erase({dev, st});
+  g_part_epoch.fetch_add(1, std::memory_order_release);
 }
 hipStream_t partition_stream(int part, int parts, int* cus_out, std::vector<unsigned>* cu_ids) {
   int dev = 0;
@@ -104,6 +120,7 @@ hipStream_t partition_stream(int part, int parts, int* cus_out, std::vector<unsi
   {
     std::lock_guard<std::mutex> lk(g_part_mu);
     g_stream_cus[{dev, st}] = 8 * (k1 - k0);
+    g_part_epoch.fetch_add(1, std::memory_order_release);   // (a recycled stream handle must not meet a thread's stale answer)
   }
   if (cus_out) *cus_out = 8 * (k1 - k0);
   return st;

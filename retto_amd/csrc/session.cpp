@@ -177,7 +177,7 @@ void rt_session::begin_call() {
   (void)hipGetLastError();   // HIP's last error is sticky per host thread: a failure of the PREVIOUS call on this thread (a refused
                              // hipMalloc, say) must not be what the first RT_LAUNCH of this call reports
   if (failed) { arena.abandon_pass(); scratch.abandon_pass(); dbws.abandon_pass(); failed = false; }
-  arena.reset(); scratch.reset(); pinned.reset();
+  arena.reset(); scratch.reset(); pinned.reset(); dbws.reset();   // (dbws too: its mark below must see the previous pass folded in)
   arena.mark_call(); scratch.mark_call(); dbws.mark_call();
   // (last_error belongs to the API caller's thread -- api.cpp guarded(); lane threads run this function and never touch it)
 }
@@ -363,7 +363,6 @@ void rt_session::det_postprocess(const float* pred, int h, int w, int ori_h, int
   float* d = arena.alloc<float>((size_t)h * w);
   RT_HIP_CHECK(hipMemcpyAsync(d, pred, (size_t)h * w * 4, hipMemcpyHostToDevice, st));
   const int mb = max_boxes_of(cfg);
-  dbws.reset();
   void* ws = dbws.alloc_bytes(pp::db_workspace_bytes(h, w, mb));
   pp::DbBox* db = arena.alloc<pp::DbBox>(mb);
   int* cnt = arena.alloc<int>(2);
@@ -543,9 +542,10 @@ rt_results* rt_session::run_pages(const uint8_t* const* rgb, const int* hs, cons
   // a one-page call is the reference's real mode (retto-cli/src/main.rs:80-86): it polls through its waits; a multi-page batch
   // is a throughput run whose lane threads must not hold a core each (8 ranks x 3 lanes on a 16-CPU pod)
   struct SpinScope { int& r; int old; ~SpinScope() { r = old; } } spin_scope{spin_us, spin_us};
-  spin_us = n_pages <= 1 ? 5000 : 50;
+  // (a lane worker's one-page part -- a batch of <= lanes pages, or several one-page submissions in flight -- is a throughput run
+  //  too: it polls for a bounded 250 us per wait, not 5 ms)
+  spin_us = n_pages > 1 ? 50 : on_lane_worker ? 250 : 5000;
   begin_call();
-  dbws.reset();
   tick0.lap("begin_call + arena reset");
   std::unique_ptr<rt_results> res(new rt_results());
   res->pages.resize((size_t)n_pages);
@@ -563,7 +563,7 @@ rt_results* rt_session::run_pages(const uint8_t* const* rgb, const int* hs, cons
     p.ori_h = hs[i]; p.ori_w = ws[i];
     if (hs[i] <= 0 || ws[i] <= 0 || rgb[i] == nullptr) throw RtError(RT_ERR_IMAGE, "empty page");
     const uint8_t* raw = rgb[i];
-    if (mem == RT_MEM_HOST) {
+    if (mem != RT_MEM_DEVICE) {   // (RT_MEM_HOST, RT_MEM_HOST_MAPS_DEVICE: the pages cross PCIe)
       uint8_t* d = arena.alloc<uint8_t>((size_t)hs[i] * ws[i] * 3);
       RT_HIP_CHECK(hipMemcpyAsync(d, rgb[i], (size_t)hs[i] * ws[i] * 3, hipMemcpyHostToDevice, st));
       raw = d;
@@ -978,6 +978,7 @@ rt_ticket* rt_session::submit_batch(const uint8_t* const* rgb, const int* hs, co
       // a lane inside a submitted batch works on its own CU partition (every call ends with its stream drained, so the lane's
       // arenas and pinned staging can change streams between calls)
       s->st = (s->st_part && use_parts) ? s->st_part : s->st_full;
+      s->on_lane_worker = true;
       try {
         tp->parts[l] = s->run_pages(tp->rgb.data() + f0, tp->hs.data() + f0, tp->ws.data() + f0, f1 - f0, tp->mem,
                                     tp->maps.empty() ? nullptr : tp->maps.data() + f0);
@@ -990,7 +991,7 @@ rt_ticket* rt_session::submit_batch(const uint8_t* const* rgb, const int* hs, co
         (void)hipGetLastError();
       }
       s->stage_cb = nullptr; s->stage_mu = nullptr;   // the callback never outlives the batch
-      s->st = s->st_full;
+      s->st = s->st_full; s->on_lane_worker = false;
       // notify while holding the mutex: rt_wait_batch owns the ticket and deletes it as soon as it sees remaining == 0, so
       // nothing of *tp may be touched once the decrement is visible outside the lock
       { std::lock_guard<std::mutex> lk(tp->mu); tp->remaining--; tp->cv.notify_all(); }

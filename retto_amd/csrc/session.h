@@ -101,6 +101,7 @@ struct rt_session {
   void emit_stage(int page, int stage, const rt_results::Page& P);
 
   rt::RunCtx ctx(rt::Arena* a) { return rt::RunCtx{st, a, &pinned, &prof}; }
+  bool on_lane_worker = false;    // set by a lane's worker thread around run_pages (submitted batches): bounded polling there
   int spin_us = 5000;              // sync(): how long to poll before sleeping; run_pages drops it to 50 for multi-page batches
   void begin_call();
   void sync();

@@ -571,27 +571,57 @@ def test_c3_full_size_properties(hip_session):
 
 
 def test_c4_mixed_sizes_full_size_properties(hip_session, oracle_session):
-    """BASELINE config C4 at its real page sizes (640^2 ... 2480 x 3508, the largest taking the session size limit a2),
-    32 planted lines per page, 18 pages in one batch over 3 lanes: every page equals the oracle fed by the HIP worker in
-    the reference's batches of 6 (boxes, labels, token ids bit-exact; scores to fp32 tolerance), and a page run alone
-    gives the same result as inside the batch."""
+    """BASELINE config C4 at its real page sizes (640^2 ... 2480 x 3508, the largest taking the session size limit a2) and at
+    its per-GPU share (256 pages / 8 GPUs = 32 pages in one batch over the session's lanes), 32 planted lines per page: the pages
+    checked equal the oracle fed by the HIP worker in the reference's batches of 6 (boxes, labels, token ids bit-exact; scores to
+    fp32 tolerance), every page has its 32 boxes, and a page run alone gives the same result as inside the batch."""
     sizes = [(640, 640), (960, 960), (720, 1280), (1080, 1920), (1754, 1240), (3508, 2480)]
-    specs = [(h, w, 32, 300 + 7 * i) for i, (h, w) in enumerate(sizes * 3)]
+    specs = [(h, w, 32, 300 + 7 * i) for i, (h, w) in enumerate((sizes * 6)[:32])]
     pages, maps = zip(*[_planted_for(h, w, L, s) for h, w, L, s in specs])
     res = hip_session.run_batch(list(pages), det_map_override=list(maps))
+    assert len(res) == 32 and all(len(r.det_result) == 32 and len(r.rec_result) == 32 for r in res)
     _teacher_forced(oracle_session, hip_session)
-    for j in (0, 3, 5, 8, 16, 17):
+    for j in (0, 3, 5, 8, 16, 17, 29, 31):
         o = oracle_session.run(pages[j], det_map_override=maps[j])
         assert len(o.det_boxes) == 32
         _assert_page_equal(res[j], o)
         np.testing.assert_allclose([g.score for g in res[j].rec_result], o.rec_scores, rtol=1e-4, equal_nan=True)
         np.testing.assert_allclose([c.label.score for c in res[j].cls_result], o.cls_scores, atol=1e-5)
-    for j in (5, 10):
+    for j in (5, 10, 30):
         alone = hip_session.run_batch([pages[j]], det_map_override=[maps[j]])[0]
         assert np.array_equal(np.stack([d.boxes.as_array() for d in alone.det_result]),
                               np.stack([d.boxes.as_array() for d in res[j].det_result]))
         assert [(g.text, g.score) for g in alone.rec_result] == [(g.text, g.score) for g in res[j].rec_result]
         assert [(c.label.label, c.label.score) for c in alone.cls_result] == [(c.label.label, c.label.score) for c in res[j].cls_result]
+
+
+def test_reference_large_image_scenario(hip_session, oracle_session):
+    """session.rs:231-255 restated (`test_large_image`, the regression test of the reference's commit 7fc4127b): ONE 7680 x 4320
+    page -- the max_side_len path of resize_both: 7680 x 4320 -> 1984 x 1120 (image_helper.rs:106-148), which is also the det
+    input -- with a 300-pixel-high text blob in the bottom-right corner (the reference renders its text at (0, 0) and rotates the
+    page by 180 degrees).  Through rt_run_batch: boxes, label and token ids equal the oracle's (bit-exact), and the first box's
+    bottom-right corner lies within 100 px of (7680, 4320) -- the reference's own assertion."""
+    H, W = 4320, 7680
+    page = np.zeros((H, W, 3), np.uint8)
+    x0, y0, x1, y1 = W - 1560, H - 330, W - 20, H - 20
+    page[y0:y1, x0:x1] = 255
+    # five glyph-like gaps so that the crop is not one flat rectangle
+    for k in range(1, 5):
+        page[y0:y1, x0 + k * 308 - 12:x0 + k * 308 + 12] = 0
+    plan = R.resize_both_plan(H, W)
+    assert plan and tuple(plan[-1]) == (1120, 1984)
+    dh, dw = R.resize_either_dims(*plan[-1])
+    assert (dh, dw) == (1120, 1984)
+    m = workload.planted_map(dh, dw, H, W, [(x0, y0, x1, y1)])
+    r = hip_session.run_batch([page], det_map_override=[m])[0]
+    assert len(r.det_result) == 1
+    br = r.det_result[0].boxes.br()
+    assert np.hypot(br.x - W, br.y - H) < 100
+    _teacher_forced(oracle_session, hip_session)
+    o = oracle_session.run(page, det_map_override=m)
+    _assert_page_equal(r, o)
+    assert r.cls_result[0].label.label in (0, 180)
+    np.testing.assert_allclose([g.score for g in r.rec_result], o.rec_scores, rtol=1e-4, equal_nan=True)
 
 
 def test_extreme_line_shapes(hip_session, oracle_session):
@@ -972,5 +1002,47 @@ def test_submit_wait_failed_batch_does_not_poison_the_session():
         lib.rt_results_free(r)
         again = sess.run_batch(good, det_map_override=gmaps)
         assert [len(p.det_result) for p in again] == [len(p.det_result) for p in ref]
+    finally:
+        sess.close()
+
+
+def test_submit_ahead_at_the_cap_with_a_failing_submission():
+    """C2's default depth: RT_MAX_INFLIGHT (4) one-page submissions in flight, the page of the SECOND one is empty (ImageError on
+    the lane that gets it).  Its ticket returns that error; the submissions behind it (slots 3 and 4) complete with the results
+    of a synchronous call; a fifth submission while four are in flight is refused without disturbing them; the cap is not
+    leaked (four more submissions go through afterwards)."""
+    sess = retto_amd.RettoSession(retto_amd.synthetic_session_config(0))
+    try:
+        lib = sess._hd.lib
+        pages, maps = [], []
+        for i in range(4):
+            page, rects = workload.planted_page(320, 480, 3, seed=90 + i)
+            dh, dw = R.resize_either_dims(320, 480)
+            pages.append(page); maps.append(workload.planted_map(dh, dw, 320, 480, rects))
+        ref = [sess.run_batch([pages[i]], det_map_override=[maps[i]])[0] for i in range(4)]
+
+        def submit(i, h=None):
+            return sess.submit_batch_raw([pages[i]], [pages[i].shape[0] if h is None else h], [pages[i].shape[1]], retto_amd.RT_MEM_HOST,
+                                         None if h == 0 else [maps[i]])
+
+        def check(r, i):
+            n = lib.rt_results_count(r, 0)
+            assert n == len(ref[i].det_result) > 0
+            assert np.array_equal(np.ctypeslib.as_array(lib.rt_results_boxes(r, 0), (n, 8)),
+                                  np.stack([d.boxes.as_array().reshape(8) for d in ref[i].det_result]))
+            lib.rt_results_free(r)
+
+        tickets = [submit(0), submit(1, h=0), submit(2), submit(3)]
+        with pytest.raises(retto_amd.RettoError):   # the cap: refused, nothing queued
+            submit(0)
+        check(sess.wait_batch_raw(tickets[0]), 0)
+        with pytest.raises(retto_amd.ImageError):
+            sess.wait_batch_raw(tickets[1])
+        check(sess.wait_batch_raw(tickets[2]), 2)
+        check(sess.wait_batch_raw(tickets[3]), 3)
+        again = [submit(i) for i in range(4)]
+        for i, t in enumerate(again):
+            check(sess.wait_batch_raw(t), i)
+        assert [len(p.det_result) for p in sess.run_batch(pages, det_map_override=maps)] == [len(p.det_result) for p in ref]
     finally:
         sess.close()
