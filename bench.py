@@ -74,6 +74,7 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the CPU baseline leg")
     ap.add_argument("--profile-all", action="store_true", help="print the per-family table to stderr")
     ap.add_argument("--dry-run", action="store_true", help="rank plumbing only (no GPU needed): launch / rendezvous / weight broadcast / gather, then one JSON line")
+    ap.add_argument("--no-split-leg", action="store_true", help="skip the split-bf16 leg (opt-in kernels, reported as `split_bf16`)")
     ap.add_argument("--no-c5", action="store_true", help="skip the C5 leg (server graphs, fp16) that the default C3 run appends as `c5`")
     ap.add_argument("--c5-pages", type=int, default=32)
     ap.add_argument("--c5-steps", type=int, default=5)
@@ -424,16 +425,61 @@ def main():
             step(on_host)
         barrier()
         sync_ms = 1000.0 * (time.perf_counter() - tr) / a.steps
-    # the same steps with the pages starting in host memory (PCIe inside the timed region): reported beside `value`, never as it
+    # the same steps with the pages starting in host memory (PCIe inside the timed region): reported beside `value`, never as it.
+    # What crosses PCIe is what RettoSession::run would be handed (session.rs:108-131): the RGB pages.  The planted maps are
+    # benchmark scaffolding and stay in HBM (RT_MEM_HOST_MAPS_DEVICE); the leg has its own warm-up and at least 20
+    # steps whatever --steps says (the first host-fed calls size the staging; 5 steps after one cold call measured that).
     other_rate = None
     if not global_mode:
-        step(not on_host)
-        lib.rt_synchronize(h)
-        k2 = max(2, a.steps // 4)
-        t2 = time.perf_counter()
-        run_steps(k2, not on_host)
-        lib.rt_synchronize(h)
-        other_rate = n_my * k2 / (time.perf_counter() - t2)
+        ks_all = list(range(n_my))
+
+        def host_steps(k):
+            q = []
+            for _ in range(k):
+                q.append(sess.submit_batch_raw([h_pages[j] for j in ks_all], hs, ws, retto_amd.RT_MEM_HOST_MAPS_DEVICE, d_maps))
+                if len(q) >= max(1, a.inflight):
+                    lib.rt_results_free(sess.wait_batch_raw(q.pop(0)))
+            while q:
+                lib.rt_results_free(sess.wait_batch_raw(q.pop(0)))
+        if not on_host:
+            host_steps(3)
+            lib.rt_synchronize(h)
+            k2 = max(20, a.steps) if a.workload != "c2" else max(100, a.steps)
+            t2 = time.perf_counter()
+            host_steps(k2)
+            lib.rt_synchronize(h)
+            other_rate = n_my * k2 / (time.perf_counter() - t2)
+        else:
+            run_steps(2, False)
+            lib.rt_synchronize(h)
+            k2 = max(20, a.steps)
+            t2 = time.perf_counter()
+            run_steps(k2, False)
+            lib.rt_synchronize(h)
+            other_rate = n_my * k2 / (time.perf_counter() - t2)
+    # ---- split-bf16 leg (round 6; opt-in kernels, NEVER `value`): the wide rec-net GEMMs that have no squeeze-excite operand on
+    # k_gemm_split -- three bf16 planes per fp32 operand, six v_mfma_f32_16x16x32_bf16 products per fp32 product, fp32
+    # accumulation (error against an fp64 product measured BELOW the fp32-MFMA kernel's: tests/test_gpu_parity.py
+    # test_split_bf16_gemm_error_against_fp64, tools/bench_gemm_split.py).  Same steps, same batches in flight.
+    split_leg = None
+    if a.workload == "c3" and a.dtype == "f32" and not global_mode and not on_host and not a.no_split_leg:
+        vv = [int(v) for v in a.variants.split(',')] if a.variants else [0, 0, 0]
+        lib.rt_debug_set_variants(vv[0], vv[1], vv[2] | 4096)
+        try:
+            run_steps(3)
+            barrier()
+            ts_ = time.perf_counter()
+            run_steps(a.steps)
+            barrier()
+            sp_ms = 1000.0 * (time.perf_counter() - ts_) / a.steps
+            split_leg = {"value": round(n_my * 1000.0 / sp_ms * (world if dist_on else 1), 3), "unit": "images/s", "ms_per_step": round(sp_ms, 3),
+                         "arithmetic": "fp32 operands split exactly into 3 bf16 terms each; 6 of the 9 bf16 x bf16 products (the dropped ones are below 2^-26 of "
+                                       "the product) on v_mfma_f32_16x16x32_bf16 with fp32 accumulation",
+                         "layers": "the 5 wide pointwise convs of the rec network without a squeeze-excite operand (4 x 1230432x240x240-class, "
+                                   "2 x 307608x480x480-class, 1 x 1230432x128x240-class at C3 size, minus the two `+se` launches, which stay on k_gemm32p)",
+                         "note": "opt-in (RT_GEMM_SPLIT=1 / rt_debug_set_variants bit 12); `value`, `dtype` and `roofline` are the fp32-MFMA kernels"}
+        finally:
+            lib.rt_debug_set_variants(vv[0], vv[1], vv[2])
     # ---- global mode: gather every page's digest in INPUT order; rank invariance is checked on rank 0 below -------
     gathered = None
     if global_mode:   # every rank ends with every page's digest in input order (retto_amd.dist.run_global_batch)
@@ -737,7 +783,11 @@ def main():
     if other_rate is not None:
         out["pages_on_host" if not on_host else "pages_on_hbm"] = {
             "value": round(other_rate * (world if not global_mode else 1), 3), "unit": "images/s",
-            "note": "same steps on rank 0 with the pages starting in %s, x%d ranks" % ("host memory (H2D copies inside the timed region)" if not on_host else "HBM", world)}
+            "note": "rank 0, x%d ranks: %s" % (world, ("the pages start in host memory: 2.76 MB per 960^2 page cross PCIe inside the timed region (pageable memory, "
+                    "hipMemcpyAsync on the lane's stream); own warm-up, >= 20 steps, %d batches in flight; the planted maps (benchmark scaffolding) stay in HBM" % max(1, a.inflight))
+                    if not on_host else "the pages start in HBM")}
+    if split_leg:
+        out["split_bf16"] = split_leg
     if c2:
         out["c2"] = c2
     if rank_invariance:

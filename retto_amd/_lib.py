@@ -51,7 +51,7 @@ EXPORTS = [
     "rt_device_malloc", "rt_device_free", "rt_memcpy_h2d", "rt_memcpy_d2h", "rt_synchronize",
     "rt_set_lanes", "rt_profile_enable", "rt_profile_get",
     "rt_onnx_to_rtwb", "rt_buffer_free", "rt_model_manifest", "rt_decode_image", "rt_run_encoded_batch",
-    "rt_debug_set_variants", "rt_bench_gemm", "rt_bench_lc", "rt_debug_conv16", "rt_parse_dictionary", "rt_format_f32", "rt_rccl_unique_id", "rt_broadcast_blobs",
+    "rt_debug_set_variants", "rt_bench_gemm", "rt_bench_gemm_err", "rt_bench_lc", "rt_debug_conv16", "rt_parse_dictionary", "rt_format_f32", "rt_rccl_unique_id", "rt_broadcast_blobs",
 ]
 
 STAGE_CALLBACK = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.c_int, C.c_char_p)  # rt_stage_callback

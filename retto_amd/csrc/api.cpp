@@ -448,10 +448,10 @@ size_t rt_model_manifest(int which, char* buf, size_t cap) {
 // what the environment selected when the library was loaded (dynamic initialisation runs after the nn:: globals of the other
 // translation units only by luck of link order, so these are read on the first call of rt_create -- before any hook can have
 // changed them -- see capture_variant_defaults())
-static int g_default_lc_wave = 3, g_default_gemm_dma = 1, g_default_dw_sweep = 4, g_default_cls_fused = 1;
+static int g_default_lc_wave = 3, g_default_gemm_dma = 1, g_default_dw_sweep = 4, g_default_cls_fused = 1, g_default_gemm_split = 0;
 static void capture_variant_defaults() {
   static const bool once = [] {
-    g_default_lc_wave = nn::g_lc_wave; g_default_gemm_dma = nn::g_gemm_dma; g_default_dw_sweep = nn::g_dw_sweep; g_default_cls_fused = nn::g_cls_fused;
+    g_default_lc_wave = nn::g_lc_wave; g_default_gemm_dma = nn::g_gemm_dma; g_default_dw_sweep = nn::g_dw_sweep; g_default_cls_fused = nn::g_cls_fused; g_default_gemm_split = nn::g_gemm_split;
     return true;
   }();
   (void)once;
@@ -472,6 +472,7 @@ RT_API void rt_debug_set_variants(int gemm_variant, int dw_variant, int flags) {
   nn::g_gemm_dma = (flags & 256) ? 0 : gemm_dma0;
   nn::g_dw_sweep = (flags & 512) ? 0 : dw_sweep0;
   nn::g_fpn_phase_off = (flags & 2048) ? 1 : 0;   // (bit 11: RSEFPN / DB-head convs as the round-3 launch series; equal to fp32 rounding, not bit-identical)
+  nn::g_gemm_split = (flags & 4096) ? 1 : g_default_gemm_split;   // (bit 12: the split-bf16 form of the wide rec-net GEMMs, opt-in)
   nn::g_cls_fused = (flags & 1024) ? 0 : cls_fused0;   // (bit 10: the classifier's blocks as the unfused launch series; fp32-tolerance equal, not bit-identical)
 }
 // Runs one nh::conv16 launch on host tensors (diagnostics: the numerics tests compare it with torch conv2d).

@@ -61,7 +61,10 @@ void upload_levels(RunCtx& c, std::vector<Level*> levels) {
 // ---------------------------------------------------------------------------
 // weights
 // ---------------------------------------------------------------------------
-WeightStore::~WeightStore() { for (void* p : bufs_) (void)hipFree(p); }
+WeightStore::~WeightStore() {
+  // (the split-bf16 planes nn::gemm_split derived from a pack go with it: a later allocation may reuse the address)
+  for (void* p : bufs_) { nn::gemm_split_forget((const float*)p); (void)hipFree(p); }
+}
 void* WeightStore::upload_bytes(const void* host, size_t bytes) {
   void* p = nullptr;
   size_t cap = std::max<size_t>(bytes, 16);

@@ -16,12 +16,15 @@
 //     that operand, two K slabs of 32 in flight per wave), are read as fp32 fragments and split in registers (11 VALU
 //     instructions per pair of values, issued between the MFMAs of the previous slab's second half);
 //   * a wave owns 32 pixel rows x all 240 channels of the column block (120 accumulator registers), so every pixel value is
-//     split once; 8 waves = 256 rows per workgroup, persistent over the row blocks;
-//   * the weight stream (45 KB per K slab) passes through a ring of THREE 24 KB half-slab buffers (tiles 0..7 | 8..14), one
-//     workgroup barrier per half slab placed before the half's last 12 MFMAs are issued.  Three, not two: vmcnt retires in
-//     order, so a wait for a weight request forces every OLDER pixel request of the wave to have landed; with the weights of
-//     half g + 2 requested at the start of half g (and the pixels behind them) a pixel slab has 1.5 slab times to arrive
-//     and ~48 KB per CU stay in flight -- with a ring of two it had half a slab time (measured: 0.96 ms per launch);
+//     split once; 4 waves = 128 rows per workgroup, persistent over the row blocks, TWO workgroups per CU (80 KB of LDS
+//     each).  Two independent workgroups, not one of eight waves: with one barrier domain the two waves of a SIMD leave
+//     every barrier together and run the same program in lockstep -- both in their MFMAs, then both in their requests /
+//     splits / stores -- and in-kernel stamps showed the SIMD's time to be the SUM of the two waves' streams (10.9 k
+//     cycles per slab for 2 x 2880 of MFMAs at 1.99 GHz).  Two workgroups drift apart by themselves;
+//   * the weight stream (45 KB per K slab) passes through a ring of THREE 15 KB group buffers (tiles 0..4 | 5..9 | 10..14),
+//     one workgroup barrier per group placed before the group's last 12 MFMAs are issued.  Three, not two: vmcnt retires
+//     in order, so a wait for a weight request forces every OLDER pixel request of the wave to have landed; with the
+//     weights two groups ahead (and the pixels behind them) a pixel slab has more than a slab time to arrive;
 //   * the previous tile's epilogue (bias / hardswish / LAB / 16-byte stores) rides in front of the next tile's first
 //     MFMA steps, one 16-channel tile at a time (its accumulators restart from zero there).
 #include "nn.h"
@@ -32,6 +35,7 @@
 #include <cstdlib>
 #include <map>
 #include <mutex>
+#include <string>
 
 namespace rt {
 namespace nn {
@@ -47,8 +51,12 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 #pragma clang diagnostic ignored "-Winline-asm"
 // LDS-DMA through a buffer resource: lane i writes 16 bytes at M0 + 16 i; source = base + per-lane offset + scalar offset; a
 // lane whose per-lane offset is beyond the resource's range writes zeros.
+// s_nop 4 first: this kernel spills scalar registers to VGPR lanes, and a descriptor word restored by v_readlane (a VALU write
+// of an SGPR) right in front of the asm block needs 5 wait states before a VMEM instruction reads it -- the hazard recogniser
+// does not see the buffer_load inside the block.  Without it: stale descriptor words, memory faults that came and went with
+// the register allocation.
 __device__ __forceinline__ void blds16(unsigned voff, __amdgpu_buffer_rsrc_t rs, unsigned lds_sgpr, unsigned soff) {
-  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %3 offen lds" ::"v"(voff), "s"(rs), "s"(lds_sgpr), "s"(soff) : "memory", "m0");
+  asm volatile("s_nop 4\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %3 offen lds" ::"v"(voff), "s"(rs), "s"(lds_sgpr), "s"(soff) : "memory", "m0");
 }
 #pragma clang diagnostic pop
 __device__ __forceinline__ unsigned lds_addr32(const void* p) { return (unsigned)(size_t)(__attribute__((address_space(3))) const char*)p; }
@@ -95,21 +103,24 @@ __device__ __forceinline__ f32x4 mfma_bf16(const u32x4 w, const u32x4 a, const f
 
 }  // namespace
 
-constexpr int S_BM = 256, S_BN = 240, S_NT = 15, S_NW = 8, S_NTHR = 512;
-constexpr int S_NT0 = 8;                                        // tiles 0..7 = half 0 of a slab, 8..14 = half 1
+constexpr int S_BM = 128, S_BN = 240, S_NT = 15, S_NW = 4, S_NTHR = 256;
+constexpr int S_GT = 5;                                         // tiles per weight group: a slab = 3 groups (0..4 | 5..9 | 10..14)
 constexpr unsigned S_WSLAB = S_NT * 3 * 1024;                   // 46080 bytes of split weights per K slab and column block
-constexpr unsigned S_WHALF = S_NT0 * 3 * 1024;                  // ring buffer of one half (24 KB; half 1 uses 21 KB of it)
+constexpr unsigned S_WGRP = S_GT * 3 * 1024;                    // ring buffer of one group: 15 KB
 constexpr unsigned S_AWAVE = 32 * 128;                          // a wave's 32 rows of one 32-deep fp32 slab
-constexpr unsigned S_ASLOT = S_NW * S_AWAVE;                    // 32 KB
-constexpr unsigned S_OFF_W = 2 * S_ASLOT, S_OFF_BIAS = S_OFF_W + 3 * S_WHALF;
-constexpr int S_BIAS_MAX = 960;
-constexpr size_t S_LDS = S_OFF_BIAS + S_BIAS_MAX * 4;           // 64 KB pixels | 72 KB weights | bias = 143104 bytes
+constexpr unsigned S_ASLOT = S_NW * S_AWAVE;                    // 16 KB
+constexpr unsigned S_OFF_W = 2 * S_ASLOT, S_OFF_BIAS = S_OFF_W + 3 * S_WGRP;
+constexpr int S_BIAS_MAX = 240;                                 // one column block's bias (restaged per tile)
+constexpr unsigned S_OFF_TQ = S_OFF_BIAS + S_BIAS_MAX * 4;      // ids of the workgroup's tiles j, j + 1, ... (slot j & 3)
+constexpr size_t S_LDS = S_OFF_TQ + 16;           // 32 KB pixels | 45 KB weights | bias | tile ids = 79824 bytes: two workgroups per CU
 
 struct GemmSArgs {
   const float* A; const unsigned short* Ws; float* C;
   long long M;
   int lda, nslab, N, ldc, coff;
   int n_rb, n_cb;
+  int dyn;           // 1: tile ids from the queue; 2 (debugging): the queue runs, the ids stay static
+  unsigned* sched;   // [0] tiles handed out beyond the workgroups' first ones, [1] workgroups done; zero between launches
   Epilogue epi;
 };
 
@@ -149,7 +160,12 @@ __global__ __launch_bounds__(S_NTHR, 2) void k_gemm_split(const GemmSArgs g) {
   const int r = lane & 15, q = lane >> 4;
   const unsigned lds_b = __builtin_amdgcn_readfirstlane(lds_addr32(smem_s));
   float* bias_l = reinterpret_cast<float*>(smem_s + S_OFF_BIAS);
-  for (int i = tid; i < S_BIAS_MAX; i += S_NTHR) bias_l[i] = (g.epi.bias && i < g.N) ? g.epi.bias[i] : 0.f;
+  // (the bias of the column block whose epilogue is pending; restaged between two barriers of a tile's last slab when the
+  //  next tile's column block differs)
+  int bias_cb = -1;
+  auto stage_bias = [&](int cb) __attribute__((always_inline)) {
+    if (cb != bias_cb) { for (int i = tid; i < S_BIAS_MAX; i += S_NTHR) bias_l[i] = g.epi.bias ? g.epi.bias[cb * S_BN + i] : 0.f; bias_cb = cb; }
+  };
   const int G = gridDim.x, n_tiles = g.n_rb * g.n_cb, nslab = g.nslab;
   const unsigned pitch = (unsigned)(g.lda * 4);
 
@@ -162,8 +178,29 @@ __global__ __launch_bounds__(S_NTHR, 2) void k_gemm_split(const GemmSArgs g) {
   const unsigned rq_w = (unsigned)lane * 16u;
   // The descriptors of the tile a request stream is in are rebuilt when the stream enters the next tile, not per request (an
   // integer division and 64-bit address arithmetic on the scalar unit: ~100 instructions the wave issues instead of MFMAs).
+  // Tiles are handed out dynamically: workgroup b starts with tile b, every further one comes from an atomic counter (block end
+  // times of the static form: min 720, mean 840, max 970 us -- the CUs do not run at one speed).  Wave 0 fetches the id of the
+  // workgroup's tile j + 1 in the first slab of tile j and publishes it through tileq[]; the request streams need it when they
+  // leave tile j (its last two slabs), the MFMA side when tile j ends.
+  // (explicit DS instructions: through a volatile generic pointer hipcc emits FLAT loads / stores, each followed by vmcnt(0) --
+  //  every queue access would drain the wave's requests)
+  const unsigned tq_addr = lds_b + S_OFF_TQ;
+  auto tq_read = [&](int j) __attribute__((always_inline)) {
+    int v;
+    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(tq_addr + (unsigned)((j & 3) * 4)) : "memory");
+    return (int)__builtin_amdgcn_readfirstlane(v);
+  };
+  auto tq_write = [&](int j, int v) __attribute__((always_inline)) {
+    asm volatile("ds_write_b32 %0, %1" ::"v"(tq_addr + (unsigned)((j & 3) * 4)), "v"(v) : "memory");
+  };
+  if (tid == 0) tq_write(0, (int)blockIdx.x);
+  int aq_j = 0, wq_j = 0;   // tile ordinals of the two request streams
   int aq_t = (int)blockIdx.x, aq_s = 0, aq_slot = 0;        // next pixel slab to request: tile, slab, ring slot
-  int wq_t = (int)blockIdx.x, wq_h = 0, wq_buf = 0; unsigned wq_so = 0; // next weight half to request: tile, half 0 .. 2 nslab - 1, ring buffer, byte offset of the half
+  int wq_t = (int)blockIdx.x, wq_h = 0, wq_buf = 0; unsigned wq_so = 0; // next weight group to request: tile, group 0 .. 3 nslab - 1, ring buffer, byte offset of the group
+  // (measured and removed: walking a tile's K slabs in an order rotated by its row block, so that the workgroups of the chip do not
+  //  all read the same 128 bytes of their 1-KB rows at the same time -- requests only, no MFMAs: 0.489 vs 0.501 ms, whole kernel
+  //  0.966 vs 0.979: not channel camping)
+  int aq_p = 0, wq_p = 0, wq_g = 0;   // slab of the next pixel / weight request, weight group within it
   bool dbg_pro = true;   // (DBG: requests of the prologue are always issued)
   auto a_desc = [&](int t) __attribute__((always_inline)) {
     const bool live = t < n_tiles;
@@ -185,38 +222,39 @@ __global__ __launch_bounds__(S_NTHR, 2) void k_gemm_split(const GemmSArgs g) {
   // issue their piece BEFORE the step's MFMAs, their SIMD partners 4..7 AFTER them: one's request under the other's MFMAs.
   // vmcnt bookkeeping at run time: vc_next / vc_later = vector-memory instructions issued after the last piece of the weight
   // group the next / the next-but-one barrier wait needs (that many may stay in flight at that wait).
-  int vc_next = 0, vc_later = 0;
-  auto vm_note = [&](int n) __attribute__((always_inline)) { vc_next += n; vc_later += n; };
+  int vc_next = 0, vc_later = 0, vc_at = 0;   // vc_at: ... after the tile-queue atomic of wave 0
+  auto vm_note = [&](int n) __attribute__((always_inline)) { vc_next += n; vc_later += n; vc_at += n; };
   auto a_piece = [&](auto ktag) __attribute__((always_inline)) {
     constexpr int k = decltype(ktag)::value;
     const unsigned dst = a_dst0 + (unsigned)aq_slot * S_ASLOT + k * 1024u;
-    const unsigned so = (unsigned)aq_s * 128u;
+    const unsigned so = (unsigned)aq_p * 128u;
     if (!(DBG & 2) || dbg_pro) { blds16(((k & 1) ? rq_a1 : rq_a0) + (unsigned)(8 * k) * pitch, ars, dst, so); vm_note(1); }
     if (k == 3) {
       aq_slot ^= 1;
-      if (++aq_s == nslab) { aq_s = 0; aq_t += G; ars = a_desc(aq_t); }
+      aq_p = aq_p + 1 == nslab ? 0 : aq_p + 1;
+      if (++aq_s == nslab) { aq_s = 0; aq_j++; { const int q_ = (g.dyn & 8) ? tq_read(aq_j) : 0; aq_t = (g.dyn & 1) ? q_ : aq_t + G; } ars = a_desc(aq_t); aq_p = 0; }
     }
     __builtin_amdgcn_sched_barrier(0);
   };
-  // (always three pieces per wave and half: the second half of a slab has 21, the waves 5..7 then fetch 1 KB of the next slab
-  //  into the unused end of the ring buffer)
+  // (a group has 15 pieces: wave w takes w, w + 4, w + 8, w + 12 -- wave 3 has three; its bookkeeping still runs at k == 3)
   auto w_piece = [&](auto ktag) __attribute__((always_inline)) {
     constexpr int k = decltype(ktag)::value;
-    const unsigned dst = w_dst0 + (unsigned)wq_buf * S_WHALF + k * 8192u;
-    const unsigned so = wq_so + (unsigned)wid * 1024u + k * 8192u;
-    if (!(DBG & 4) || dbg_pro) { blds16(rq_w, wrs, dst, so); vm_note(1); }
-    if (k == 2) {
+    const unsigned dst = w_dst0 + (unsigned)wq_buf * S_WGRP + k * 4096u;
+    const unsigned so = wq_so + (unsigned)wid * 1024u + k * 4096u;
+    if ((!(DBG & 4) || dbg_pro) && (k < 3 || wid < 3)) { blds16(rq_w, wrs, dst, so); vm_note(1); }
+    if (k == 3) {
       vc_later = 0;
       wq_buf = wq_buf == 2 ? 0 : wq_buf + 1;
-      wq_so += (wq_h & 1) ? S_WSLAB - S_WHALF : S_WHALF;
-      if (++wq_h == 2 * nslab) { wq_h = 0; wq_so = 0; wq_t += G; wrs = w_desc(wq_t); }
+      if (++wq_g == 3) { wq_g = 0; wq_p = wq_p + 1 == nslab ? 0 : wq_p + 1; }
+      if (++wq_h == 3 * nslab) { wq_h = 0; wq_j++; { const int q_ = (g.dyn & 8) ? tq_read(wq_j) : 0; wq_t = (g.dyn & 1) ? q_ : wq_t + G; } wrs = w_desc(wq_t); wq_p = 0; wq_g = 0; }
+      wq_so = (unsigned)wq_p * S_WSLAB + (unsigned)wq_g * S_WGRP;
     }
     __builtin_amdgcn_sched_barrier(0);
   };
   auto a_issue = [&]() __attribute__((always_inline)) { a_piece(IntTag<0>{}); a_piece(IntTag<1>{}); a_piece(IntTag<2>{}); a_piece(IntTag<3>{}); };
-  auto w_issue = [&]() __attribute__((always_inline)) { w_piece(IntTag<0>{}); w_piece(IntTag<1>{}); w_piece(IntTag<2>{}); };
+  auto w_issue = [&]() __attribute__((always_inline)) { w_piece(IntTag<0>{}); w_piece(IntTag<1>{}); w_piece(IntTag<2>{}); w_piece(IntTag<3>{}); };
   // s_waitcnt vmcnt(n), n at run time (the instruction takes an immediate; a smaller n only waits for more)
-  auto vm_wait = [&](int n) __attribute__((always_inline)) {
+  auto vm_wait_n = [&](int n) __attribute__((always_inline)) {
 #define RT_VW(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); break;
     switch (min(n, 47)) {
       RT_VW(0) RT_VW(1) RT_VW(2) RT_VW(3) RT_VW(4) RT_VW(5) RT_VW(6) RT_VW(7) RT_VW(8) RT_VW(9) RT_VW(10) RT_VW(11) RT_VW(12) RT_VW(13) RT_VW(14) RT_VW(15)
@@ -224,9 +262,9 @@ __global__ __launch_bounds__(S_NTHR, 2) void k_gemm_split(const GemmSArgs g) {
       RT_VW(32) RT_VW(33) RT_VW(34) RT_VW(35) RT_VW(36) RT_VW(37) RT_VW(38) RT_VW(39) RT_VW(40) RT_VW(41) RT_VW(42) RT_VW(43) RT_VW(44) RT_VW(45) RT_VW(46) RT_VW(47)
     }
 #undef RT_VW
-    vc_next = vc_later;
     __builtin_amdgcn_sched_barrier(0);
   };
+  auto vm_wait = [&](int n) __attribute__((always_inline)) { vm_wait_n(n); vc_next = vc_later; };
 
   // ---- fragment side --------------------------------------------------------------------------------------------------------
   // pixels: lane (r, q) of row tile mt reads row 16 mt + r of the wave's rows, logical chunks q and 4 + q (k = 4 q .. + 3 and
@@ -258,7 +296,7 @@ __global__ __launch_bounds__(S_NTHR, 2) void k_gemm_split(const GemmSArgs g) {
 
   // ---- epilogue of the previous tile, one 16-channel tile at a time ------------------------------------------------------------
   char* pend_c = nullptr;     // &C[first row of the wave][first channel of the column block] of the tile waiting for its epilogue
-  int pend_n0 = 0, pend_rows = 0;
+  int pend_rows = 0;
   bool pend_full = false;   // every lane of the wave stores (32 valid rows): the chunk's two stores are certainly issued
   const unsigned mt_step = (unsigned)(16 * g.ldc * 4);
   auto epi_chunk = [&](auto nttag) __attribute__((always_inline)) {
@@ -267,7 +305,7 @@ __global__ __launch_bounds__(S_NTHR, 2) void k_gemm_split(const GemmSArgs g) {
     asm volatile("" : "+v"(ln));
     const int rr = ln & 15;
     const unsigned lo = (unsigned)((rr * g.ldc + nt * 16 + (ln >> 4) * 4) * 4);
-    const f32x4 bias = *reinterpret_cast<const f32x4*>(bias_l + pend_n0 + nt * 16 + (ln >> 4) * 4);
+    const f32x4 bias = *reinterpret_cast<const f32x4*>(bias_l + nt * 16 + (ln >> 4) * 4);
 #pragma unroll
     for (int mt = 0; mt < 2; mt++) {
       f32x4 o;
@@ -327,78 +365,95 @@ __global__ __launch_bounds__(S_NTHR, 2) void k_gemm_split(const GemmSArgs g) {
   read_b(IntTag<0>{}, IntTag<0>{}, w_fr);
   __builtin_amdgcn_sched_barrier(0);
   int a_slot = 0;   // ring slot of the current slab's pixels
+  int tile_j = 0;   // ordinal of the workgroup's current tile
   int wb = 0;       // ring buffer of the current half's weights
   u32x4 Nh[2], Nm[2], Nl[2];   // the next slab's split pixel fragments (built during the current slab's second half)
 
-  // One 32-deep slab: 15 steps of 12 MFMAs.  EPI: first slab of a tile -- the accumulators start from zero and, if a tile is
-  // pending, its epilogue chunks ride along (chunk nt + 1 woven into the MFMAs of step nt).
-  // Request schedule of a slab (one piece per step): steps 0-2 the weights of the NEXT slab's first half (ring buffer of the half
-  // the last barrier retired), steps 3-6 the pixels two slabs ahead (the slot whose fragments were read a slab ago), steps 8-10
-  // the next slab's second half of weights.  The barrier that closes half g needs the weights of half g + 1, requested two
-  // halves earlier: everything issued since may stay in flight (vc_next).
-  const bool late = wid >= 4;
+  // One 32-deep slab: 15 steps of 12 MFMAs in three groups of five.  EPI: first slab of a tile -- the accumulators start from zero
+  // and, if a tile is pending, its epilogue chunks ride along (chunk nt + 1 woven into the MFMAs of step nt).
+  // Request schedule of a slab (at most one weight and one pixel piece per step): steps 0-3, 5-8, 10-13 the weights two groups
+  // ahead (the ring buffer of the group the last barrier retired), steps 0-3 also the pixels two slabs ahead (the slot whose
+  // fragments were read a slab ago).  The barrier that closes a group needs the weights of the next one, requested two groups
+  // earlier: everything issued since may stay in flight (vc_next).
   auto slab = [&](auto epi_tag, bool pend) __attribute__((always_inline)) {
     constexpr bool EPI = decltype(epi_tag)::value;
-    unsigned wf = w_fr + (unsigned)wb * S_WHALF;
+    unsigned wf = w_fr + (unsigned)wb * S_WGRP;
 #define RT_WEAVE() do { \
       _Pragma("unroll") for (int i_ = 0; i_ < 12; i_++) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 4, 0); } } while (0)
-    // one step: request the next tile's weight fragments, wait for this tile's, (this wave's request piece), 12 MFMAs -- with the
+    // one step: request the next tile's weight fragments, wait for this tile's, this step's request pieces, 12 MFMAs -- with the
     // VALU work that rides along woven in, four instructions behind each MFMA: the epilogue chunk of the NEXT step's tile (whose
-    // accumulators this step does not touch) and WORK (the split).  The two waves of a SIMD run in lockstep between barriers:
-    // a VALU BLOCK of one coincides with the other's and the matrix pipe idles for both.
+    // accumulators this step does not touch) and WORK (the split)
 #define RT_STEP_V(SL, nt, NOFF, REQ, WORK) do { \
       read_b(IntTag<1 - SL>{}, IntTag<NOFF>{}, wf); \
       lgkm_wait<3>(); \
-      if (!late) { REQ; } \
+      REQ; \
       RT_SMF(SL, nt, EPI); \
       if (EPI && pend) epi_chunk(IntTag<(nt) + 1>{}); \
       WORK; \
       RT_WEAVE(); \
-      __builtin_amdgcn_sched_barrier(0); \
-      if (late) { REQ; } } while (0)
+      __builtin_amdgcn_sched_barrier(0); } while (0)
 #define RT_STEP(SL, nt, NOFF, REQ) RT_STEP_V(SL, nt, NOFF, REQ, (void)0)
-    // ---- half 0: tiles 0..7
+    // last step of a group: this tile's fragments are in registers; the next group's weights have landed (this wave's pieces:
+    // vm_wait; everybody's: the barrier), its first fragments are requested, then the 12 MFMAs
+#define RT_LAST(SL, nt, REQ, WORK, STI) do { \
+      RT_STA(); \
+      lgkm_wait<0>(); \
+      vm_wait(vc_next); \
+      RT_STB(STI); \
+      __builtin_amdgcn_s_barrier(); \
+      __builtin_amdgcn_sched_barrier(0); \
+      RT_STB(STI + 1); \
+      wb = wb == 2 ? 0 : wb + 1; \
+      wf = w_fr + (unsigned)wb * S_WGRP; \
+      read_b(IntTag<1 - SL>{}, IntTag<0>{}, wf); \
+      __builtin_amdgcn_sched_barrier(0); \
+      REQ; \
+      RT_SMF(SL, nt, EPI); \
+      if (EPI && pend && (nt) + 1 < S_NT) { epi_chunk(IntTag<((nt) + 1 < S_NT ? (nt) + 1 : 0)>{}); } \
+      WORK; \
+      RT_WEAVE(); \
+      __builtin_amdgcn_sched_barrier(0); } while (0)
+#define RT_WA(k) do { w_piece(IntTag<k>{}); a_piece(IntTag<k>{}); } while (0)
+    // The id of the workgroup's next tile: one returning atomic of wave 0 at the start of a tile's first slab, published through
+    // tileq[] before the barrier that closes the slab's second group.  The request streams read it when they leave the tile --
+    // for K = 128 (four slabs) that is as early as the second slab's fourth step, so TWO barriers of the first slab must lie
+    // behind the write (published at the slab's end, with no barrier in between, the other waves raced it: memory faults that
+    // depended on how the session's lanes happened to line up).
+    unsigned fetched = 0;
+    if (EPI && (g.dyn & 2)) {
+      if (wid == 0) {
+        if (lane_id() == 0) asm volatile("s_nop 4\n\tglobal_atomic_add %0, %1, %2, %3 sc0" : "=v"(fetched) : "v"(0u), "v"(1u), "s"(g.sched) : "memory");
+        vm_note(1); vc_at = 0;
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
     if (EPI && pend) epi_chunk(IntTag<0>{});
-    RT_STEP(0, 0, 1 * 3072, w_piece(IntTag<0>{})); RT_STEP(1, 1, 2 * 3072, w_piece(IntTag<1>{})); RT_STEP(0, 2, 3 * 3072, w_piece(IntTag<2>{}));
-    RT_STEP(1, 3, 4 * 3072, a_piece(IntTag<0>{})); RT_STEP(0, 4, 5 * 3072, a_piece(IntTag<1>{})); RT_STEP(1, 5, 6 * 3072, a_piece(IntTag<2>{}));
-    RT_STEP(0, 6, 7 * 3072, a_piece(IntTag<3>{}));
-    RT_STA();
-    lgkm_wait<0>();
-    vm_wait(vc_next);
-    RT_STB(0);
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-    RT_STB(1);
-    wb = wb == 2 ? 0 : wb + 1;
-    wf = w_fr + (unsigned)wb * S_WHALF;
-    read_b(IntTag<0>{}, IntTag<0>{}, wf);
-    __builtin_amdgcn_sched_barrier(0);
-    RT_SMF(1, 7, EPI);
-    if (EPI && pend) { epi_chunk(IntTag<8>{}); RT_WEAVE(); }
-    __builtin_amdgcn_sched_barrier(0);
-    // ---- half 1: tiles 8..14
-    // (the next slab's pixels have landed: their request is older than the weights the barrier above waited for)
+    // ---- group 0: tiles 0..4
+    RT_STEP(0, 0, 1 * 3072, RT_WA(0)); RT_STEP(1, 1, 2 * 3072, RT_WA(1)); RT_STEP(0, 2, 3 * 3072, RT_WA(2)); RT_STEP(1, 3, 4 * 3072, RT_WA(3));
+    RT_LAST(0, 4, (void)0, (void)0, 0);
+    // ---- group 1: tiles 5..9
+    RT_STEP(1, 5, 1 * 3072, w_piece(IntTag<0>{})); RT_STEP(0, 6, 2 * 3072, w_piece(IntTag<1>{})); RT_STEP(1, 7, 3 * 3072, w_piece(IntTag<2>{}));
+    RT_STEP(0, 8, 4 * 3072, w_piece(IntTag<3>{}));
+    if (EPI && (g.dyn & 4)) {   // the next tile's id has returned (everything issued since may stay in flight)
+      if (wid == 0) {
+        vm_wait_n(vc_at);
+        if (lane_id() == 0) tq_write(tile_j + 1, G + (int)fetched);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    RT_LAST(1, 9, (void)0, (void)0, 2);
+    // ---- group 2: tiles 10..14.  The next slab's pixels have landed: their request is older than the weights the barrier
+    // above waited for (requested in this slab's first steps, behind them).
     read_raw2(a_slot ^ 1);
     __builtin_amdgcn_sched_barrier(0);
-    RT_STEP(0, 8, 1 * 3072, w_piece(IntTag<0>{}));
-    RT_STEP_V(1, 9, 2 * 3072, w_piece(IntTag<1>{}), split_into(0, Nh[0], Nm[0], Nl[0]));
-    RT_STEP_V(0, 10, 3 * 3072, w_piece(IntTag<2>{}), split_into(1, Nh[1], Nm[1], Nl[1]));
-    RT_STEP(1, 11, 4 * 3072, (void)0); RT_STEP(0, 12, 5 * 3072, (void)0); RT_STEP(1, 13, 6 * 3072, (void)0);
-    RT_STA();
-    lgkm_wait<0>();
-    vm_wait(vc_next);
-    RT_STB(2);
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-    RT_STB(3);
-    wb = wb == 2 ? 0 : wb + 1;
-    wf = w_fr + (unsigned)wb * S_WHALF;
-    read_b(IntTag<1>{}, IntTag<0>{}, wf);
-    __builtin_amdgcn_sched_barrier(0);
-    RT_SMF(0, 14, EPI);
-    __builtin_amdgcn_sched_barrier(0);
+    RT_STEP_V(0, 10, 1 * 3072, w_piece(IntTag<0>{}), split_into(0, Nh[0], Nm[0], Nl[0]));
+    RT_STEP_V(1, 11, 2 * 3072, w_piece(IntTag<1>{}), split_into(1, Nh[1], Nm[1], Nl[1]));
+    RT_STEP(0, 12, 3 * 3072, w_piece(IntTag<2>{})); RT_STEP(1, 13, 4 * 3072, w_piece(IntTag<3>{}));
+    RT_LAST(0, 14, (void)0, (void)0, 2);
 #undef RT_STEP
 #undef RT_STEP_V
+#undef RT_LAST
+#undef RT_WA
 #undef RT_WEAVE
     // hand the fragments over (register moves; the second set keeps the 12 MFMAs above independent of the split).  The weight
     // fragment just requested must have landed before it is moved: the 12 MFMAs above are in the pipe meanwhile.
@@ -409,23 +464,41 @@ __global__ __launch_bounds__(S_NTHR, 2) void k_gemm_split(const GemmSArgs g) {
     a_slot ^= 1;
   };
 
-  for (int t = (int)blockIdx.x; t < n_tiles; t += G) {
+  for (int t = (int)blockIdx.x; t < n_tiles; ) {
     const int rb = t / g.n_cb, cb = t - rb * g.n_cb;
     const bool pend = pend_c != nullptr;
     pend_full = pend && pend_rows >= 32 && !(DBG & 1);
     slab(std::true_type{}, pend);
+    // (the pending tile's last bias read lies before the last barrier of the slab above; this tile's epilogue -- the next reader --
+    //  begins with the next tile's first slab or the tail below, barriers away)
+    stage_bias(cb);
     for (int s = 1; s < nslab; s++) slab(std::false_type{}, false);
     const long long m0 = (long long)rb * S_BM + 32 * wid;
     pend_c = reinterpret_cast<char*>(g.C + m0 * g.ldc + g.coff + cb * S_BN);
-    pend_n0 = cb * S_BN;
     pend_rows = (int)max(0ll, min(32ll, g.M - m0));
+    tile_j++;
+    { const int q_ = (g.dyn & 8) ? tq_read(tile_j) : 0;
+      t = (g.dyn & 1) ? q_ : t + G; }   // (published in this tile's first slab, barriers ago)
   }
+  __syncthreads();
   if (pend_c) {
     epi_chunk(IntTag<0>{}); epi_chunk(IntTag<1>{}); epi_chunk(IntTag<2>{}); epi_chunk(IntTag<3>{}); epi_chunk(IntTag<4>{});
     epi_chunk(IntTag<5>{}); epi_chunk(IntTag<6>{}); epi_chunk(IntTag<7>{}); epi_chunk(IntTag<8>{}); epi_chunk(IntTag<9>{});
     epi_chunk(IntTag<10>{}); epi_chunk(IntTag<11>{}); epi_chunk(IntTag<12>{}); epi_chunk(IntTag<13>{}); epi_chunk(IntTag<14>{});
   }
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // (requests issued for tiles that do not exist write zeros into LDS)
+  // the last workgroup to finish leaves the two counters at zero for the next launch on this stream
+  if (tid == 0 && (g.dyn & 16)) {
+    const unsigned done = __hip_atomic_fetch_add(g.sched + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (done == (unsigned)G - 1) {
+      __hip_atomic_store(g.sched, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(g.sched + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+  if (ST && wid == 0 && lane == 0) {
+    unsigned long long* o = reinterpret_cast<unsigned long long*>(g.epi.am_max);
+    o[8 + 2 * blockIdx.x] = st_r0; o[9 + 2 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();
+  }
   if (ST && st_on && lane == 0) {
     unsigned long long* o = reinterpret_cast<unsigned long long*>(g.epi.am_max);
     o[0] = __builtin_amdgcn_s_memtime() - st_c0; o[1] = __builtin_amdgcn_s_memrealtime() - st_r0;
@@ -441,10 +514,11 @@ int g_gemm_split = getenv("RT_GEMM_SPLIT") ? atoi(getenv("RT_GEMM_SPLIT")) : 0; 
 
 bool gemm_split_supported(int lda, long long M, int K, int N, int Npad16, const Epilogue& epi) {
   if (epi.am_max || epi.residual || epi.a_scale) return false;
-  if (Npad16 != N || N % S_BN != 0 || N > S_BIAS_MAX) return false;
+  if (Npad16 != N || N % S_BN != 0 || N > 960) return false;
   if (lda < round_up(K, KC) || (lda & 3)) return false;          // whole 32-deep slabs readable (padding channels hold zeros)
   if ((long long)lda * 4 * 32 >= (1ll << 31)) return false;
-  return M >= S_BM && K > KC;
+  // (large launches only: the small-batch dispatch of a one-page call stays on the narrow fp32 kernel)
+  return M >= 32768 && K > 3 * KC;   // (>= 4 slabs: the request streams read the next tile's id two slabs before a tile ends; it is published in the tile's first slab)
 }
 
 // the split planes of a packed fp32 weight matrix, built on first use and kept for the life of the process (keyed by the
@@ -455,14 +529,23 @@ static const unsigned short* split_pack_of(hipStream_t st, const float* Wp, int 
   int dev = 0;
   RT_HIP_CHECK(hipGetDevice(&dev));
   std::lock_guard<std::mutex> lk(g_split_mu);
-  unsigned short*& p = g_split_cache[{dev, Wp}];
-  if (!p) {
-    const size_t bytes = (size_t)n_cb * nslab * S_WSLAB;
-    RT_HIP_CHECK(hipMalloc((void**)&p, bytes + 65536));   // (+ slack: half 1's third request of the waves 5..7 is skipped, not clamped)
-    RT_HIP_CHECK(hipMemsetAsync(p, 0, bytes + 65536, st));
+  auto it = g_split_cache.find({dev, Wp});
+  if (it != g_split_cache.end()) return it->second;
+  // First use of this pack on this device: build the planes and WAIT for them before the entry becomes visible -- the session's
+  // lanes launch the same layers from their own threads on their own streams, and a lane that found the entry while the pack
+  // kernel was still queued on another lane's stream multiplied by whatever the allocation held.
+  unsigned short* p = nullptr;
+  const size_t bytes = (size_t)n_cb * nslab * S_WSLAB;
+  RT_HIP_CHECK(hipMalloc((void**)&p, bytes + 65536));   // (+ slack behind the last group)
+  hipError_t e = hipMemsetAsync(p, 0, bytes + 65536, st);
+  if (e == hipSuccess) {
     const long long total = (long long)n_cb * nslab * S_NT * 64;
-    RT_LAUNCH(k_split_pack, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, Wp, nslab, Npad, n_cb, p);
+    hipLaunchKernelGGL(k_split_pack, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, Wp, nslab, Npad, n_cb, p);
+    e = hipGetLastError();
   }
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  if (e != hipSuccess) { (void)hipFree(p); throw RtError(4, std::string("gemm_split: building the split planes failed: ") + hipGetErrorString(e)); }
+  g_split_cache[{dev, Wp}] = p;
   return p;
 }
 
@@ -480,21 +563,46 @@ void gemm_split(hipStream_t st, const float* A, int lda, long long M, int K, con
   g.A = A; g.C = C; g.M = M; g.lda = lda; g.nslab = (K + KC - 1) / KC; g.N = N; g.ldc = ldc; g.coff = coff;
   g.n_rb = (int)((M + S_BM - 1) / S_BM); g.n_cb = N / S_BN; g.epi = epi;
   g.Ws = split_pack_of(st, Wp, g.nslab, Npad16, g.n_cb);
-  const int grid = std::min(g.n_rb * g.n_cb, stream_cus(st));
+  {
+    int dev = 0;
+    RT_HIP_CHECK(hipGetDevice(&dev));
+    static std::mutex mu;
+    static std::map<std::pair<int, hipStream_t>, unsigned*> counters;   // zero between launches (the kernel resets them)
+    std::lock_guard<std::mutex> lk(mu);
+    unsigned*& c = counters[{dev, st}];
+    if (!c) { RT_HIP_CHECK(hipMalloc((void**)&c, 256)); RT_HIP_CHECK(hipMemset(c, 0, 256)); }
+    g.sched = c;
+    static const int stat = getenv("RT_GS_STATIC") ? atoi(getenv("RT_GS_STATIC")) : 0;   // A/B: static tile lists
+    g.dyn = stat ? 0 : 31;   // (bits: 1 ids from the queue, 2 atomic, 4 publish, 8 queue reads, 16 end-of-kernel counters)
+  }
+  const int grid = std::min(g.n_rb * g.n_cb, 2 * stream_cus(st));   // two workgroups per CU
 #define RT_GS(ACTV, LABV) do { allow_big_lds((const void*)k_gemm_split<ACTV, LABV>, 160 * 1024); \
     RT_LAUNCH((k_gemm_split<ACTV, LABV>), dim3((unsigned)grid), dim3(S_NTHR), S_LDS, st, g); } while (0)
   static const int dbg = getenv("RT_GS_DBG") ? atoi(getenv("RT_GS_DBG")) : 0;   // timing experiments only (wrong results)
   if (dbg & 256) {
     static unsigned long long* dst = nullptr;
-    if (!dst) RT_HIP_CHECK(hipMalloc((void**)&dst, 64));
-    RT_HIP_CHECK(hipMemsetAsync(dst, 0, 64, st));
+    if (!dst) RT_HIP_CHECK(hipMalloc((void**)&dst, 64 + 16 * 1024));
+    RT_HIP_CHECK(hipMemsetAsync(dst, 0, 64 + 16 * 1024, st));
     g.epi.am_max = reinterpret_cast<float*>(dst);
     g.epi.am_tiles = getenv("RT_GS_WAVE") ? atoi(getenv("RT_GS_WAVE")) : 0;
     allow_big_lds((const void*)k_gemm_split<ACT_HSWISH, 1, 256>, 160 * 1024);
     RT_LAUNCH((k_gemm_split<ACT_HSWISH, 1, 256>), dim3((unsigned)grid), dim3(S_NTHR), S_LDS, st, g);
-    unsigned long long h[8];
+    unsigned long long h[8 + 2048];
     RT_HIP_CHECK(hipMemcpyAsync(h, dst, sizeof(h), hipMemcpyDeviceToHost, st));
     RT_HIP_CHECK(hipStreamSynchronize(st));
+    {
+      int occ = -1;
+      (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)k_gemm_split<ACT_HSWISH, 1, 256>, S_NTHR, S_LDS);
+      unsigned long long t0 = ~0ull, t1 = 0;
+      for (int b = 0; b < grid && b < 1024; b++) { t0 = std::min(t0, h[8 + 2 * b]); t1 = std::max(t1, h[9 + 2 * b]); }
+      int late_start = 0; double s_end = 0, mn = 1e30, mx = 0;
+      for (int b = 0; b < grid && b < 1024; b++) {
+        if ((h[8 + 2 * b] - t0) > 5000) late_start++;
+        const double e = (h[9 + 2 * b] - t0) / 100.0; s_end += e; mn = std::min(mn, e); mx = std::max(mx, e);
+      }
+      fprintf(stderr, "gsplit blocks: occupancy API %d per CU; grid %d; span %.1f us; %d blocks started > 50 us after the first; block end min %.1f mean %.1f max %.1f us\n",
+              occ, grid, (t1 - t0) / 100.0, late_start, mn, s_end / std::min(grid, 1024), mx);
+    }
     if (h[1]) fprintf(stderr, "gsplit wave %d of block 7: %llu cycles in %.1f us = %.3f GHz; per launch: mid wait %llu + barrier %llu, end wait %llu + barrier %llu cycles (%d slabs per tile)\n",
                       g.epi.am_tiles, h[0], h[1] / 100.0, h[0] / (h[1] * 10.0), h[2], h[3], h[4], h[5], g.nslab);
     return;

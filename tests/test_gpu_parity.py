@@ -101,6 +101,56 @@ def test_rec_net_ragged_production_size(hip_session, oracle_session):
     assert dec_eq == dec_n and dec_n > 0.9 * tot, (dec_eq, dec_n, tot)
 
 
+# ---- split-bf16 form of the wide rec-net GEMMs (round 6; opt-in, rt_debug_set_variants bit 12) ----------------------------------
+def _gemm_err(hip_session, M, K, N, variant, seed):
+    import ctypes as C
+    lib, h = hip_session._hd.lib, hip_session._hd.h
+    lib.rt_bench_gemm_err.argtypes = [C.c_void_p, C.c_longlong, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint, C.POINTER(C.c_double)]
+    o = (C.c_double * 4)()
+    assert lib.rt_bench_gemm_err(h, M, K, N, variant, 512, 0, seed, o) == 0, lib.rt_last_error(h)
+    return list(o)   # max |err|, rms err, max |ref|, rms ref
+
+
+@pytest.mark.parametrize("M,K,N", [(65613, 240, 240), (40000, 480, 480), (70001, 128, 240)])
+def test_split_bf16_gemm_error_against_fp64(hip_session, M, K, N):
+    """The evidence behind the split-bf16 GEMM (nn_gemm_split.hip): operands with FULL 24-bit significands, bias 0, no activation;
+    3 x 512 rows (start, middle, the partial last row block) against sum_k (double)a (double)w on the host.  The split form
+    (variant 40: 3 bf16 planes per operand, 6 bf16 MFMAs per product, fp32 accumulate) must be NO WORSE than the fp32-MFMA
+    kernel (variant 30, k_gemm32p: v_mfma_f32_16x16x4_f32) on the same data -- in the maximum and in the rms error, seed by seed --
+    and both must sit at fp32 rounding level (a few ulp of the result's rms)."""
+    for seed in (1, 2, 3):
+        e32 = _gemm_err(hip_session, M, K, N, 30, seed)
+        esp = _gemm_err(hip_session, M, K, N, 40, seed)
+        assert esp[2] == e32[2] and esp[3] == e32[3]            # same reference
+        assert esp[0] <= e32[0], (seed, esp, e32)               # max |err|
+        assert esp[1] <= e32[1], (seed, esp, e32)               # rms err
+        assert e32[1] <= 1e-6 * e32[3] and esp[1] <= 1e-6 * e32[3]   # both at fp32 rounding level (rms ref ~2.4: 2.4e-6)
+
+
+@pytest.mark.parametrize("n,w", [(120, 400), (1000, 96), (130, 412)])
+def test_rec_net_split_bf16(hip_session, oracle_session, n, w):
+    """test_rec_net's production-size cases with the split-bf16 kernels switched in (the 240- / 480-channel pointwise convs of
+    >= 32768 rows without a squeeze-excite operand): the SAME bars -- <= 2e-4 on the softmax output against the torch fp32
+    oracle, argmax exact wherever the oracle's top-2 margin exceeds 1e-4."""
+    lib = hip_session._hd.lib
+    x = np.random.default_rng(w).uniform(-1, 1, (n, 3, 48, w)).astype(np.float32)
+    x[:, :, :, w // 2:] = 0.0
+    base = hip_session.worker.rec(x)
+    lib.rt_debug_set_variants(0, 0, 4096)
+    try:
+        got = hip_session.worker.rec(x)
+    finally:
+        lib.rt_debug_set_variants(0, 0, 0)
+    ref = N.rec_forward(oracle_session.wr, torch.from_numpy(x)).numpy()
+    assert not np.array_equal(got, base)                # the split kernels did run (a different summation)
+    assert np.abs(got - ref).max() <= 2e-4
+    ga, ra = got.argmax(-1), ref.argmax(-1)
+    top2 = np.sort(ref, -1)[..., -2:]
+    decisive = (top2[..., 1] - top2[..., 0]) > 1e-4
+    assert (ga[decisive] == ra[decisive]).all()
+    assert decisive.mean() > 0.9
+
+
 # ---------------------------------------------------------------- a2 / a3 preprocessing
 @pytest.mark.parametrize("h,w", [(640, 640), (96, 160), (2100, 1300), (20, 300), (50, 200)])
 def test_resize_both(hip_session, h, w):
