@@ -222,32 +222,36 @@ __global__ __launch_bounds__(S_NTHR, 2) void k_gemm_split(const GemmSArgs g) {
   // issue their piece BEFORE the step's MFMAs, their SIMD partners 4..7 AFTER them: one's request under the other's MFMAs.
   // vmcnt bookkeeping at run time: vc_next / vc_later = vector-memory instructions issued after the last piece of the weight
   // group the next / the next-but-one barrier wait needs (that many may stay in flight at that wait).
-  int vc_next = 0, vc_later = 0, vc_at = 0;   // vc_at: ... after the tile-queue atomic of wave 0
-  auto vm_note = [&](int n) __attribute__((always_inline)) { vc_next += n; vc_later += n; vc_at += n; };
+  // (one running count of issued operations and snapshots of it: an add per operation instead of three -- a wave issues one scalar
+  //  instruction per ~4 cycles, and in-kernel stamps put the ~15 scalar instructions around a request at 110 cycles per piece)
+  int vc_ops = 0, vs_next = 0, vs_later = 0, vs_at = 0;   // vs_at: ... at the tile-queue atomic of wave 0
+  auto vm_note = [&](int n) __attribute__((always_inline)) { vc_ops += n; };
+  // destination / source offsets of the current request group, advanced when a group's last piece has been issued
+  unsigned aq_dst = a_dst0, aq_so = 0, wq_dst = w_dst0;
+  unsigned wq_sow = (unsigned)wid * 1024u;   // wq_so + this wave's first piece
+  const unsigned pitch8 = 8u * pitch;
   auto a_piece = [&](auto ktag) __attribute__((always_inline)) {
     constexpr int k = decltype(ktag)::value;
-    const unsigned dst = a_dst0 + (unsigned)aq_slot * S_ASLOT + k * 1024u;
-    const unsigned so = (unsigned)aq_p * 128u;
-    if (!(DBG & 2) || dbg_pro) { blds16(((k & 1) ? rq_a1 : rq_a0) + (unsigned)(8 * k) * pitch, ars, dst, so); vm_note(1); }
+    if (!(DBG & 2) || dbg_pro) { blds16(((k & 1) ? rq_a1 : rq_a0) + (unsigned)k * pitch8, ars, aq_dst + k * 1024u, aq_so); vm_note(1); }
     if (k == 3) {
       aq_slot ^= 1;
       aq_p = aq_p + 1 == nslab ? 0 : aq_p + 1;
       if (++aq_s == nslab) { aq_s = 0; aq_j++; { const int q_ = (g.dyn & 8) ? tq_read(aq_j) : 0; aq_t = (g.dyn & 1) ? q_ : aq_t + G; } ars = a_desc(aq_t); aq_p = 0; }
+      aq_dst = a_dst0 + (unsigned)aq_slot * S_ASLOT; aq_so = (unsigned)aq_p * 128u;
     }
     __builtin_amdgcn_sched_barrier(0);
   };
   // (a group has 15 pieces: wave w takes w, w + 4, w + 8, w + 12 -- wave 3 has three; its bookkeeping still runs at k == 3)
   auto w_piece = [&](auto ktag) __attribute__((always_inline)) {
     constexpr int k = decltype(ktag)::value;
-    const unsigned dst = w_dst0 + (unsigned)wq_buf * S_WGRP + k * 4096u;
-    const unsigned so = wq_so + (unsigned)wid * 1024u + k * 4096u;
-    if ((!(DBG & 4) || dbg_pro) && (k < 3 || wid < 3)) { blds16(rq_w, wrs, dst, so); vm_note(1); }
+    if ((!(DBG & 4) || dbg_pro) && (k < 3 || wid < 3)) { blds16(rq_w, wrs, wq_dst + k * 4096u, wq_sow + k * 4096u); vm_note(1); }
     if (k == 3) {
-      vc_later = 0;
+      vs_later = vc_ops;
       wq_buf = wq_buf == 2 ? 0 : wq_buf + 1;
       if (++wq_g == 3) { wq_g = 0; wq_p = wq_p + 1 == nslab ? 0 : wq_p + 1; }
       if (++wq_h == 3 * nslab) { wq_h = 0; wq_j++; { const int q_ = (g.dyn & 8) ? tq_read(wq_j) : 0; wq_t = (g.dyn & 1) ? q_ : wq_t + G; } wrs = w_desc(wq_t); wq_p = 0; wq_g = 0; }
       wq_so = (unsigned)wq_p * S_WSLAB + (unsigned)wq_g * S_WGRP;
+      wq_sow = wq_so + (unsigned)wid * 1024u; wq_dst = w_dst0 + (unsigned)wq_buf * S_WGRP;
     }
     __builtin_amdgcn_sched_barrier(0);
   };
@@ -264,7 +268,15 @@ __global__ __launch_bounds__(S_NTHR, 2) void k_gemm_split(const GemmSArgs g) {
 #undef RT_VW
     __builtin_amdgcn_sched_barrier(0);
   };
-  auto vm_wait = [&](int n) __attribute__((always_inline)) { vm_wait_n(n); vc_next = vc_later; };
+  // the wait that closes a weight group: everything issued after the last piece of the group it needs may stay in flight.  EXPECT =
+  // the count of the steady state at that site (one compare instead of the switch's tree)
+  auto vm_wait = [&](auto expect_tag) __attribute__((always_inline)) {
+    constexpr int EXPECT = decltype(expect_tag)::value;
+    const int n = vc_ops - vs_next;
+    if (n == EXPECT) { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(EXPECT) : "memory"); __builtin_amdgcn_sched_barrier(0); }
+    else vm_wait_n(n);
+    vs_next = vs_later;
+  };
 
   // ---- fragment side --------------------------------------------------------------------------------------------------------
   // pixels: lane (r, q) of row tile mt reads row 16 mt + r of the wave's rows, logical chunks q and 4 + q (k = 4 q .. + 3 and
@@ -344,6 +356,10 @@ __global__ __launch_bounds__(S_NTHR, 2) void k_gemm_split(const GemmSArgs g) {
   const bool st_on = ST && blockIdx.x == 7 && wid == (int)g.epi.am_tiles;
   unsigned long long st_c0 = 0, st_r0 = 0, st_a = 0, st_sum[4] = {0, 0, 0, 0};
   if (ST) { st_c0 = __builtin_amdgcn_s_memtime(); st_r0 = __builtin_amdgcn_s_memrealtime(); }
+  // DBG & 512: the same wave's time inside a step: fragment request + wait | request pieces | 12 MFMAs (+ woven VALU)
+  constexpr bool ST2 = ST && (DBG & 512) != 0;
+  unsigned long long st2_t = 0, st2_sum[4] = {0, 0, 0, 0};
+#define RT_ST2(i) do { if (ST2) { if (st_on) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); if (i) st2_sum[i] += n_ - st2_t; st2_t = n_; } __builtin_amdgcn_sched_barrier(0); } } while (0)
 #define RT_STA() do { if (ST) { if (st_on) st_a = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } } while (0)
 #define RT_STB(i) do { if (ST) { if (st_on) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); st_sum[i] += n_ - st_a; st_a = n_; } __builtin_amdgcn_sched_barrier(0); } } while (0)
   // ---- prologue ---------------------------------------------------------------------------------------------------------------
@@ -352,7 +368,7 @@ __global__ __launch_bounds__(S_NTHR, 2) void k_gemm_split(const GemmSArgs g) {
   a_issue();
   a_issue();
   dbg_pro = false;
-  vc_next = vc_later = 0;
+  vs_next = vs_later = vc_ops;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   auto split_into = [&](int mt, u32x4& h, u32x4& m, u32x4& l) __attribute__((always_inline)) {
@@ -374,7 +390,7 @@ __global__ __launch_bounds__(S_NTHR, 2) void k_gemm_split(const GemmSArgs g) {
   // Request schedule of a slab (at most one weight and one pixel piece per step): steps 0-3, 5-8, 10-13 the weights two groups
   // ahead (the ring buffer of the group the last barrier retired), steps 0-3 also the pixels two slabs ahead (the slot whose
   // fragments were read a slab ago).  The barrier that closes a group needs the weights of the next one, requested two groups
-  // earlier: everything issued since may stay in flight (vc_next).
+  // earlier: everything issued since may stay in flight.
   auto slab = [&](auto epi_tag, bool pend) __attribute__((always_inline)) {
     constexpr bool EPI = decltype(epi_tag)::value;
     unsigned wf = w_fr + (unsigned)wb * S_WGRP;
@@ -384,21 +400,25 @@ __global__ __launch_bounds__(S_NTHR, 2) void k_gemm_split(const GemmSArgs g) {
     // VALU work that rides along woven in, four instructions behind each MFMA: the epilogue chunk of the NEXT step's tile (whose
     // accumulators this step does not touch) and WORK (the split)
 #define RT_STEP_V(SL, nt, NOFF, REQ, WORK) do { \
+      RT_ST2(0); \
       read_b(IntTag<1 - SL>{}, IntTag<NOFF>{}, wf); \
       lgkm_wait<3>(); \
+      RT_ST2(1); \
       REQ; \
+      RT_ST2(2); \
       RT_SMF(SL, nt, EPI); \
       if (EPI && pend) epi_chunk(IntTag<(nt) + 1>{}); \
       WORK; \
       RT_WEAVE(); \
-      __builtin_amdgcn_sched_barrier(0); } while (0)
+      __builtin_amdgcn_sched_barrier(0); \
+      RT_ST2(3); } while (0)
 #define RT_STEP(SL, nt, NOFF, REQ) RT_STEP_V(SL, nt, NOFF, REQ, (void)0)
     // last step of a group: this tile's fragments are in registers; the next group's weights have landed (this wave's pieces:
     // vm_wait; everybody's: the barrier), its first fragments are requested, then the 12 MFMAs
-#define RT_LAST(SL, nt, REQ, WORK, STI) do { \
+#define RT_LAST(SL, nt, REQ, WORK, STI, VME) do { \
       RT_STA(); \
       lgkm_wait<0>(); \
-      vm_wait(vc_next); \
+      vm_wait(IntTag<VME>{}); \
       RT_STB(STI); \
       __builtin_amdgcn_s_barrier(); \
       __builtin_amdgcn_sched_barrier(0); \
@@ -423,25 +443,25 @@ __global__ __launch_bounds__(S_NTHR, 2) void k_gemm_split(const GemmSArgs g) {
     if (EPI && (g.dyn & 2)) {
       if (wid == 0) {
         if (lane_id() == 0) asm volatile("s_nop 4\n\tglobal_atomic_add %0, %1, %2, %3 sc0" : "=v"(fetched) : "v"(0u), "v"(1u), "s"(g.sched) : "memory");
-        vm_note(1); vc_at = 0;
+        vm_note(1); vs_at = vc_ops;
       }
       __builtin_amdgcn_sched_barrier(0);
     }
     if (EPI && pend) epi_chunk(IntTag<0>{});
     // ---- group 0: tiles 0..4
     RT_STEP(0, 0, 1 * 3072, RT_WA(0)); RT_STEP(1, 1, 2 * 3072, RT_WA(1)); RT_STEP(0, 2, 3 * 3072, RT_WA(2)); RT_STEP(1, 3, 4 * 3072, RT_WA(3));
-    RT_LAST(0, 4, (void)0, (void)0, 0);
+    RT_LAST(0, 4, (void)0, (void)0, 0, 8);
     // ---- group 1: tiles 5..9
     RT_STEP(1, 5, 1 * 3072, w_piece(IntTag<0>{})); RT_STEP(0, 6, 2 * 3072, w_piece(IntTag<1>{})); RT_STEP(1, 7, 3 * 3072, w_piece(IntTag<2>{}));
     RT_STEP(0, 8, 4 * 3072, w_piece(IntTag<3>{}));
     if (EPI && (g.dyn & 4)) {   // the next tile's id has returned (everything issued since may stay in flight)
       if (wid == 0) {
-        vm_wait_n(vc_at);
+        vm_wait_n(vc_ops - vs_at);
         if (lane_id() == 0) tq_write(tile_j + 1, G + (int)fetched);
       }
       __builtin_amdgcn_sched_barrier(0);
     }
-    RT_LAST(1, 9, (void)0, (void)0, 2);
+    RT_LAST(1, 9, (void)0, (void)0, 2, 5);
     // ---- group 2: tiles 10..14.  The next slab's pixels have landed: their request is older than the weights the barrier
     // above waited for (requested in this slab's first steps, behind them).
     read_raw2(a_slot ^ 1);
@@ -449,7 +469,7 @@ __global__ __launch_bounds__(S_NTHR, 2) void k_gemm_split(const GemmSArgs g) {
     RT_STEP_V(0, 10, 1 * 3072, w_piece(IntTag<0>{}), split_into(0, Nh[0], Nm[0], Nl[0]));
     RT_STEP_V(1, 11, 2 * 3072, w_piece(IntTag<1>{}), split_into(1, Nh[1], Nm[1], Nl[1]));
     RT_STEP(0, 12, 3 * 3072, w_piece(IntTag<2>{})); RT_STEP(1, 13, 4 * 3072, w_piece(IntTag<3>{}));
-    RT_LAST(0, 14, (void)0, (void)0, 2);
+    RT_LAST(0, 14, (void)0, (void)0, 2, 4);
 #undef RT_STEP
 #undef RT_STEP_V
 #undef RT_LAST
@@ -503,8 +523,10 @@ __global__ __launch_bounds__(S_NTHR, 2) void k_gemm_split(const GemmSArgs g) {
     unsigned long long* o = reinterpret_cast<unsigned long long*>(g.epi.am_max);
     o[0] = __builtin_amdgcn_s_memtime() - st_c0; o[1] = __builtin_amdgcn_s_memrealtime() - st_r0;
     for (int i = 0; i < 4; i++) o[2 + i] = st_sum[i];
+    for (int i = 0; i < 4; i++) o[1040 + i] = st2_sum[i];
   }
 #undef RT_STA
+#undef RT_ST2
 #undef RT_STB
 #undef RT_SMF
 }
@@ -575,18 +597,22 @@ void gemm_split(hipStream_t st, const float* A, int lda, long long M, int K, con
     static const int stat = getenv("RT_GS_STATIC") ? atoi(getenv("RT_GS_STATIC")) : 0;   // A/B: static tile lists
     g.dyn = stat ? 0 : 31;   // (bits: 1 ids from the queue, 2 atomic, 4 publish, 8 queue reads, 16 end-of-kernel counters)
   }
-  const int grid = std::min(g.n_rb * g.n_cb, 2 * stream_cus(st));   // two workgroups per CU
+  const int grid0 = std::min(g.n_rb * g.n_cb, 2 * stream_cus(st));   // two workgroups per CU
 #define RT_GS(ACTV, LABV) do { allow_big_lds((const void*)k_gemm_split<ACTV, LABV>, 160 * 1024); \
     RT_LAUNCH((k_gemm_split<ACTV, LABV>), dim3((unsigned)grid), dim3(S_NTHR), S_LDS, st, g); } while (0)
   static const int dbg = getenv("RT_GS_DBG") ? atoi(getenv("RT_GS_DBG")) : 0;   // timing experiments only (wrong results)
+  const int grid_env = getenv("RT_GS_GRID") ? atoi(getenv("RT_GS_GRID")) : 0;   // (experiments: e.g. 256 = one workgroup per CU)
+  const int grid = grid_env > 0 ? std::min(grid0, grid_env) : grid0;
   if (dbg & 256) {
     static unsigned long long* dst = nullptr;
     if (!dst) RT_HIP_CHECK(hipMalloc((void**)&dst, 64 + 16 * 1024));
     RT_HIP_CHECK(hipMemsetAsync(dst, 0, 64 + 16 * 1024, st));
     g.epi.am_max = reinterpret_cast<float*>(dst);
     g.epi.am_tiles = getenv("RT_GS_WAVE") ? atoi(getenv("RT_GS_WAVE")) : 0;
-    allow_big_lds((const void*)k_gemm_split<ACT_HSWISH, 1, 256>, 160 * 1024);
-    RT_LAUNCH((k_gemm_split<ACT_HSWISH, 1, 256>), dim3((unsigned)grid), dim3(S_NTHR), S_LDS, st, g);
+    if (dbg & 512) { allow_big_lds((const void*)k_gemm_split<ACT_HSWISH, 1, 768>, 160 * 1024);
+      RT_LAUNCH((k_gemm_split<ACT_HSWISH, 1, 768>), dim3((unsigned)grid), dim3(S_NTHR), S_LDS, st, g); }
+    else { allow_big_lds((const void*)k_gemm_split<ACT_HSWISH, 1, 256>, 160 * 1024);
+      RT_LAUNCH((k_gemm_split<ACT_HSWISH, 1, 256>), dim3((unsigned)grid), dim3(S_NTHR), S_LDS, st, g); }
     unsigned long long h[8 + 2048];
     RT_HIP_CHECK(hipMemcpyAsync(h, dst, sizeof(h), hipMemcpyDeviceToHost, st));
     RT_HIP_CHECK(hipStreamSynchronize(st));
@@ -603,6 +629,7 @@ void gemm_split(hipStream_t st, const float* A, int lda, long long M, int K, con
       fprintf(stderr, "gsplit blocks: occupancy API %d per CU; grid %d; span %.1f us; %d blocks started > 50 us after the first; block end min %.1f mean %.1f max %.1f us\n",
               occ, grid, (t1 - t0) / 100.0, late_start, mn, s_end / std::min(grid, 1024), mx);
     }
+    if (dbg & 512) fprintf(stderr, "gsplit step stamps: fragment request + wait %llu | request pieces %llu | MFMAs + woven work %llu cycles per launch\n", h[1041], h[1042], h[1043]);
     if (h[1]) fprintf(stderr, "gsplit wave %d of block 7: %llu cycles in %.1f us = %.3f GHz; per launch: mid wait %llu + barrier %llu, end wait %llu + barrier %llu cycles (%d slabs per tile)\n",
                       g.epi.am_tiles, h[0], h[1] / 100.0, h[0] / (h[1] * 10.0), h[2], h[3], h[4], h[5], g.nslab);
     return;
