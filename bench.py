@@ -475,8 +475,9 @@ def main():
             split_leg = {"value": round(n_my * 1000.0 / sp_ms * (world if dist_on else 1), 3), "unit": "images/s", "ms_per_step": round(sp_ms, 3),
                          "arithmetic": "fp32 operands split exactly into 3 bf16 terms each; 6 of the 9 bf16 x bf16 products (the dropped ones are below 2^-26 of "
                                        "the product) on v_mfma_f32_16x16x32_bf16 with fp32 accumulation",
-                         "layers": "the 5 wide pointwise convs of the rec network without a squeeze-excite operand (4 x 1230432x240x240-class, "
-                                   "2 x 307608x480x480-class, 1 x 1230432x128x240-class at C3 size, minus the two `+se` launches, which stay on k_gemm32p)",
+                         "layers": "the 7 wide pointwise convs of the rec network (k_gemm32p's: 4 x 1230432x240x240, 2 x 307608x480x480, 1 x 1230432x128x240 "
+                                   "at C3 size and the two squeeze-excite launches 615216x480x480 / x240x480, whose per-image scale multiplies the fp32 pixel "
+                                   "operand before it is split)",
                          "note": "opt-in (RT_GEMM_SPLIT=1 / rt_debug_set_variants bit 12); `value`, `dtype` and `roofline` are the fp32-MFMA kernels"}
         finally:
             lib.rt_debug_set_variants(vv[0], vv[1], vv[2])

@@ -59,6 +59,10 @@ __device__ __forceinline__ void blds16(unsigned voff, __amdgpu_buffer_rsrc_t rs,
   asm volatile("s_nop 4\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %3 offen lds" ::"v"(voff), "s"(rs), "s"(lds_sgpr), "s"(soff) : "memory", "m0");
 }
 #pragma clang diagnostic pop
+// 4-byte form: lane i writes one dword at M0 + 4 i (the squeeze-excite scale vectors of a slab: 2 images x 32 channels per instruction)
+__device__ __forceinline__ void blds4(unsigned voff, __amdgpu_buffer_rsrc_t rs, unsigned lds_sgpr) {
+  asm volatile("s_nop 4\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dword %0, %1, 0 offen lds" ::"v"(voff), "s"(rs), "s"(lds_sgpr) : "memory", "m0");
+}
 __device__ __forceinline__ unsigned lds_addr32(const void* p) { return (unsigned)(size_t)(__attribute__((address_space(3))) const char*)p; }
 #pragma clang diagnostic pop
 template <int OFF>
@@ -112,7 +116,8 @@ constexpr unsigned S_ASLOT = S_NW * S_AWAVE;                    // 16 KB
 constexpr unsigned S_OFF_W = 2 * S_ASLOT, S_OFF_BIAS = S_OFF_W + 3 * S_WGRP;
 constexpr int S_BIAS_MAX = 240;                                 // one column block's bias (restaged per tile)
 constexpr unsigned S_OFF_TQ = S_OFF_BIAS + S_BIAS_MAX * 4;      // ids of the workgroup's tiles j, j + 1, ... (slot j & 3)
-constexpr size_t S_LDS = S_OFF_TQ + 16;           // 32 KB pixels | 45 KB weights | bias | tile ids = 79824 bytes: two workgroups per CU
+constexpr unsigned S_OFF_SC = S_OFF_TQ + 16;                     // ASC: scale vectors of two slabs in flight, [slot][2 images][32] floats
+constexpr size_t S_LDS = S_OFF_TQ + 16, S_LDS_ASC = S_OFF_SC + 512;           // 32 KB pixels | 45 KB weights | bias | tile ids = 79824 bytes: two workgroups per CU
 
 struct GemmSArgs {
   const float* A; const unsigned short* Ws; float* C;
@@ -120,6 +125,10 @@ struct GemmSArgs {
   int lda, nslab, N, ldc, coff;
   int n_rb, n_cb;
   int dyn;           // 1: tile ids from the queue; 2 (debugging): the queue runs, the ids stay static
+  // ASC (squeeze-excite scale folded into the pixel operand): row m of image i is multiplied by a_scale[i * ld_scale + k] before
+  // it is split.  a_tab: per 256-row block {image of its first row, first row of the next image, of the one after} (stride 3,
+  // what k_gemm32p+se reads) or per 128-row block {image, first row of the next image} (stride 2); every image has >= 128 rows.
+  const float* a_scale; const int* a_tab; int ld_scale, n_img, tab_stride, K;
   unsigned* sched;   // [0] tiles handed out beyond the workgroups' first ones, [1] workgroups done; zero between launches
   Epilogue epi;
 };
@@ -152,7 +161,7 @@ __global__ void k_split_pack(const float* __restrict__ Wp, int nslab, int Npad, 
 
 // DBG (timing experiments, wrong results): 1 no stores, 2 no pixel requests after the prologue, 4 no weight requests after it,
 // 8 no split arithmetic, 16 no MFMAs
-template <int ACT, int LAB, int DBG = 0>
+template <int ACT, int LAB, int DBG = 0, bool ASC = false>
 __global__ __launch_bounds__(S_NTHR, 2) void k_gemm_split(const GemmSArgs g) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_s[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -215,6 +224,29 @@ __global__ __launch_bounds__(S_NTHR, 2) void k_gemm_split(const GemmSArgs g) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(g.Ws + (long long)cb * nslab * (S_WSLAB / 2)), 0, live ? 0x7fffffffu : 0u, 0x00020000);
   };
   __amdgpu_buffer_rsrc_t ars = a_desc(aq_t), wrs = w_desc(wq_t);
+  // ASC: image of a tile's first row and the tile-relative row at which the next image begins (a 128-row tile meets at most two
+  // images: every image has >= 128 rows).  The scale vectors of a slab (2 images x 32 channels = 256 bytes) are requested by
+  // wave 0 with the slab's pixels, one 4-byte-per-lane instruction, into the slot of the pixel ring's parity.
+  int sc_img = 0, sc_bnd[2] = {0x7fffffff, 0x7fffffff};   // of the request stream's tile; boundary by ring slot (read when that slab is split)
+  auto tile_images = [&](int t, int* img, int* bnd) __attribute__((always_inline)) {
+    *img = 0; *bnd = 0x7fffffff;
+    if (ASC && t < n_tiles) {
+      const int rb = t / g.n_cb;
+      const long long m0 = (long long)rb * S_BM;
+      if (g.tab_stride == 2) { *img = g.a_tab[2 * rb]; const long long b1 = g.a_tab[2 * rb + 1]; *bnd = (int)min(0x7fffffffll, max(0ll, b1 - m0)); }
+      else {
+        const int* e = g.a_tab + 3 * (rb >> 1);
+        const long long b1 = e[1], b2 = e[2];
+        *img = e[0] + (m0 >= b1 ? 1 : 0) + (m0 >= b2 ? 1 : 0);
+        const long long nb = m0 < b1 ? b1 : (m0 < b2 ? b2 : 0x7fffffffll + m0);
+        *bnd = (int)min(0x7fffffffll, nb - m0);
+      }
+    }
+  };
+  int sc_bnd_t = 0x7fffffff;
+  if (ASC) tile_images(aq_t, &sc_img, &sc_bnd_t);
+  const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ASC ? g.a_scale : g.A), 0, ASC ? (unsigned)g.n_img * (unsigned)g.ld_scale * 4u : 0u, 0x00020000);
+  const unsigned sc_dst0 = lds_b + S_OFF_SC;
   const unsigned a_dst0 = lds_b + (unsigned)wid * S_AWAVE, w_dst0 = lds_b + S_OFF_W + (unsigned)wid * 1024u;
   // Requests go out ONE PIECE PER MFMA STEP, not as a burst behind the barrier: an LDS-DMA instruction holds the issuing wave for
   // 60-180 cycles, the two waves of a SIMD leave a barrier together, and seven requests each right there are ~1000 cycles in
@@ -233,10 +265,19 @@ __global__ __launch_bounds__(S_NTHR, 2) void k_gemm_split(const GemmSArgs g) {
   auto a_piece = [&](auto ktag) __attribute__((always_inline)) {
     constexpr int k = decltype(ktag)::value;
     if (!(DBG & 2) || dbg_pro) { blds16(((k & 1) ? rq_a1 : rq_a0) + (unsigned)k * pitch8, ars, aq_dst + k * 1024u, aq_so); vm_note(1); }
+    if (ASC && k == 0) {
+      sc_bnd[aq_slot] = sc_bnd_t;
+      if (wid == 0) {   // lane i: image sc_img + i / 32 (clamped), channel 32 slab + i % 32 (beyond K: out of range, zero)
+        const int kk = aq_p * 32 + (lane & 31);
+        const int im = min(sc_img + (lane >> 5), g.n_img - 1);
+        const unsigned off = kk < g.K ? (unsigned)(im * g.ld_scale + kk) * 4u : 0x80000000u;
+        blds4(off, srs, sc_dst0 + (unsigned)aq_slot * 256u); vm_note(1);
+      }
+    }
     if (k == 3) {
       aq_slot ^= 1;
       aq_p = aq_p + 1 == nslab ? 0 : aq_p + 1;
-      if (++aq_s == nslab) { aq_s = 0; aq_j++; { const int q_ = (g.dyn & 8) ? tq_read(aq_j) : 0; aq_t = (g.dyn & 1) ? q_ : aq_t + G; } ars = a_desc(aq_t); aq_p = 0; }
+      if (++aq_s == nslab) { aq_s = 0; aq_j++; { const int q_ = (g.dyn & 8) ? tq_read(aq_j) : 0; aq_t = (g.dyn & 1) ? q_ : aq_t + G; } ars = a_desc(aq_t); aq_p = 0; if (ASC) tile_images(aq_t, &sc_img, &sc_bnd_t); }
       aq_dst = a_dst0 + (unsigned)aq_slot * S_ASLOT; aq_so = (unsigned)aq_p * 128u;
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -371,13 +412,20 @@ __global__ __launch_bounds__(S_NTHR, 2) void k_gemm_split(const GemmSArgs g) {
   vs_next = vs_later = vc_ops;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  auto split_into = [&](int mt, u32x4& h, u32x4& m, u32x4& l) __attribute__((always_inline)) {
+  const float* sc_lds = reinterpret_cast<const float*>(smem_s + S_OFF_SC);
+  auto split_into = [&](int mt, u32x4& h, u32x4& m, u32x4& l, int slot) __attribute__((always_inline)) {
+    if (ASC) {   // the slab's scale vector of this lane's row's image: channels 4 q .. + 3 and 16 + 4 q .. + 3
+      const int row = 32 * wid + 16 * mt + r;
+      const float* t = sc_lds + slot * 64 + (row >= sc_bnd[slot] ? 32 : 0) + 4 * q;
+      raw[mt][0] *= *reinterpret_cast<const f32x4*>(t);
+      raw[mt][1] *= *reinterpret_cast<const f32x4*>(t + 16);
+    }
     if (DBG & 8) { h = __builtin_bit_cast(u32x4, raw[mt][0]); m = __builtin_bit_cast(u32x4, raw[mt][1]); l = h ^ m; }
     else split8(raw[mt][0], raw[mt][1], h, m, l);
   };
   read_raw2(0);
-  split_into(0, Ah[0], Am[0], Al[0]);
-  split_into(1, Ah[1], Am[1], Al[1]);
+  split_into(0, Ah[0], Am[0], Al[0], 0);
+  split_into(1, Ah[1], Am[1], Al[1], 0);
   read_b(IntTag<0>{}, IntTag<0>{}, w_fr);
   __builtin_amdgcn_sched_barrier(0);
   int a_slot = 0;   // ring slot of the current slab's pixels
@@ -466,8 +514,8 @@ __global__ __launch_bounds__(S_NTHR, 2) void k_gemm_split(const GemmSArgs g) {
     // above waited for (requested in this slab's first steps, behind them).
     read_raw2(a_slot ^ 1);
     __builtin_amdgcn_sched_barrier(0);
-    RT_STEP_V(0, 10, 1 * 3072, w_piece(IntTag<0>{}), split_into(0, Nh[0], Nm[0], Nl[0]));
-    RT_STEP_V(1, 11, 2 * 3072, w_piece(IntTag<1>{}), split_into(1, Nh[1], Nm[1], Nl[1]));
+    RT_STEP_V(0, 10, 1 * 3072, w_piece(IntTag<0>{}), split_into(0, Nh[0], Nm[0], Nl[0], a_slot ^ 1));
+    RT_STEP_V(1, 11, 2 * 3072, w_piece(IntTag<1>{}), split_into(1, Nh[1], Nm[1], Nl[1], a_slot ^ 1));
     RT_STEP(0, 12, 3 * 3072, w_piece(IntTag<2>{})); RT_STEP(1, 13, 4 * 3072, w_piece(IntTag<3>{}));
     RT_LAST(0, 14, (void)0, (void)0, 2, 4);
 #undef RT_STEP
@@ -535,7 +583,9 @@ __global__ __launch_bounds__(S_NTHR, 2) void k_gemm_split(const GemmSArgs g) {
 int g_gemm_split = getenv("RT_GEMM_SPLIT") ? atoi(getenv("RT_GEMM_SPLIT")) : 0;   // opt-in (RT_GEMM_SPLIT=1 / rt_debug_set_variants): gemm() takes the split-bf16 kernel where it applies
 
 bool gemm_split_supported(int lda, long long M, int K, int N, int Npad16, const Epilogue& epi) {
-  if (epi.am_max || epi.residual || epi.a_scale) return false;
+  if (epi.am_max || epi.residual) return false;
+  // squeeze-excite scale: a row-block table of either form, hardswish epilogue, images of >= 128 rows (what gemm_se_tile_rows() > 0 says)
+  if (epi.a_scale && (!epi.a_tab || (epi.a_tab_stride != 2 && epi.a_tab_stride != 3) || epi.act != ACT_HSWISH || epi.n_img <= 0 || epi.ld_scale < K)) return false;
   if (Npad16 != N || N % S_BN != 0 || N > 960) return false;
   if (lda < round_up(K, KC) || (lda & 3)) return false;          // whole 32-deep slabs readable (padding channels hold zeros)
   if ((long long)lda * 4 * 32 >= (1ll << 31)) return false;
@@ -584,6 +634,7 @@ void gemm_split(hipStream_t st, const float* A, int lda, long long M, int K, con
   GemmSArgs g;
   g.A = A; g.C = C; g.M = M; g.lda = lda; g.nslab = (K + KC - 1) / KC; g.N = N; g.ldc = ldc; g.coff = coff;
   g.n_rb = (int)((M + S_BM - 1) / S_BM); g.n_cb = N / S_BN; g.epi = epi;
+  g.a_scale = epi.a_scale; g.a_tab = epi.a_tab; g.ld_scale = epi.ld_scale; g.n_img = epi.n_img; g.tab_stride = epi.a_tab_stride; g.K = K;
   g.Ws = split_pack_of(st, Wp, g.nslab, Npad16, g.n_cb);
   {
     int dev = 0;
@@ -640,6 +691,13 @@ void gemm_split(hipStream_t st, const float* A, int lda, long long M, int K, con
     switch (dbg) { RT_GSD(1) RT_GSD(2) RT_GSD(4) RT_GSD(6) RT_GSD(8) RT_GSD(7) RT_GSD(24) RT_GSD(25) RT_GSD(26) RT_GSD(28) RT_GSD(30) RT_GSD(94) RT_GSD(158) RT_GSD(64) RT_GSD(128)
       default: throw RtError(8, "gemm_split: unknown RT_GS_DBG"); }
 #undef RT_GSD
+    return;
+  }
+  if (epi.a_scale) {
+#define RT_GSE(LABV) do { allow_big_lds((const void*)k_gemm_split<ACT_HSWISH, LABV, 0, true>, 160 * 1024); \
+    RT_LAUNCH((k_gemm_split<ACT_HSWISH, LABV, 0, true>), dim3((unsigned)grid), dim3(S_NTHR), S_LDS_ASC, st, g); } while (0)
+    if (epi.has_lab) RT_GSE(1); else RT_GSE(0);
+#undef RT_GSE
     return;
   }
   if (epi.act == ACT_HSWISH && epi.has_lab) RT_GS(ACT_HSWISH, 1);

@@ -276,14 +276,15 @@ def test_server_rec_net_full_batch(hip_server, server_models):
 
 
 def test_c5_full_size_properties(hip_server, models, server_models):
-    """BASELINE config 5 at its per-GPU size (32 pages of 960 x 960, 32 planted lines each, PP-OCRv4 server graphs in fp16,
-    3 lanes) through size-independent properties, the fp16 counterpart of test_c3_full_size_properties:
+    """BASELINE config 5 at its per-GPU size (1024 pages / 8 GPUs = 128 pages of 960 x 960 in ONE batch -- the dispatch sizes a
+    `bench.py --workload c5` step produces --, 32 planted lines each, PP-OCRv4 server graphs in fp16, 3 lanes) through
+    size-independent properties, the fp16 counterpart of test_c3_full_size_properties:
     (1) batch / lane / order composition does not change a page's discrete results -- the batch equals the same pages
         shuffled and pages run alone: boxes, box scores, cls labels and token ids bit for bit; line / label scores equal to the
         fp16 tolerance (a page alone runs other kernel shapes: tile sizes follow the launch size);
     (2) two pages of the batch equal the oracle pipeline teacher-forced by the fp16 worker in the reference's batches of 6;
     (3) the planted lines come back: 32 boxes per page, each inside its planted rectangle grown by the unclip offset."""
-    n = 32
+    n = 128
     pages, maps, rects = [], [], []
     for i in range(n):
         page, rc = workload.planted_page(960, 960, 32, seed=100 + i)
@@ -310,7 +311,7 @@ def test_c5_full_size_properties(hip_server, models, server_models):
     from oracle.pipeline import OracleSession
     o = OracleSession(*(models[:3] + (server_models[3],)))   # the oracle's own nets are unused: all three workers are replaced
     o.det_worker, o.cls_worker, o.rec_worker = hip_server.worker.det, hip_server.worker.cls, hip_server.worker.rec
-    for j in (0, 21):
+    for j in (0, 21, 100):
         ref = o.run(pages[j], det_map_override=maps[j])
         assert len(ref.det_boxes) == 32
         assert np.array_equal(np.stack([d.boxes.as_array() for d in full[j].det_result]), ref.det_boxes)
@@ -326,7 +327,7 @@ def test_c5_full_size_properties(hip_server, models, server_models):
     again = hip_server.run_batch(pages, det_map_override=maps)      # the same call twice: bit-identical (no races in the LDS-DMA kernels)
     for a, b in zip(again, full):
         same(a, b, strict=True)
-    for j in (0, 9, 31):
+    for j in (0, 9, 31, 127):
         alone = hip_server.run_batch([pages[j]], det_map_override=[maps[j]])[0]
         same(alone, full[j], strict=False)
     for r, rc in zip(full, rects):

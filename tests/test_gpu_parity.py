@@ -131,7 +131,7 @@ def test_split_bf16_gemm_error_against_fp64(hip_session, M, K, N):
 @pytest.mark.parametrize("n,w", [(120, 400), (1000, 96), (130, 412)])
 def test_rec_net_split_bf16(hip_session, oracle_session, n, w):
     """test_rec_net's production-size cases with the split-bf16 kernels switched in (the 240- / 480-channel pointwise convs of
-    >= 32768 rows without a squeeze-excite operand): the SAME bars -- <= 2e-4 on the softmax output against the torch fp32
+    >= 32768 rows, the two squeeze-excite layers included -- [1000-96]: 144-row lines, 128-row tiles that span two lines): the SAME bars -- <= 2e-4 on the softmax output against the torch fp32
     oracle, argmax exact wherever the oracle's top-2 margin exceeds 1e-4."""
     lib = hip_session._hd.lib
     x = np.random.default_rng(w).uniform(-1, 1, (n, 3, 48, w)).astype(np.float32)
