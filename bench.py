@@ -512,6 +512,22 @@ def main():
         lib.rt_synchronize(h)
         prof_nets = {name: v for name, v in sess.profile_get().items() if name.startswith("net/")}
         sess.profile_enable(False)
+        # the same serial pass with the split-bf16 kernels on: launch times of the two families of the opt-in leg
+        prof_split = {}
+        if split_leg:
+            vv = [int(v) for v in a.variants.split(',')] if a.variants else [0, 0, 0]
+            lib.rt_debug_set_variants(vv[0], vv[1], vv[2] | 4096)
+            try:
+                step()
+                sess.profile_enable(True)
+                lib.rt_synchronize(h)
+                for _ in range(psteps):
+                    step()
+                lib.rt_synchronize(h)
+                prof_split = {name: v for name, v in sess.profile_get().items() if name.startswith("gemm_pw/") or name == "net/rec"}
+                sess.profile_enable(False)
+            finally:
+                lib.rt_debug_set_variants(vv[0], vv[1], vv[2])
         lib.rt_set_lanes(h, 1 << 20)
     if dist_on:
         t = torch.tensor([elapsed], dtype=torch.float64, device=tdev)
@@ -592,6 +608,23 @@ def main():
                 wk["flops"] / per_step_ms / 1e9 if per_step_ms else 0), file=sys.stderr)
         print("sum of kernel families: %.2f ms/step; serial wall %.2f ms/step; production wall %.2f ms/step" % (
             total_ms / psteps, serial_ms, ms_per_step), file=sys.stderr)
+    if split_leg and rank == 0 and prof_split:
+        # the pointwise-conv GEMM families of the rec / det networks in the two serial passes: fp32-MFMA kernels vs split-bf16 on
+        def gemm_rows(pr):
+            return {name: {"ms_per_step": round(v[0] / psteps, 3), "launches_per_step": v[1] / psteps, "avg_launch_ms": round(v[0] / v[1], 4)}
+                    for name, v in sorted(pr.items()) if name.startswith("gemm_pw/") and v[1]}
+        f32_rows, sp_rows = gemm_rows(prof), gemm_rows(prof_split)
+        moved = [n for n in f32_rows if n not in sp_rows or abs(f32_rows[n]["launches_per_step"] - sp_rows[n]["launches_per_step"]) > 1e-9]
+        wk_f = sum(work[n]["flops"] for n in moved if n in work); wk_b = sum(work[n]["bytes"] for n in moved if n in work)
+        t_f32 = sum(f32_rows[n]["ms_per_step"] for n in moved) - sum(sp_rows[n]["ms_per_step"] for n in moved if n in sp_rows)
+        t_sp = sum(v["ms_per_step"] for n, v in sp_rows.items() if "k_gemm_split" in n)
+        split_leg["kernels"] = {"fp32_mfma_pass": f32_rows, "split_pass": sp_rows,
+                                "layers_moved_ms_per_step": {"fp32_mfma": round(t_f32, 3), "split_bf16": round(t_sp, 3)},
+                                "split_fp32_equivalent_tflops": round(wk_f / (t_sp * 1e-3) / 1e12, 1) if t_sp and wk_f else None,
+                                "split_algorithmic_gbs": round(wk_b / (t_sp * 1e-3) / 1e9, 1) if t_sp and wk_b else None,
+                                "measured": "HIP events, serial passes (lanes=1) of %d steps: default kernels | split kernels on" % psteps}
+        if "net/rec" in prof_split and prof_split["net/rec"][1]:
+            split_leg["rec_net_ms"] = round(prof_split["net/rec"][0] / psteps, 3)
     roofline = None
     for ms, calls, name in fams:
         if name in work:

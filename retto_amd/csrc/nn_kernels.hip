@@ -745,9 +745,9 @@ static int gemm_dispatch(long long M, int Npad16) {
 // Profiler label of a pointwise-conv GEMM: family + the kernel symbol the dispatcher picks, so the
 // per-kernel numbers of bench.py can be compared with rocprofv3's kernel stats one to one.
 const char* gemm_pw_label(long long M, int Npad16, bool a_scale, int se_tile_rows) {
+  if (!g_gemm_variant && g_gemm_split && Npad16 % 240 == 0 && M >= 32768 && (!a_scale || se_tile_rows > 0)) return a_scale ? "gemm_pw/k_gemm_split+se" : "gemm_pw/k_gemm_split";   // (K > 96 is what the rec net's layers have)
   if (a_scale && se_tile_rows == 256) return "gemm_pw/k_gemm32p+se";
   if (a_scale && !g_gemm_variant) return gemm_dispatch(M, Npad16) == 0 ? "gemm_pw/k_gemm_wide<2,4,4,2>+se" : "gemm_pw/k_gemm_wide<2,5,4,3>+se";
-  if (!g_gemm_variant && g_gemm_split && Npad16 % 240 == 0 && M >= 32768 && (!a_scale || se_tile_rows > 0)) return a_scale ? "gemm_pw/k_gemm_split+se" : "gemm_pw/k_gemm_split";   // (K > 96 is what the rec net's layers have)
   switch (g_gemm_variant ? -1 : gemm_dispatch(M, Npad16)) {
     case 15: return g_gemm_dma ? "gemm_pw/k_gemm32p" : "gemm_pw/k_gemm_wide<4,5,4,3>";
     case 10: return "gemm_pw/k_gemm_wide<2,5,4,3>";

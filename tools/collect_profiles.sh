@@ -25,6 +25,8 @@ rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/det_write -o w -- python3
 python3 tools/pmc_det_bytes.py $out/det_fetch/f_counter_collection.csv $out/det_write/w_counter_collection.csv $out/pmc_det_c3.json > $out/pmc_det.txt 2>&1
 RT_PROFILE_DETAIL=1 python3 tools/layer_profile.py 32 3 > $out/c3_layers.txt 2>&1
 RT_PROFILE_DETAIL=1 python3 tools/layer_profile.py 32 3 0 > $out/c3_det_layers.txt 2>&1
+RT_GEMM_SPLIT=1 RT_PROFILE_DETAIL=1 python3 tools/layer_profile.py 32 3 > $out/c3_layers_split.txt 2>&1   # (round 6: the opt-in split-bf16 kernels)
+SHAPES=1230432x240x240,307608x480x480,1230432x128x240 ITERS=10 python3 tools/bench_gemm_split.py 30 40 > $out/gemm_split.txt 2>&1
 WORKLOAD=c5 RT_PROFILE_DETAIL=1 python3 tools/layer_profile.py 32 3 > $out/c5_layers.txt 2>&1
 cp $out/c3_trace/t_kernel_stats.csv $out/c3_kernel_stats.csv 2>/dev/null
 cp $out/c5_trace/t_kernel_stats.csv $out/c5_kernel_stats.csv 2>/dev/null

@@ -50,11 +50,13 @@ LABELS = {"gemm_pw/k_gemm32p": "family:gemm32p", "gemm_pw/k_gemm32p+se": "family
           "gemm_pw/k_gemm_wide<4,5,4,3>": "k_gemm_wide<4, 5, 4, 3, 0, 0, 0, 0, 0>",
           "gemm_pw/k_gemm_wide<2,5,4,3>+se": "k_gemm_wide<2, 5, 4, 3, 0, 0, 1, 0, 0>",
           "gemm_pw/k_gemm_wide<2,4,4,2>": "k_gemm_wide<2, 4, 4, 2, 0, 0, 0, 0, 0>",
+          "gemm_pw/k_gemm_split": "family:gemm_split", "gemm_pw/k_gemm_split+se": "family:gemm_split_se",
           "conv16_3x3": "family:conv16_3x3", "gemm16": "family:gemm16", "conv16_9x9": "family:conv16_9x9"}
 # fp16 families that several template instances serve: their "family:<name>" entry is the launch-weighted mean over the
 # member kernels (traffic per launch) and the cycle-weighted MFMA utilisation.  (The 3x3 family's few register-staged
 # launches -- the 3-channel stems -- run k_conv16 instances shared with other families and are left out.)
 FAMILIES = {"gemm32p": r"k_gemm32p<-?\d+, -?\d+, (true|false), 0, false>", "gemm32p_se": r"k_gemm32p<-?\d+, -?\d+, (true|false), 0, true>",   # (fp32: the persistent LDS-DMA wide GEMM, K = 32 j and K = 32 j + 16 instances)
+            "gemm_split": r"k_gemm_split<-?\d+, -?\d+, 0, false>", "gemm_split_se": r"k_gemm_split<-?\d+, -?\d+, 0, true>",   # (round 6, opt-in leg: split-bf16 form of the same layers)
             "conv16_3x3": r"k_conv16v2<\d, (3, 3|9, 3)(, 0)?(, \d)?(, (true|false))?>", "gemm16": r"k_gemm16p?<", "conv16_9x9": r"k_conv16v2<2, 9, 9(, 0)?(, \d)?(, (true|false))?>"}
 
 
