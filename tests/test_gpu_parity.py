@@ -152,6 +152,39 @@ def test_rec_net_split_bf16(hip_session, oracle_session, n, w):
     assert decisive.mean() > 0.9
 
 
+def test_pipeline_split_bf16_equals_fp32_mfma_pipeline(hip_session):
+    """A C3-shaped batch (8 pages of 960 x 960, 32 planted lines each: 98 k rows at the 240-channel stages per lane part, above the
+    split kernels' 32768-row threshold) through rt_run_batch with the split-bf16 kernels on and off: boxes, labels and every
+    line's token ids identical, line scores within 1e-5 (the two forms differ in the order of an fp32 summation, nothing else)."""
+    lib = hip_session._hd.lib
+    pages, maps = [], []
+    for i in range(8):
+        page, rects = workload.planted_page(960, 960, 32, seed=500 + i)
+        pages.append(page); maps.append(workload.planted_map(960, 960, 960, 960, rects))
+    lib.rt_set_lanes(hip_session._hd.h, 1)      # one lane: the whole batch in one launch series (the split kernels' sizes)
+    try:
+        base = hip_session.run_batch(pages, det_map_override=maps)
+        lib.rt_debug_set_variants(0, 0, 4096)
+        try:
+            got = hip_session.run_batch(pages, det_map_override=maps)
+        finally:
+            lib.rt_debug_set_variants(0, 0, 0)
+    finally:
+        lib.rt_set_lanes(hip_session._hd.h, 1 << 20)
+    n_lines, worst = 0, 0.0
+    for b, g in zip(base, got):
+        assert len(b.det_result) == len(g.det_result) == 32
+        assert np.array_equal(np.stack([d.boxes.as_array() for d in b.det_result]), np.stack([d.boxes.as_array() for d in g.det_result]))
+        assert [c.label.label for c in b.cls_result] == [c.label.label for c in g.cls_result]
+        for x, y in zip(b.rec_result, g.rec_result):
+            assert np.array_equal(x.tokens, y.tokens) and x.text == y.text
+            if x.score == x.score:
+                worst = max(worst, abs(x.score - y.score))
+            n_lines += 1
+    assert n_lines == 256 and worst <= 1e-5, worst
+    assert any(not (x.score == y.score) for b, g in zip(base, got) for x, y in zip(b.rec_result, g.rec_result) if x.score == x.score)   # the split kernels did run
+
+
 # ---------------------------------------------------------------- a2 / a3 preprocessing
 @pytest.mark.parametrize("h,w", [(640, 640), (96, 160), (2100, 1300), (20, 300), (50, 200)])
 def test_resize_both(hip_session, h, w):
