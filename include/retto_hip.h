@@ -191,7 +191,7 @@ RT_API int rt_run_batch_stream(rt_session* s, const uint8_t* const* rgb, const i
  * unchanged until rt_wait_batch has returned for that ticket.  Every ticket must be waited for exactly once (any order); until
  * then every other call on the session except rt_submit_batch / rt_wait_batch fails with RT_ERR_INVALID.  rt_wait_batch of a
  * failed batch returns the failing stage's status (the other batches in flight are not affected). */
-#define RT_MAX_INFLIGHT 4
+#define RT_MAX_INFLIGHT 8   /* (a cap on queued tickets only: a lane works on one part at a time, whatever is queued behind it) */
 typedef struct rt_ticket rt_ticket;
 RT_API int rt_submit_batch(rt_session* s, const uint8_t* const* rgb, const int* hs, const int* ws, int n_pages, int mem,
                            const float* const* det_map_override, rt_ticket** out);

@@ -18,7 +18,7 @@ from typing import Callable, List, Optional, Sequence, Union
 import numpy as np
 
 from . import _lib
-from ._lib import Config, ModelSource, RT_MEM_DEVICE, RT_MEM_HOST, RT_MEM_HOST_MAPS_DEVICE
+from ._lib import Config, ModelSource, RT_MEM_DEVICE, RT_MEM_HOST, RT_MEM_HOST_MAPS_DEVICE, RT_MAX_INFLIGHT
 
 
 # ---- errors (error.rs:2-21) ------------------------------------------------------------
@@ -407,7 +407,7 @@ class RettoSession:
     def submit_batch_raw(self, pages, hs, ws, mem=RT_MEM_HOST, det_map_override=None):
         """rt_submit_batch (the counterpart of RettoSession::run_stream's worker thread, session.rs:108-143): the batch is
         split over the session's lanes and this returns at once with a ticket; wait_batch_raw(ticket) gives the results
-        handle.  Up to RT_MAX_INFLIGHT (4) batches ahead; nothing else may be called on the session in between."""
+        handle.  Up to RT_MAX_INFLIGHT (8) batches ahead; nothing else may be called on the session in between."""
         return self.run_batch_raw(pages, hs, ws, mem, det_map_override, submit=True)
 
     def wait_batch_raw(self, ticket):

@@ -14,6 +14,7 @@ LIB_PATH = os.path.join(_HERE, "libretto_hip.so")
 
 RT_OK = 0
 RT_MEM_HOST, RT_MEM_DEVICE, RT_MEM_HOST_MAPS_DEVICE = 0, 1, 2
+RT_MAX_INFLIGHT = 8   # include/retto_hip.h
 RT_DTYPE_F32, RT_DTYPE_F16 = 0, 1
 STATUS_NAMES = {0: "OK", 1: "IOError", 2: "ImageError", 3: "ShapeError", 4: "BackendError", 5: "Utf8Error",
                 7: "ModelNotFoundError", 8: "InvalidArgument", 9: "CapacityError"}

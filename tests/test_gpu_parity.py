@@ -152,6 +152,25 @@ def test_rec_net_split_bf16(hip_session, oracle_session, n, w):
     assert decisive.mean() > 0.9
 
 
+def test_rec_net_split_bf16_is_repeatable(hip_session):
+    """Race screen for the hand-kept vmcnt bookkeeping of k_gemm_split (run-time counts of the operations that may stay in flight at
+    every barrier wait, a dynamic tile queue, LDS-DMA rings): a fragment read that overtakes its request, or a request that
+    overwrites a ring slot still being read, shows up as run-to-run differences long before it shows up against a tolerance.
+    Many tiles per workgroup (410 k rows at the 240-channel stages), the same launch series eight times: bit-identical."""
+    lib = hip_session._hd.lib
+    x = np.random.default_rng(77).uniform(-1, 1, (340, 3, 48, 400)).astype(np.float32)
+    x[:, :, :, 300:] = 0.0
+    lib.rt_debug_set_variants(0, 0, 4096)
+    try:
+        first = hip_session.worker.rec(x)
+        for _ in range(7):
+            again = hip_session.worker.rec(x)
+            assert np.array_equal(first.view(np.uint32), again.view(np.uint32))
+    finally:
+        lib.rt_debug_set_variants(0, 0, 0)
+    assert np.isfinite(first).all()
+
+
 def test_pipeline_split_bf16_equals_fp32_mfma_pipeline(hip_session):
     """A C3-shaped batch (8 pages of 960 x 960, 32 planted lines each: 98 k rows at the 240-channel stages per lane part, above the
     split kernels' 32768-row threshold) through rt_run_batch with the split-bf16 kernels on and off: boxes, labels and every
@@ -1091,10 +1110,10 @@ def test_submit_wait_failed_batch_does_not_poison_the_session():
 
 
 def test_submit_ahead_at_the_cap_with_a_failing_submission():
-    """C2's default depth: RT_MAX_INFLIGHT (4) one-page submissions in flight, the page of the SECOND one is empty (ImageError on
-    the lane that gets it).  Its ticket returns that error; the submissions behind it (slots 3 and 4) complete with the results
-    of a synchronous call; a fifth submission while four are in flight is refused without disturbing them; the cap is not
-    leaked (four more submissions go through afterwards)."""
+    """RT_MAX_INFLIGHT (8; C2's default depth is 4) one-page submissions in flight, the page of the SECOND one is empty (ImageError
+    on the lane that gets it).  Its ticket returns that error; the submissions behind it complete with the results of a
+    synchronous call; one more submission while the cap is reached is refused without disturbing them; the cap is not leaked
+    (as many submissions again go through afterwards)."""
     sess = retto_amd.RettoSession(retto_amd.synthetic_session_config(0))
     try:
         lib = sess._hd.lib
@@ -1116,17 +1135,21 @@ def test_submit_ahead_at_the_cap_with_a_failing_submission():
                                   np.stack([d.boxes.as_array().reshape(8) for d in ref[i].det_result]))
             lib.rt_results_free(r)
 
-        tickets = [submit(0), submit(1, h=0), submit(2), submit(3)]
+        cap = retto_amd.RT_MAX_INFLIGHT
+        assert cap >= 5
+        order = [0, 1, 2, 3] + [k % 4 for k in range(4, cap)]
+        tickets = [submit(i, h=0) if k == 1 else submit(i) for k, i in enumerate(order)]
         with pytest.raises(retto_amd.RettoError):   # the cap: refused, nothing queued
             submit(0)
-        check(sess.wait_batch_raw(tickets[0]), 0)
-        with pytest.raises(retto_amd.ImageError):
-            sess.wait_batch_raw(tickets[1])
-        check(sess.wait_batch_raw(tickets[2]), 2)
-        check(sess.wait_batch_raw(tickets[3]), 3)
-        again = [submit(i) for i in range(4)]
+        for k, (i, t) in enumerate(zip(order, tickets)):
+            if k == 1:
+                with pytest.raises(retto_amd.ImageError):
+                    sess.wait_batch_raw(t)
+            else:
+                check(sess.wait_batch_raw(t), i)
+        again = [submit(i % 4) for i in range(cap)]
         for i, t in enumerate(again):
-            check(sess.wait_batch_raw(t), i)
+            check(sess.wait_batch_raw(t), i % 4)
         assert [len(p.det_result) for p in sess.run_batch(pages, det_map_override=maps)] == [len(p.det_result) for p in ref]
     finally:
         sess.close()
