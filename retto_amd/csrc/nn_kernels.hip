@@ -2705,11 +2705,136 @@ __global__ __launch_bounds__(256) void k_attention_line(const float* __restrict_
     }
   }
 }
+// Round 6: the same attention on the matrix pipe (v_mfma_f32_16x16x4_f32), lines of <= 128 tokens (longer ones keep
+// k_attention_line).  A workgroup per line, two passes of four heads (K and V of four heads x <= 128 keys = 64 KB of LDS as
+// [key][head][16 floats], slot 15 zero), wave w = head 4 pass + w.  Per (16-query, 16-key) tile:
+//   S^T = K_tile Q^T      4 MFMAs: lane (r, q4) feeds K[key r][4 q4 .. + 3] (one ds_read_b128) and Q[query r][4 q4 .. + 3] -- MFMA
+//                         step s pairs channel 4 q4 + s of both operands, any pairing is a dot product -- and receives
+//                         S[keys 4 q4 .. + 3][query r];
+//   online softmax        per query = per lane column: tile maximum over the lane's four keys and the three other lane rows of
+//                         its column (two shuffles), one correction factor and four exponentials per lane;
+//   O^T += V^T P          4 MFMAs: P is the MFMA's pixel operand AS IT STANDS in the accumulator layout (step e takes element e:
+//                         key 4 q4 + e), V^T comes from LDS with the same key order; lane (r, q4) holds O[query r][4 q4 .. + 3].
+// The per-lane partial sums of the softmax denominator meet once at the end.  Same mathematics as k_attention_line in another
+// summation order (fp32 tolerance; tests/test_gpu_parity.py::test_rec_net).
+template <int HD>
+__global__ __launch_bounds__(512) void k_attention_mfma(const float* __restrict__ qkv, const ImgGeom* __restrict__ geom,
+                                                        int heads, float* __restrict__ out) {
+  static_assert(HD <= 16, "a head's row is padded to 16 floats");
+  extern __shared__ __attribute__((aligned(16))) float att_lds[];
+  const ImgGeom g = geom[blockIdx.x];
+  const int T = g.H * g.W, C = heads * HD;
+  if (T <= 0) return;
+  const int Tp = (T + 15) & ~15;
+  // [Tp keys][4 heads x 16 floats + 4 pad]: 68 floats per key (padding the key rows to 68 floats against the fragment reads' bank conflicts measured
+  // slower: 0.069 vs 0.061 ms per launch)
+  constexpr int KP = 64;
+  float* ks = att_lds;
+  float* vs = att_lds + (size_t)Tp * KP;
+  // 8 waves: wave = head of the pass (w & 3) x half of the query-tile pairs (w >> 2): a long line's chain per wave halves
+  const int tid = threadIdx.x, lane = tid & 63, wave = (tid >> 6) & 3, qhalf = tid >> 8, r = lane & 15, q4 = lane >> 4;
+  const float scale = 1.0f / sqrtf((float)HD);
+  const int qt = Tp >> 4;
+  // slot 15 of every row and the rows of keys >= T stay zero for the whole kernel (the staging below writes real entries only)
+  for (int i = tid; i < Tp * (2 * KP / 4); i += 512) reinterpret_cast<f32x4*>(att_lds)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int pass = 0; pass * 4 < heads; pass++) {
+    const int h0 = pass * 4, nh = min(4, heads - h0);
+    __syncthreads();   // (the zero fill / the previous pass's readers are done)
+    // stage K and V of the pass's heads: their channels are nh * HD contiguous floats of a token's K / V projection, fetched as
+    // 16-byte chunks (a token's three projections are 3 C contiguous floats; h0 * HD * 4 bytes is a multiple of 16 for HD = 15,
+    // h0 = 0 / 4) and scattered to [key][head][d]
+    const int nch = (nh * HD + 3) >> 2;
+    for (int i = tid; i < T * nch; i += 512) {
+      const int kk = i / nch, j = i - kk * nch;
+      const float* row = qkv + (g.off + kk) * 3 * C + h0 * HD + 4 * j;
+      const f32x4 kq = *reinterpret_cast<const f32x4*>(row + C), vq = *reinterpret_cast<const f32x4*>(row + 2 * C);
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        const int c = 4 * j + e, hh = c / HD, d = c - hh * HD;
+        if (hh < nh) { ks[kk * KP + hh * 16 + d] = kq[e]; vs[kk * KP + hh * 16 + d] = vq[e]; }
+      }
+    }
+    __syncthreads();
+    if (wave >= nh) continue;
+    const int head = h0 + wave;
+    // two query tiles at a time: their chains (MFMA -> shuffles -> exponentials -> MFMA, serial over the key tiles) are independent
+    // and interleave in the wave's instruction stream
+    for (int qi = 2 * qhalf; qi < qt; qi += 4) {
+      int tq[2];
+      f32x4 qf[2], o[2];
+      float m[2], l[2];
+#pragma unroll
+      for (int u = 0; u < 2; u++) {
+        tq[u] = (qi + u) * 16 + r;          // this lane's query (column of every tile)
+        qf[u] = f32x4{0.f, 0.f, 0.f, 0.f}; o[u] = qf[u]; m[u] = -INFINITY; l[u] = 0.f;
+        if (tq[u] < T) {
+          const float* qrow = qkv + (g.off + tq[u]) * 3 * C + head * HD + 4 * q4;
+#pragma unroll
+          for (int e = 0; e < 4; e++)
+            if (4 * q4 + e < HD) qf[u][e] = qrow[e] * scale;
+        }
+      }
+      for (int ki = 0; ki < qt; ki++) {
+        const f32x4 kf = *reinterpret_cast<const f32x4*>(ks + (ki * 16 + r) * KP + wave * 16 + 4 * q4);
+        float ve[4];
+#pragma unroll
+        for (int e = 0; e < 4; e++) ve[e] = vs[(ki * 16 + 4 * q4 + e) * KP + wave * 16 + r];   // V^T[channel r][key 4 q4 + e]
+        const int kb = ki * 16 + 4 * q4;
+        f32x4 sv[2], pv[2];
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+          sv[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int st = 0; st < 4; st++) sv[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[st], qf[u][st], sv[u], 0, 0, 0);
+        }
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+#pragma unroll
+          for (int e = 0; e < 4; e++)
+            if (kb + e >= T) sv[u][e] = -INFINITY;   // keys beyond T do not take part
+          float tm = fmaxf(fmaxf(sv[u][0], sv[u][1]), fmaxf(sv[u][2], sv[u][3]));
+          tm = fmaxf(tm, __shfl_xor(tm, 16, 64));
+          tm = fmaxf(tm, __shfl_xor(tm, 32, 64));
+          const float mn = fmaxf(m[u], tm);     // (finite: key 0 of tile 0 exists)
+          const float corr = __expf(m[u] - mn);
+#pragma unroll
+          for (int e = 0; e < 4; e++) pv[u][e] = __expf(sv[u][e] - mn);
+          l[u] = l[u] * corr + ((pv[u][0] + pv[u][1]) + (pv[u][2] + pv[u][3]));
+          o[u] *= corr;
+          m[u] = mn;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; e++)
+#pragma unroll
+          for (int u = 0; u < 2; u++) o[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(ve[e], pv[u][e], o[u], 0, 0, 0);
+      }
+#pragma unroll
+      for (int u = 0; u < 2; u++) {
+        l[u] += __shfl_xor(l[u], 16, 64);
+        l[u] += __shfl_xor(l[u], 32, 64);
+        if (tq[u] < T) {
+          const float inv = 1.0f / l[u];
+          float* orow = out + (g.off + tq[u]) * C + head * HD + 4 * q4;
+#pragma unroll
+          for (int e = 0; e < 4; e++)
+            if (4 * q4 + e < HD) orow[e] = o[u][e] * inv;
+        }
+      }
+    }
+  }
+}
 int g_attention_line = getenv("RT_ATT_LINE") ? atoi(getenv("RT_ATT_LINE")) : 1;   // A/B: 0 = k_attention (one wave per 64 queries and head)
 void attention(hipStream_t st, const float* qkv, const ImgGeom* geom, int n_img, int maxT, int heads, int hd,
                float* out) {
   if (n_img <= 0) return;
   if (hd != 15) throw RtError(8, "attention: head dim must be 15");
+  static const int att_mfma = getenv("RT_ATT_MFMA") ? atoi(getenv("RT_ATT_MFMA")) : 1;   // A/B: 0 = k_attention_line for every line
+  if (att_mfma && g_attention_line && maxT <= 128 && heads <= 8) {
+    const size_t lds = (size_t)2 * ((maxT + 15) & ~15) * 64 * 4;   // K and V of four heads: 64 KB at 128 tokens
+    allow_big_lds((const void*)k_attention_mfma<15>, 64 * 1024);
+    RT_LAUNCH(k_attention_mfma<15>, dim3((unsigned)n_img), dim3(512), lds, st, qkv, geom, heads, out);
+    return;
+  }
   if (g_attention_line && (heads * hd) % 4 == 0 && heads <= 8) {
     const size_t lds = (size_t)2 * 64 * heads * 16 * 4;   // 64 KB at 8 heads
     allow_big_lds((const void*)k_attention_line<15>, 64 * 1024);
