@@ -817,8 +817,8 @@ def main():
     if other_rate is not None:
         out["pages_on_host" if not on_host else "pages_on_hbm"] = {
             "value": round(other_rate * (world if not global_mode else 1), 3), "unit": "images/s",
-            "note": "rank 0, x%d ranks: %s" % (world, ("the pages start in host memory: 2.76 MB per 960^2 page cross PCIe inside the timed region (pageable memory, "
-                    "hipMemcpyAsync on the lane's stream); own warm-up, >= 20 steps, %d batches in flight; the planted maps (benchmark scaffolding) stay in HBM" % max(1, a.inflight))
+            "note": "rank 0, x%d ranks: %s" % (world, ("the pages start in host memory: 2.76 MB per 960^2 page cross PCIe inside the timed region (pageable memory; rt_submit_batch "
+                    "stages them into HBM on a copy stream, one batch ahead of the lanes); own warm-up, >= 20 steps, %d batches in flight; the planted maps (benchmark scaffolding) stay in HBM" % max(1, a.inflight))
                     if not on_host else "the pages start in HBM")}
     if split_leg:
         out["split_bf16"] = split_leg

@@ -190,7 +190,12 @@ RT_API int rt_run_batch_stream(rt_session* s, const uint8_t* const* rgb, const i
  * work.  The argument ARRAYS are copied by rt_submit_batch; the PAGES (and override maps) they point to must stay valid and
  * unchanged until rt_wait_batch has returned for that ticket.  Every ticket must be waited for exactly once (any order); until
  * then every other call on the session except rt_submit_batch / rt_wait_batch fails with RT_ERR_INVALID.  rt_wait_batch of a
- * failed batch returns the failing stage's status (the other batches in flight are not affected). */
+ * failed batch returns the failing stage's status (the other batches in flight are not affected).
+ * Host pages (RT_MEM_HOST, RT_MEM_HOST_MAPS_DEVICE) are copied to HBM by rt_submit_batch itself, on a copy stream of the session,
+ * part by part right before each lane's job is queued: with a batch submitted ahead the transfer of batch i + 1 runs under the
+ * kernels of batch i, and no lane waits for PCIe with an empty stream.  The session keeps one staging buffer per batch in flight
+ * (the batch's page bytes; reused).  From pageable memory the copy has completed when rt_submit_batch returns; from pinned memory
+ * it is asynchronous -- either way the rule above (pages unchanged until rt_wait_batch) is the contract. */
 #define RT_MAX_INFLIGHT 8   /* (a cap on queued tickets only: a lane works on one part at a time, whatever is queued behind it) */
 typedef struct rt_ticket rt_ticket;
 RT_API int rt_submit_batch(rt_session* s, const uint8_t* const* rgb, const int* hs, const int* ws, int n_pages, int mem,

@@ -131,6 +131,7 @@ void rt_destroy(rt_session* s) {
     if (h->st_full) (void)hipStreamDestroy(h->st_full);
   }
   s->helpers.clear();
+  s->free_stage();
   s->det.reset(); s->cls.reset(); s->rec.reset();
   if (s->d_flags) (void)hipFree(s->d_flags);
   if (s->ev_block) (void)hipEventDestroy(s->ev_block);

@@ -563,7 +563,7 @@ rt_results* rt_session::run_pages(const uint8_t* const* rgb, const int* hs, cons
     p.ori_h = hs[i]; p.ori_w = ws[i];
     if (hs[i] <= 0 || ws[i] <= 0 || rgb[i] == nullptr) throw RtError(RT_ERR_IMAGE, "empty page");
     const uint8_t* raw = rgb[i];
-    if (mem != RT_MEM_DEVICE) {   // (RT_MEM_HOST, RT_MEM_HOST_MAPS_DEVICE: the pages cross PCIe)
+    if (mem == RT_MEM_HOST || mem == RT_MEM_HOST_MAPS_DEVICE) {   // the pages cross PCIe here (a submitted batch staged them already)
       uint8_t* d = arena.alloc<uint8_t>((size_t)hs[i] * ws[i] * 3);
       RT_HIP_CHECK(hipMemcpyAsync(d, rgb[i], (size_t)hs[i] * ws[i] * 3, hipMemcpyHostToDevice, st));
       raw = d;
@@ -647,7 +647,7 @@ rt_results* rt_session::run_pages(const uint8_t* const* rgb, const int* hs, cons
       PageState& p = pg[i];
       const float* pred = p.map;
       if (det_map_override && det_map_override[i]) {
-        if (mem == RT_MEM_HOST) {
+        if (mem == RT_MEM_HOST || mem == RT_MEM_STAGED_MAPS_HOST) {
           float* d = arena.alloc<float>((size_t)p.det_h * p.det_w);
           RT_HIP_CHECK(hipMemcpyAsync(d, det_map_override[i], (size_t)p.det_h * p.det_w * 4, hipMemcpyHostToDevice, st));
           pred = d;
@@ -929,6 +929,65 @@ void rt_session::ensure_workers() {
   }
 }
 
+// ---- page staging ----------------------------------------------------------------------------------------------------------
+// A lane that uploads its own pages blocks its host thread in hipMemcpyAsync (pageable memory: the call returns when the copy is
+// done) with nothing queued on its stream: about 3 ms per 11-page part.  rt_submit_batch therefore copies the host pages of the
+// whole batch itself, on a copy stream, into a slot of HBM the session keeps per batch in flight; the lanes' streams wait for the
+// slot's event.  With one batch submitted ahead the copy of batch i+1 runs on the DMA engines under the kernels of batch i.
+void rt_session::stage_pages(rt_ticket* t) {
+  if (t->mem != RT_MEM_HOST && t->mem != RT_MEM_HOST_MAPS_DEVICE) return;
+  size_t total = 0;
+  std::vector<size_t> off((size_t)t->n_pages, (size_t)-1);
+  for (int i = 0; i < t->n_pages; i++) {
+    if (t->hs[i] <= 0 || t->ws[i] <= 0 || !t->rgb[i]) continue;   // left to the lane, which reports it as the reference does
+    off[(size_t)i] = total;
+    total += ((size_t)t->hs[i] * t->ws[i] * 3 + 255) & ~(size_t)255;
+  }
+  if (!total) return;
+  int slot = -1;
+  for (size_t k = 0; k < stage_slots.size(); k++) if (!stage_slots[k].busy) { slot = (int)k; break; }
+  if (slot < 0) { stage_slots.emplace_back(); slot = (int)stage_slots.size() - 1; }
+  StageSlot& S = stage_slots[(size_t)slot];
+  if (!st_copy) RT_HIP_CHECK(hipStreamCreateWithFlags(&st_copy, hipStreamNonBlocking));
+  while ((int)S.ev.size() < t->nl) {
+    hipEvent_t e = nullptr;
+    RT_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    S.ev.push_back(e);
+  }
+  if (S.cap < total) {
+    if (S.p) { (void)hipFree(S.p); S.p = nullptr; S.cap = 0; }
+    if (hipMalloc((void**)&S.p, total) != hipSuccess) { (void)hipGetLastError(); S.p = nullptr; return; }   // the lanes copy, as before
+    S.cap = total;
+  }
+  S.busy = true;
+  t->stage_slot = slot;
+  t->stage_off = std::move(off);
+  t->ev_up.assign(S.ev.begin(), S.ev.begin() + t->nl);
+  t->mem_lane = t->mem == RT_MEM_HOST ? RT_MEM_STAGED_MAPS_HOST : RT_MEM_DEVICE;
+}
+// the part's pages go up right before its lane job is queued: the first lane starts after its own pages, not after the batch's
+void rt_session::stage_part(rt_ticket* t, int l) {
+  if (t->stage_slot < 0) return;
+  StageSlot& S = stage_slots[(size_t)t->stage_slot];
+  for (int i = t->first[l]; i < t->first[l + 1]; i++) {
+    const size_t o = t->stage_off[(size_t)i];
+    if (o == (size_t)-1) continue;
+    RT_HIP_CHECK(hipMemcpyAsync(S.p + o, t->rgb[i], (size_t)t->hs[i] * t->ws[i] * 3, hipMemcpyHostToDevice, st_copy));
+    t->rgb[i] = S.p + o;
+  }
+  RT_HIP_CHECK(hipEventRecord(t->ev_up[(size_t)l], st_copy));
+}
+void rt_session::release_stage(rt_ticket* t) {
+  if (t->stage_slot >= 0) stage_slots[(size_t)t->stage_slot].busy = false;
+  t->stage_slot = -1;
+}
+void rt_session::free_stage() {
+  if (st_copy) (void)hipStreamSynchronize(st_copy);
+  for (auto& S : stage_slots) { if (S.p) (void)hipFree(S.p); for (hipEvent_t e : S.ev) (void)hipEventDestroy(e); }
+  stage_slots.clear();
+  if (st_copy) { (void)hipStreamDestroy(st_copy); st_copy = nullptr; }
+}
+
 rt_ticket* rt_session::submit_batch(const uint8_t* const* rgb, const int* hs, const int* ws, int n_pages, int mem,
                                     const float* const* det_map_override, rt_stage_callback cb, void* user) {
   ensure_workers();
@@ -959,7 +1018,10 @@ rt_ticket* rt_session::submit_batch(const uint8_t* const* rgb, const int* hs, co
     for (int k = 1; k <= nl; k++) t->first[k] = std::max(t->first[k], t->first[k - 1]);
   }
   t->remaining = nl;
+  t->mem_lane = mem;
   rt_ticket* tp = t.get();
+  static const bool no_stage = getenv("RT_NO_STAGE") && atoi(getenv("RT_NO_STAGE"));   // (A/B switch of the measurement in DESIGN.md)
+  if (!no_stage) stage_pages(tp);
   // parts go to consecutive lanes starting behind the previous batch's last one: batches that fill fewer lanes than the session
   // has (single pages: one lane each) run side by side instead of queueing on lane 0
   const int total_lanes = (int)helpers.size() + 1;
@@ -972,6 +1034,7 @@ rt_ticket* rt_session::submit_batch(const uint8_t* const* rgb, const int* hs, co
   for (int l = 0; l < nl; l++) {
     const int li = (base + l) % total_lanes;
     rt_session* s = li == 0 ? this : helpers[(size_t)li - 1].get();
+    stage_part(tp, l);
     workers[(size_t)li]->push([tp, s, l, use_parts] {
       const int f0 = tp->first[l], f1 = tp->first[l + 1];
       s->stage_cb = tp->cb; s->stage_user = tp->user; s->stage_mu = &tp->cb_mu; s->page_base = f0;
@@ -980,7 +1043,8 @@ rt_ticket* rt_session::submit_batch(const uint8_t* const* rgb, const int* hs, co
       s->st = (s->st_part && use_parts) ? s->st_part : s->st_full;
       s->on_lane_worker = true;
       try {
-        tp->parts[l] = s->run_pages(tp->rgb.data() + f0, tp->hs.data() + f0, tp->ws.data() + f0, f1 - f0, tp->mem,
+        if (!tp->ev_up.empty()) RT_HIP_CHECK(hipStreamWaitEvent(s->st, tp->ev_up[(size_t)l], 0));
+        tp->parts[l] = s->run_pages(tp->rgb.data() + f0, tp->hs.data() + f0, tp->ws.data() + f0, f1 - f0, tp->mem_lane,
                                     tp->maps.empty() ? nullptr : tp->maps.data() + f0);
       } catch (...) {
         tp->errs[l] = std::current_exception();
@@ -1007,6 +1071,7 @@ rt_ticket* rt_session::submit_batch(const uint8_t* const* rgb, const int* hs, co
       tp->cv.wait(lk, [&] { return tp->remaining == 0; });
     }
     for (auto* r : tp->parts) delete r;
+    release_stage(tp);
     throw;
   }
   inflight.fetch_add(1);
@@ -1020,6 +1085,7 @@ rt_results* rt_session::wait_batch(rt_ticket* tp) {
     t->cv.wait(lk, [&] { return t->remaining == 0; });
   }
   inflight.fetch_sub(1);
+  release_stage(t.get());   // (every lane has drained its stream: nothing reads the slot any more)
   std::unique_ptr<rt_results> res(new rt_results());
   std::exception_ptr err;
   for (int l = 0; l < t->nl; l++) {

@@ -65,7 +65,16 @@ struct rt_ticket {
   std::mutex mu;
   std::condition_variable cv;
   int remaining = 0;
+  // host pages staged by rt_submit_batch itself (session.cpp "page staging"): rgb[] then holds device addresses inside the
+  // session's staging slot `stage_slot`, and the lanes wait for `ev_up` on their streams instead of copying
+  int stage_slot = -1;
+  int mem_lane = 0;                 // what the lanes are told: mem, or pages-on-device once staged
+  std::vector<size_t> stage_off;    // per page: offset inside the slot, (size_t)-1 = not staged (empty page)
+  std::vector<hipEvent_t> ev_up;    // per lane part; owned by the staging slot
 };
+
+// internal to the library (never accepted from a caller): pages already in HBM, det map overrides still host pointers
+#define RT_MEM_STAGED_MAPS_HOST 3
 
 struct rt_session {
   rt_config cfg{};
@@ -128,6 +137,15 @@ struct rt_session {
   std::atomic<int> inflight{0};
   int next_lane = 0;               // first lane of the next submitted batch
   bool failed = false;             // the lane's previous call threw: its arena statistics are discarded at the next begin_call
+  // page staging: host pages of a submitted batch are copied to HBM by the submitting thread on a copy stream of their own, one
+  // batch ahead of the lanes that read them (slots are reused; one per batch in flight)
+  struct StageSlot { uint8_t* p = nullptr; size_t cap = 0; std::vector<hipEvent_t> ev; bool busy = false; };
+  std::vector<StageSlot> stage_slots;
+  hipStream_t st_copy = nullptr;
+  void stage_pages(rt_ticket* t);          // picks the slot
+  void stage_part(rt_ticket* t, int l);    // copies the pages of lane part l
+  void release_stage(rt_ticket* t);
+  void free_stage();
   void ensure_workers();
   rt_ticket* submit_batch(const uint8_t* const* rgb, const int* hs, const int* ws, int n_pages, int mem,
                           const float* const* det_map_override, rt_stage_callback cb = nullptr, void* user = nullptr);

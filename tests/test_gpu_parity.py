@@ -1010,6 +1010,53 @@ def test_submit_wait_equals_run_batch(hip_session):
     assert hip_session.worker.cls(np.zeros((1, 3, 48, 192), np.float32)).shape == (1, 2)
 
 
+def test_staged_host_pages_equal_pages_in_hbm(hip_session):
+    """rt_submit_batch copies host pages to HBM itself, on a copy stream, one batch ahead of the lanes (session.cpp "page
+    staging").  The three memory modes -- pages and maps on the host, pages on the host with maps in HBM, everything in HBM --
+    must give the same bytes, over more batches in flight than staging slots existed before (slots are created, grown and
+    reused) and with batches of different total size."""
+    import torch
+    lib = hip_session._hd.lib
+    batches = []
+    for b, shapes in enumerate((((352, 512, 3), (640, 480, 5)), ((640, 640, 6), (480, 704, 4), (352, 512, 3), (640, 480, 5), (320, 480, 2)),
+                                ((736, 416, 4),))):
+        pages, maps = [], []
+        for i, (h, w, L) in enumerate(shapes):
+            page, rects = workload.planted_page(h, w, L, seed=700 + 10 * b + i)
+            dh, dw = R.resize_either_dims(h, w)
+            pages.append(page); maps.append(workload.planted_map(dh, dw, h, w, rects))
+        batches.append((pages, maps))
+
+    def digest(r, n):
+        return [hip_session._collect(r, i) for i in range(n)]
+
+    def same(a, b):
+        assert len(a) == len(b)
+        for x, y in zip(a, b):
+            assert len(x.det_result) == len(y.det_result) > 0
+            assert [d.boxes.as_array().tobytes() for d in x.det_result] == [d.boxes.as_array().tobytes() for d in y.det_result]
+            assert [c.label.label for c in x.cls_result] == [c.label.label for c in y.cls_result]
+            assert [(t.text, np.float32(t.score).tobytes()) for t in x.rec_result] == [(t.text, np.float32(t.score).tobytes()) for t in y.rec_result]
+
+    dev = [([torch.from_numpy(p).cuda() for p in pages], [torch.from_numpy(m).cuda() for m in maps]) for pages, maps in batches]
+    torch.cuda.synchronize()
+    ref = []
+    for (pages, maps), (dp, dm) in zip(batches, dev):
+        r = hip_session.run_batch_raw([t.data_ptr() for t in dp], [p.shape[0] for p in pages], [p.shape[1] for p in pages],
+                                      retto_amd.RT_MEM_DEVICE, [t.data_ptr() for t in dm])
+        ref.append(digest(r, len(pages))); lib.rt_results_free(r)
+    for mode in (retto_amd.RT_MEM_HOST, retto_amd.RT_MEM_HOST_MAPS_DEVICE):
+        for rounds in range(2):   # the second round reuses the slots of the first
+            tickets = []
+            for k in (1, 0, 2, 1, 2, 0):   # six batches in flight, sizes going up and down
+                pages, maps = batches[k]
+                mm = maps if mode == retto_amd.RT_MEM_HOST else [t.data_ptr() for t in dev[k][1]]
+                tickets.append((k, hip_session.submit_batch_raw(pages, [p.shape[0] for p in pages], [p.shape[1] for p in pages], mode, mm)))
+            for k, t in reversed(tickets):
+                r = hip_session.wait_batch_raw(t)
+                same(digest(r, len(batches[k][0])), ref[k]); lib.rt_results_free(r)
+
+
 def test_submit_wait_against_the_oracle_teacher_forced(hip_session, oracle_session):
     """The TIMED path itself (bench.py times rt_submit_batch / rt_wait_batch with two batches in flight) compared with the
     oracle directly, not through rt_run_batch: two batches submitted ahead, waited in reverse order, every page against
