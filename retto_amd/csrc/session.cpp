@@ -944,6 +944,7 @@ void rt_session::stage_pages(rt_ticket* t) {
     total += ((size_t)t->hs[i] * t->ws[i] * 3 + 255) & ~(size_t)255;
   }
   if (!total) return;
+  RT_HIP_CHECK(hipSetDevice(device));   // (the caller's thread: nothing else has chosen the device on the submit path)
   int slot = -1;
   for (size_t k = 0; k < stage_slots.size(); k++) if (!stage_slots[k].busy) { slot = (int)k; break; }
   if (slot < 0) { stage_slots.emplace_back(); slot = (int)stage_slots.size() - 1; }

@@ -152,6 +152,22 @@ def test_rec_net_split_bf16(hip_session, oracle_session, n, w):
     assert decisive.mean() > 0.9
 
 
+@pytest.mark.parametrize("M", [131072 + 1, 131072 + 255, 140003, 200000 + 8 * 31])
+def test_wide_gemms_with_a_partial_last_row_block(hip_session, M):
+    """The persistent wide GEMMs on row counts that end inside a tile (256 rows for k_gemm32p, 128 for k_gemm_split; the rows past
+    M are range-checked by the buffer descriptor of the wave's requests -- ADVICE round 5): k_gemm32p is bit-identical to the
+    narrow fp32 kernel over the first and the last 4 M outputs (rt_bench_gemm compares exactly those), the split-bf16 kernel within
+    its error bound, for K = N = 240 and for the 480-channel shape."""
+    import ctypes as C
+    lib, h = hip_session._hd.lib, hip_session._hd.h
+    lib.rt_bench_gemm.argtypes = [C.c_void_p, C.c_longlong, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    for K, N in ((240, 240), (480, 480)):
+        for variant, bound in ((30, 0.0), (40, 2e-5)):
+            ms, md = C.c_float(), C.c_float(-1)
+            assert lib.rt_bench_gemm(h, M, K, N, variant, 1, C.byref(ms), C.byref(md)) == 0, lib.rt_last_error(h)
+            assert 0.0 <= md.value <= bound, (M, K, N, variant, md.value)
+
+
 def test_rec_net_split_bf16_is_repeatable(hip_session):
     """Race screen for the hand-kept vmcnt bookkeeping of k_gemm_split (run-time counts of the operations that may stay in flight at
     every barrier wait, a dynamic tile queue, LDS-DMA rings): a fragment read that overtakes its request, or a request that
