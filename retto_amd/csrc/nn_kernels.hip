@@ -1469,7 +1469,9 @@ __global__ __launch_bounds__(256, 4) void k_dwconv_rows(const float* __restrict_
 // order per output (bias, taps in (dy, dx) order): bit-identical.  Measured on the 1.23 M-pixel 256-channel maps (k_dwconv_rows
 // 0.621 ms): PX = 4 at 3 waves / SIMD 0.543 ms (4.64 TB/s), PX = 2 at 4 waves / SIMD 0.567; a first form that loaded the
 // columns one tap column ahead (dx-outer loop) ran 0.674 -- the eight loads of a row must be in flight together.
+// Round 6: buffer-descriptor addressing (below) 0.533 -> 0.519 ms; PX = 4 at 4 waves / SIMD still spills (300 bytes of scratch).
 // ---------------------------------------------------------------------------
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 template <int K, int LP, int PX, int WAVES>
 __global__ __launch_bounds__(256, WAVES) void k_dwconv_sweep(const float* __restrict__ x, const ImgGeom* __restrict__ gin,
                                                            const ImgGeom* __restrict__ gout, int Cp, int C,
@@ -1499,22 +1501,37 @@ __global__ __launch_bounds__(256, WAVES) void k_dwconv_sweep(const float* __rest
   for (int r = 0; r < K; r++)
 #pragma unroll
     for (int j = 0; j < PX; j++) acc[r][j] = b;
-  const float* xcol = x + gi.off * Cp + ch;
-  float* ycol = y + (go.off + ox0) * Cp + ch;
+  // Addresses: one buffer descriptor per ROW (its base is uniform: scalar registers; num_records = the row's bytes) + a 32-bit
+  // per-lane byte offset that does not depend on the row.  Columns right of the map are out of the descriptor's range -- loads
+  // return zeros, stores are dropped -- and columns left of it carry the out-of-range mark: no per-load test or branch is left.
+  // (The first form kept 64-bit per-lane pointers and laundered the running column pointer through an asm operand to keep hipcc
+  // from precomputing and spilling the 64-bit column addresses of every row; a pointer that went through an asm operand loses its
+  // address space, so every load was a flat_load -- counted in lgkmcnt as well, which made the waits for the taps' LDS reads wait
+  // for the row in flight.)
+  unsigned loff[NV];   // column ox0 - P + j, this lane's 4 channels
+#pragma unroll
+  for (int j = 0; j < NV; j++) loff[j] = ox0 - P + j >= 0 ? (unsigned)((ox0 - P + j) * Cp + ch) * 4u : 0x80000000u;
+  auto uni_ptr = [](const float* p_) {   // (the image geometry comes from a load indexed by blockIdx: made scalar explicitly)
+    const unsigned long long v = (unsigned long long)p_;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return (float*)(((unsigned long long)hi << 32) | lo);
+  };
+  const float* xim = uni_ptr(x + gi.off * Cp);
+  float* yim = uni_ptr(y + go.off * Cp);
+  const unsigned row_bytes = (unsigned)__builtin_amdgcn_readfirstlane(gi.W * Cp * 4);
   act_dispatch(act, has_lab, false, [&](auto at, auto lt, auto) {
     constexpr int A = decltype(at)::value, L = decltype(lt)::value;
     auto store_row = [&](int oy, f32x4 (&a)[PX]) __attribute__((always_inline)) {
+      const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(yim + (long long)oy * go.W * Cp, 0, row_bytes, 0x00020000);
 #pragma unroll
       for (int j = 0; j < PX; j++) {
-        if (ox0 + j < go.W) {
-          f32x4 o;
+        f32x4 o;
 #pragma unroll
-          for (int e = 0; e < 4; e++) {
-            const float t = epi_val<A, L>(a[j][e], act, has_lab, lab_a, lab_c);
-            o[e] = (ch + e < C) ? t : 0.f;  // pitch padding (chan_pitch) holds zeros whatever the input padding held
-          }
-          *reinterpret_cast<f32x4*>(ycol + ((long long)oy * go.W + j) * Cp) = o;
+        for (int e = 0; e < 4; e++) {
+          const float t = epi_val<A, L>(a[j][e], act, has_lab, lab_a, lab_c);
+          o[e] = (ch + e < C) ? t : 0.f;  // pitch padding (chan_pitch) holds zeros whatever the input padding held
         }
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), yrs, loff[j + P], 0, 0);
         a[j] = b;
       }
     };
@@ -1523,18 +1540,10 @@ __global__ __launch_bounds__(256, WAVES) void k_dwconv_sweep(const float* __rest
       for (int u = 0; u < K; u++) {
         const int i = i0 + u;   // input row; feeds output rows i - P .. i + P through tap rows dy = K - 1 .. 0
         if (i < H) {
-          const float* row = xcol + (long long)i * gi.W * Cp;
-          // (one running column pointer, opaque to the optimiser: with row + ix * Cp hipcc precomputes the 64-bit column
-          //  offsets ahead of the row loop and spills them)
-          const float* colp = row + ((long long)ox0 - P) * Cp;
-          asm volatile("" : "+v"(colp));
+          const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xim) + (long long)i * gi.W * Cp, 0, row_bytes, 0x00020000);
           f32x4 v[NV];
 #pragma unroll
-          for (int j = 0; j < NV; j++) {
-            const int ix = ox0 + j - P;
-            v[j] = (ix >= 0 && ix < gi.W) ? *reinterpret_cast<const f32x4*>(colp) : f32x4{0.f, 0.f, 0.f, 0.f};
-            colp += Cp;
-          }
+          for (int j = 0; j < NV; j++) v[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, loff[j], 0, 0));
 #pragma unroll
           for (int dy = 0; dy < K; dy++) {
             const int r = i + P - dy;                  // output row fed through tap row dy
