@@ -393,7 +393,7 @@ __global__ __launch_bounds__(P_NTHR, 1) void k_gemm32p(const GemmPArgs g) {
     bool pub = false;
     if (!EPI && fetch_now) {
       if (wid == 0 && lane_id() == 0)
-        asm volatile("global_atomic_add %0, %1, %2, %3 sc0" : "=v"(fetched) : "v"((unsigned)(xq * 64)), "v"(1u), "s"(g.sched) : "memory");
+        asm volatile("s_nop 4\n\tglobal_atomic_add %0, %1, %2, %3 sc0" : "=v"(fetched) : "v"((unsigned)(xq * 64)), "v"(1u), "s"(g.sched) : "memory");
       fetch_now = false; pub = true;
       __builtin_amdgcn_sched_barrier(0);
     }
