@@ -116,8 +116,8 @@ constexpr unsigned S_ASLOT = S_NW * S_AWAVE;                    // 16 KB
 constexpr unsigned S_OFF_W = 2 * S_ASLOT, S_OFF_BIAS = S_OFF_W + 3 * S_WGRP;
 constexpr int S_BIAS_MAX = 240;                                 // one column block's bias (restaged per tile)
 constexpr unsigned S_OFF_TQ = S_OFF_BIAS + S_BIAS_MAX * 4;      // ids of the workgroup's tiles j, j + 1, ... (slot j & 3)
-constexpr unsigned S_OFF_SC = S_OFF_TQ + 16;                     // ASC: scale vectors of two slabs in flight, [slot][2 images][32] floats
-constexpr size_t S_LDS = S_OFF_TQ + 16, S_LDS_ASC = S_OFF_SC + 512;           // 32 KB pixels | 45 KB weights | bias | tile ids = 79824 bytes: two workgroups per CU
+constexpr unsigned S_OFF_SC = S_OFF_TQ + 16;                     // ASC: scale vectors of two slabs in flight, [wave][slot][2 images][32] floats
+constexpr size_t S_LDS = S_OFF_TQ + 16, S_LDS_ASC = S_OFF_SC + 2048;           // 32 KB pixels | 45 KB weights | bias | tile ids = 79824 bytes: two workgroups per CU
 
 struct GemmSArgs {
   const float* A; const unsigned short* Ws; float* C;
@@ -267,11 +267,17 @@ __global__ __launch_bounds__(S_NTHR, 2) void k_gemm_split(const GemmSArgs g) {
     if (!(DBG & 2) || dbg_pro) { blds16(((k & 1) ? rq_a1 : rq_a0) + (unsigned)k * pitch8, ars, aq_dst + k * 1024u, aq_so); vm_note(1); }
     if (ASC && k == 0) {
       sc_bnd[aq_slot] = sc_bnd_t;
-      if (wid == 0) {   // lane i: image sc_img + i / 32 (clamped), channel 32 slab + i % 32 (beyond K: out of range, zero)
+      {   // lane i: image sc_img + i / 32 (clamped), channel 32 slab + i % 32 (beyond K: out of range, zero).
+          // EVERY wave requests its own copy into its own slots, so that -- like the pixels -- the wave's vmcnt is the only
+          // hand-over.  (First form: wave 0 alone, one shared slot per ring parity, published by the group barriers.  After
+          // the prologue's __syncthreads the four waves read slot 0 for slab 0 and wave 0 went straight on to request slab 2's
+          // vectors INTO slot 0: with the session's other lanes running (cold instruction cache, contended memory) a wave could
+          // still be in front of its prologue reads when that request landed -- one text line of a 1024-line C3 batch came out
+          // different in ~3 % of the runs, tools/soak_split.py.  Four 256-byte requests per slab instead of one: +1 % on the launch.)
         const int kk = aq_p * 32 + (lane & 31);
         const int im = min(sc_img + (lane >> 5), g.n_img - 1);
         const unsigned off = kk < g.K ? (unsigned)(im * g.ld_scale + kk) * 4u : 0x80000000u;
-        blds4(off, srs, sc_dst0 + (unsigned)aq_slot * 256u); vm_note(1);
+        blds4(off, srs, sc_dst0 + (unsigned)(wid * 2 + aq_slot) * 256u); vm_note(1);
       }
     }
     if (k == 3) {
@@ -416,7 +422,7 @@ __global__ __launch_bounds__(S_NTHR, 2) void k_gemm_split(const GemmSArgs g) {
   auto split_into = [&](int mt, u32x4& h, u32x4& m, u32x4& l, int slot) __attribute__((always_inline)) {
     if (ASC) {   // the slab's scale vector of this lane's row's image: channels 4 q .. + 3 and 16 + 4 q .. + 3
       const int row = 32 * wid + 16 * mt + r;
-      const float* t = sc_lds + slot * 64 + (row >= sc_bnd[slot] ? 32 : 0) + 4 * q;
+      const float* t = sc_lds + (wid * 2 + slot) * 64 + (row >= sc_bnd[slot] ? 32 : 0) + 4 * q;
       raw[mt][0] *= *reinterpret_cast<const f32x4*>(t);
       raw[mt][1] *= *reinterpret_cast<const f32x4*>(t + 16);
     }
@@ -584,6 +590,8 @@ int g_gemm_split = getenv("RT_GEMM_SPLIT") ? atoi(getenv("RT_GEMM_SPLIT")) : 0; 
 
 bool gemm_split_supported(int lda, long long M, int K, int N, int Npad16, const Epilogue& epi) {
   if (epi.am_max || epi.residual) return false;
+  static const int only = getenv("RT_GS_ONLY") ? atoi(getenv("RT_GS_ONLY")) : 3;   // (triage: 1 = plain launches only, 2 = +se only)
+  if (!(only & (epi.a_scale ? 2 : 1))) return false;
   // squeeze-excite scale: a row-block table of either form, hardswish epilogue, images of >= 128 rows (what gemm_se_tile_rows() > 0 says)
   if (epi.a_scale && (!epi.a_tab || (epi.a_tab_stride != 2 && epi.a_tab_stride != 3) || epi.act != ACT_HSWISH || epi.n_img <= 0 || epi.ld_scale < K)) return false;
   if (Npad16 != N || N % S_BN != 0 || N > 960) return false;

@@ -1,6 +1,8 @@
 """GPU parity tests: the HIP path (through the C ABI) against the CPU oracle on the
 same seeded inputs.  Integer / byte / index results must be bit-exact; floating-point
 network outputs are compared with the tolerance written at each test."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -166,6 +168,24 @@ def test_wide_gemms_with_a_partial_last_row_block(hip_session, M):
             ms, md = C.c_float(), C.c_float(-1)
             assert lib.rt_bench_gemm(h, M, K, N, variant, 1, C.byref(ms), C.byref(md)) == 0, lib.rt_last_error(h)
             assert 0.0 <= md.value <= bound, (M, K, N, variant, md.value)
+
+
+@pytest.mark.parametrize("mode", ["split_bf16", "fp32_mfma"])
+def test_c3_batches_are_repeatable_with_three_lanes_and_batches_in_flight(mode):
+    """Race screen at the size and in the shape bench.py times (tools/soak_split.py): three C3 batches of 32 pages x 32 lines rotate,
+    submitted two ahead from host memory over three lanes; every batch must come out bit-identical to its first run.  With one
+    lane the kernels see an idle chip and a warm instruction cache; it took the lanes running side by side to show that
+    k_gemm_split's shared squeeze-excite slot could be overwritten in front of a late wave's prologue read (round 6: one line of
+    1024 different in ~3 % of the runs; every wave now requests its own copy)."""
+    import subprocess, sys
+    env = dict(os.environ)
+    env.pop("RT_GEMM_SPLIT", None)
+    if mode == "fp32_mfma":
+        env["SOAK_FP32"] = "1"
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "soak_split.py"), "90"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "0 differing batches" in r.stdout
 
 
 def test_rec_net_split_bf16_is_repeatable(hip_session):
