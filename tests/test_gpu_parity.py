@@ -170,7 +170,7 @@ def test_wide_gemms_with_a_partial_last_row_block(hip_session, M):
             assert 0.0 <= md.value <= bound, (M, K, N, variant, md.value)
 
 
-@pytest.mark.parametrize("mode", ["split_bf16", "fp32_mfma"])
+@pytest.mark.parametrize("mode", ["split_bf16", "fp32_mfma", "c5_f16"])
 def test_c3_batches_are_repeatable_with_three_lanes_and_batches_in_flight(mode):
     """Race screen at the size and in the shape bench.py times (tools/soak_split.py): three C3 batches of 32 pages x 32 lines rotate,
     submitted two ahead from host memory over three lanes; every batch must come out bit-identical to its first run.  With one
@@ -182,6 +182,8 @@ def test_c3_batches_are_repeatable_with_three_lanes_and_batches_in_flight(mode):
     env.pop("RT_GEMM_SPLIT", None)
     if mode == "fp32_mfma":
         env["SOAK_FP32"] = "1"
+    if mode == "c5_f16":   # the server graphs in fp16, 16 pages per batch
+        env["SOAK_C5"] = "1"; env["SOAK_PAGES"] = "16"
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "soak_split.py"), "90"], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]

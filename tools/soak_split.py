@@ -12,12 +12,14 @@ import numpy as np
 import retto_amd
 from retto_amd import workload
 
-s = retto_amd.RettoSession(retto_amd.synthetic_session_config(0, lanes=int(os.environ.get("SOAK_LANES", "0"))))
+C5 = bool(os.environ.get("SOAK_C5"))   # server graphs, fp16 (the split switch does nothing there)
+NP = int(os.environ.get("SOAK_PAGES", "32"))
+s = retto_amd.RettoSession(retto_amd.synthetic_session_config(0, lanes=int(os.environ.get("SOAK_LANES", "0")), **({"server": True, "dtype": "f16"} if C5 else {})))
 lib = s._hd.lib
 batches = []
 for b in range(3):
     pages, maps = [], []
-    for i in range(32):
+    for i in range(NP):
         p, r = workload.planted_page(960, 960, 32, seed=1000 * b + i)
         pages.append(p); maps.append(workload.planted_map(960, 960, 960, 960, r))
     batches.append((pages, maps))
@@ -57,7 +59,7 @@ def digest(r, n_pages):
 
 def submit(b):
     pages, maps = batches[b]
-    return s.submit_batch_raw(pages, [960] * 32, [960] * 32, retto_amd.RT_MEM_HOST, maps)
+    return s.submit_batch_raw(pages, [960] * NP, [960] * NP, retto_amd.RT_MEM_HOST, maps)
 
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 60
@@ -75,10 +77,10 @@ for it in range(steps + 2):
             break
         b, t = q.pop(0)
         r = s.wait_batch_raw(t)
-        d = digest(r, 32)
-        det = detail(r, 32) if (b not in ref or d != ref[b]) else None
+        d = digest(r, NP)
+        det = detail(r, NP) if (b not in ref or d != ref[b]) else None
         lib.rt_results_free(r)
-        assert d[1] >= 32 * 30, d
+        assert d[1] >= NP * 30, d
         if b not in ref:
             ref[b] = d; refd[b] = det
         elif d != ref[b]:
