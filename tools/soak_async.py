@@ -38,10 +38,12 @@ def digest(r, i):
     return hsh.hexdigest()[:16], n
 
 
-ref = []
+lib.rt_results_det_checksum.restype = C.c_double
+lib.rt_results_det_checksum.argtypes = [C.c_void_p]
+ref, ref_sum = [], []   # (the det network's output reaches the results only through the map checksum: the boxes come from the planted maps)
 for p, m in zip(pages, maps):
     r = s.run_batch_raw([p], [p.shape[0]], [p.shape[1]], retto_amd.RT_MEM_HOST, [m])
-    ref.append(digest(r, 0)); lib.rt_results_free(r)
+    ref.append(digest(r, 0)); ref_sum.append(lib.rt_results_det_checksum(r)); lib.rt_results_free(r)
 assert sum(n for _d, n in ref) > 0 and sum(1 for _d, n in ref if n > 0) >= len(ref) * 2 // 3, [n for _d, n in ref]
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 400
 free0 = None
@@ -59,6 +61,10 @@ for it in range(steps):
     for j in rng.permutation(len(tickets)):
         idx, t = tickets[int(j)]
         r = s.wait_batch_raw(t)
+        want = float(np.sum([ref_sum[i] for i in idx], dtype=np.float64)); got_sum = lib.rt_results_det_checksum(r)
+        # (1e-6: the sums are fp64, but at levels whose batch total reaches the wide-GEMM sizes the squeeze-excite means come from
+        #  the depthwise kernel's fused partial sums instead of k_pool_partial's -- another fp32 summation order, ~1e-8 on the map)
+        assert abs(got_sum - want) <= 1e-6 * abs(want), "iteration %d: det map checksum %.17g of a batch of %d, its pages alone sum to %.17g" % (it, got_sum, len(idx), want)
         for pos, i in enumerate(idx):
             got = digest(r, pos)
             assert got == ref[i], "iteration %d: page %d at position %d of a batch of %d differs from its own run" % (it, i, pos, len(idx))
